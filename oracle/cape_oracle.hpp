@@ -1,0 +1,137 @@
+// =====================================================================================================
+//  CAPE ORACLE  --  TEST INFRASTRUCTURE ONLY.  NOT PRODUCT CODE.
+//
+//  Dependency-free CPU restatement (C++17, libstdc++ only) of the reference's primitive extraction path
+//  (BaptisteHudyma/RGB-D-SLAM, src/features/primitives + the helpers it calls).  Only tests/, the
+//  smoke() check in __graft_entry__.py and the cpu_baseline leg of bench.py may load this library.
+//  The product (rgb-d-slam_amd/) never includes, links or calls anything in this directory.
+//
+//  PARITY STATUS: **parity unpinned**.  The reference cannot be compiled in this image (it needs Eigen3,
+//  OpenCV4, Boost.Geometry, TBB, FLANN and <format>; none are present and there is no network), and the
+//  reference's own test-suite holds no golden vector / known-answer test for this path.
+//  The third-party arithmetic the path relies on (Eigen 3.4.0 SelfAdjointEigenSolver<Matrix3d>, fixed-size
+//  reductions, Matrix3d::inverse, OpenCV 3x3 morphology borders, libstdc++ <random>) is restated from the
+//  published algorithms; the only pieces that ARE pinned here are libstdc++'s mt19937 /
+//  uniform_real_distribution (same implementation as the reference links) and closed-form known answers
+//  (depth quantisation values, thresholds, analytic planes) checked in tests/test_oracle_kat.py.
+//
+//  Every function cites the reference file:line it follows (paths relative to the reference root).
+//  Build: see oracle/Makefile  (g++ -O2 -std=c++17 -ffp-contract=off, no -ffast-math, no -march).
+// =====================================================================================================
+#pragma once
+#include <cfloat>
+#include <cstdint>
+#include <vector>
+
+namespace cape_oracle {
+
+// src/parameters.hpp:67-87 (detection constants) and the magic numbers quoted in SURVEY.md 8(a)
+constexpr unsigned kCell = 20;                         // depthMapPatchSize_px
+constexpr unsigned kPtsPerCell = kCell * kCell;        // 400
+constexpr double kMinSeedProportion = 0.8 / 100.0;     // minimumPlaneSeedProportion
+constexpr double kMinActivatedProportion = 0.65 / 100.0;
+constexpr float kMinZeroDepthProportion = 0.7f;
+constexpr float kMaxAngleForMerge_d = 18.0f;
+constexpr float kMaxDistForMerge_mm = 50.0f;
+constexpr float kCylSqrtMaxDist = 0.04f;
+constexpr float kCylMinScore = 75;
+constexpr float kCylInlierProp = 0.33f;
+constexpr float kCylPSuccess = 0.8f;
+
+struct Config
+{
+    int width = 640, height = 480;
+    double fx = 550, fy = 550, cx = 320, cy = 240; // Parameters::load_defaut, src/parameters.cpp:59-74
+    bool cylinders = true; // false: "plane-only" = skip primitive_detection.cpp:385-388
+};
+
+// src/features/primitives/plane_segment.hpp:122-139
+struct PlaneSeg
+{
+    uint32_t n = 0;
+    double score = 0.0;
+    double mse = DBL_MAX;
+    bool planar = false;
+    double centroid[3] = {0, 0, 0};
+    double normal[3] = {0, 0, 0}; // PlaneCoordinates::_normal
+    double d = 0.0;               // PlaneCoordinates::_d
+    double Sx = 0, Sy = 0, Sz = 0, Sxs = 0, Sys = 0, Szs = 0, Sxy = 0, Syz = 0, Szx = 0;
+};
+
+struct PlaneOut
+{
+    int segment_index = 0; // index in planeSegments (root of the merge)
+    double normal[3];      // Plane::_parametrization normal (one more normalisation, shape_primitives.cpp:49)
+    double d;
+    double centroid[3];
+    double mse, score;
+    uint32_t n;
+    double cov[9]; // Plane_Segment::get_point_cloud_covariance (row-major), plane_segment.cpp:192-203
+    std::vector<double> boundary; // 3*k camera-space points, ascending cell order (reference order is undefined)
+};
+
+struct CylinderOut
+{
+    double axis[3];
+    double radius; // NaN by quirk (shape_primitives.cpp:17-24 with cylinder_segment.cpp:23-29)
+};
+
+struct FrameResult
+{
+    std::vector<int32_t> planeLabels; // _gridPlaneSegmentMap, row-major cells
+    std::vector<int32_t> cylLabels;   // _gridCylinderSegMap
+    std::vector<PlaneSeg> planeSegments; // _planeSegments after merge_planes() (merged roots refitted in place)
+    std::vector<uint32_t> mergeLabels;   // planeMergeLabels
+    std::vector<PlaneOut> planes;        // planes that pass the >=3 boundary points test (polygon step is OUT)
+    std::vector<CylinderOut> cylinders;
+    // debug stream
+    std::vector<int32_t> seeds;          // seed ids in the order they were tried
+    std::vector<int32_t> seedOutcome;    // 0 none/too small, 1 plane, 2 cylinder branch, 3 dropped (score<=100), 4 not planar after merge
+    std::vector<uint32_t> seedActivated; // activated cell count per seed
+};
+
+class Oracle
+{
+  public:
+    explicit Oracle(const Config& cfg);
+
+    // Depth_Map_Transformation::get_organized_cloud_array, depth_map_transformation.cpp:89-142
+    // cloud is (W*H) x 3 column-major: x block, y block, z block.
+    void organized_cloud(const float* depth, std::vector<float>& cloud) const;
+
+    // Primitive_Detection::find_primitives, primitive_detection.cpp:119-166
+    void find_primitives(const float* cloud, const float* depth, FrameResult& out);
+
+    // convenience: both steps
+    void run(const float* depth, FrameResult& out);
+
+    // state exposed for per-stage parity
+    std::vector<PlaneSeg> planeGrid;   // _planeGrid
+    std::vector<float> cellTols;       // _cellDistanceTols
+    std::vector<int32_t> initialBins;  // Histogram::_bins right after init_histogram
+    std::vector<float> lastCloud;
+
+    int hCells() const { return hCells_; }
+    int vCells() const { return vCells_; }
+    int cells() const { return totalCells_; }
+    const Config& config() const { return cfg_; }
+
+    // ScreenCoordinate::to_camera_coordinates, point_coordinates.cpp:150-167 (x,y in f64)
+    void back_project(double col, double row, double z, double out[3]) const;
+
+  private:
+    Config cfg_;
+    int hCells_, vCells_, totalCells_;
+    double k00_, k02_, k11_, k12_; // K^-1 entries, Appendix A.3
+    std::vector<int32_t> cellMap_; // _cellMap, depth_map_transformation.cpp:147-173
+};
+
+// ---- free functions exposed for known-answer tests ----
+double depth_quantization(double depth);                       // covariances.cpp:12-19
+void self_adjoint_eigen3(const double lower[3][3], double evals[3], double evecs[3][3], int* iterations);
+void fit_plane(PlaneSeg& s);                                   // plane_segment.cpp:232-284
+bool can_be_merged(const PlaneSeg& a, const PlaneSeg& p, double maxMatchDistance); // plane_segment.cpp:322-326
+void normalize3(double v[3]);                                  // Eigen normalize(), Appendix A.2
+double mt19937_first_double(unsigned seed, int index);         // random.hpp:17-30
+
+} // namespace cape_oracle
