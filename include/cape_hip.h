@@ -1,0 +1,212 @@
+/*
+ * cape_hip.h -- C ABI of the MI355X-native CAPE plane/cylinder extractor (libcape_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of BaptisteHudyma/RGB-D-SLAM: the `primitives` library
+ * (reference CMakeLists.txt:117-123), i.e. Depth_Map_Transformation::get_organized_cloud_array +
+ * Primitive_Detection::find_primitives.  The reference has no FFI layer; the functions below are what a
+ * binding for that library would call.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the reference-side shim.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns CAPE_OK (0) or a negative
+ * cape_status and never throws, exits or logs to stdout (the reference's exit(-1)/terminate paths,
+ * histogram.hpp:105-109, become error codes).  A handle is not thread-safe; distinct handles are.
+ * All device work of a call is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as
+ * void*; NULL = the null stream).
+ */
+#ifndef CAPE_HIP_H
+#define CAPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPE_CELL_SIZE 20          /* parameters::detection::depthMapPatchSize_px, src/parameters.hpp:79-80 */
+#define CAPE_MAX_PLANES 64         /* capacity of _planeSegments per frame (reference: unbounded std::vector) */
+#define CAPE_MAX_CYLINDERS 32      /* capacity of cylinder2regionMap per frame */
+
+typedef enum cape_status
+{
+    CAPE_OK = 0,
+    CAPE_ERR_INVALID_ARGUMENT = -1,
+    CAPE_ERR_NO_DEVICE = -2,       /* no HIP device / runtime error at create: the product has NO CPU fallback */
+    CAPE_ERR_HIP = -3,             /* a HIP runtime call failed; cape_last_error() has the text */
+    CAPE_ERR_CAPACITY = -4,        /* n_frames > max_batch */
+    CAPE_ERR_UNSUPPORTED = -5
+} cape_status;
+
+enum
+{
+    CAPE_FLAG_CYLINDERS = 1u << 0, /* run cylinder RANSAC on low-score regions (primitive_detection.cpp:385-388);
+                                      cleared = "plane-only" mode of BASELINE.json configs[0..1] */
+};
+
+/* per-frame status bits (cape_frame_header.status) */
+enum
+{
+    CAPE_FRAME_PLANE_OVERFLOW = 1u << 0,    /* more than CAPE_MAX_PLANES plane segments: frame truncated */
+    CAPE_FRAME_BOUNDARY_OVERFLOW = 1u << 1, /* boundary point capacity exceeded */
+    CAPE_FRAME_CYL_OVERFLOW = 1u << 2,
+    CAPE_FRAME_BIN_NEAR_EDGE = 1u << 3,     /* a cell's histogram angle fell within 1e-9 of a bin edge (libm tie risk) */
+    CAPE_FRAME_INORDER_CELLS = 1u << 4,     /* >=1 cell took the in-order accumulation path (exactness guard) */
+    CAPE_FRAME_RNG_EXHAUSTED = 1u << 5      /* RANSAC asked for more draws than the precomputed mt19937 table */
+};
+
+/*
+ * Replaces: Depth_Map_Transformation(width,height,cellSize) + Primitive_Detection(width,height) constructors
+ * (src/rgbd_slam.cpp:48-57) and the process-global camera intrinsics they read lazily
+ * (Parameters::get_camera_1_intrinsics, src/parameters.hpp:144-149).
+ */
+typedef struct cape_config
+{
+    int32_t width;      /* multiple of 20, <= 1280 */
+    int32_t height;     /* multiple of 20, <= 1280 */
+    double fx, fy, cx, cy;
+    uint32_t flags;     /* CAPE_FLAG_* */
+    int32_t device;     /* HIP device ordinal */
+    int32_t max_batch;  /* frames per cape_extract call (sizes the per-frame scratch and result buffers) */
+    int32_t boundary_capacity; /* boundary points per frame; 0 = 2 * cells */
+} cape_config;
+
+typedef struct cape_handle_s* cape_handle;
+
+/* One plane segment of a frame = one element of Primitive_Detection::_planeSegments after merge_planes()
+ * (primitive_detection.cpp:503-560) plus what Plane(planeSeg, polygon) derives from it
+ * (shape_primitives.cpp:48-56).  Field names follow Plane_Segment (plane_segment.hpp:122-139). */
+typedef struct cape_plane_segment
+{
+    double normal[3];       /* PlaneCoordinates::_normal of the segment */
+    double d;
+    double centroid[3];
+    double mse;
+    double score;
+    double sums[9];         /* Sx Sy Sz Sxs Sys Szs Sxy Syz Szx */
+    double out_normal[3];   /* Plane::_parametrization normal (one more normalisation) ; valid if is_output */
+    double cov[9];          /* Plane_Segment::get_point_cloud_covariance(), row-major ; valid if is_output */
+    uint32_t point_count;
+    uint32_t merge_label;   /* planeMergeLabels[i] */
+    uint32_t planar;
+    uint32_t is_output;     /* root of its merge group, planar and >= 3 boundary points: becomes a `Plane` */
+    uint32_t boundary_offset; /* first point in the frame's boundary array */
+    uint32_t boundary_count;
+} cape_plane_segment;
+
+typedef struct cape_cylinder
+{
+    double axis[3];         /* Cylinder::_normal */
+    double radius;          /* NaN, as in the reference (shape_primitives.cpp:17-24 over a copy with 0 segments) */
+    uint32_t kept;          /* survived add_cylinders_to_primitives (primitive_detection.cpp:705-734) */
+    uint32_t region;        /* cylinder2regionMap[i].first */
+} cape_cylinder;
+
+typedef struct cape_frame_header
+{
+    int32_t n_plane_segments; /* _planeSegments.size() */
+    int32_t n_planes;         /* number of segments with is_output (= planeContainer.size() before polygon tests) */
+    int32_t n_cylinder_labels;/* cylinder2regionMap.size() */
+    int32_t n_cylinders;      /* cylinderContainer.size() */
+    int32_t n_boundary_points;
+    int32_t n_seeds;          /* iterations of the seed loop (debug) */
+    uint32_t status;          /* CAPE_FRAME_* */
+    int32_t n_planar_cells;
+} cape_frame_header;
+
+/* Fixed-capacity per-frame record; this is what the multi-GPU gather exchanges. */
+typedef struct cape_frame_record
+{
+    cape_frame_header header;
+    cape_plane_segment segments[CAPE_MAX_PLANES];
+    cape_cylinder cylinders[CAPE_MAX_CYLINDERS];
+} cape_frame_record;
+
+/* Per-cell statistics (debug / parity access to Primitive_Detection::_planeGrid, _cellDistanceTols,
+ * Histogram::_bins; primitive_detection.hpp:205-218).  One struct per cell, cell-row-major. */
+typedef struct cape_cell_stats
+{
+    double sums[9];
+    double normal[3];
+    double d;
+    double centroid[3];
+    double mse;
+    double score;
+    float tol;
+    uint32_t point_count;
+    int32_t bin;            /* histogram bin right after init_histogram, -1 if not planar */
+    uint32_t planar;
+    uint32_t inorder;       /* 1 if the exactness guard sent this cell through the in-order path */
+    uint32_t pad;
+} cape_cell_stats;
+
+typedef struct cape_timings
+{
+    /* mirrors the reference's stage buckets (primitive_detection.hpp:233-239), from HIP events, seconds,
+     * accumulated over calls made with CAPE timing enabled */
+    double cell_fit_s;      /* _initTime : back-projection + per-cell PCA (stage A kernel) */
+    double grow_s;          /* _growTime + _mergeTime + _refineTime : stage B kernel */
+    double total_s;
+    uint64_t frames;
+    uint64_t calls;
+} cape_timings;
+
+typedef struct cape_layout
+{
+    int32_t h_cells, v_cells, cells;
+    int32_t boundary_capacity;
+    uint64_t frame_record_bytes;  /* sizeof(cape_frame_record) */
+} cape_layout;
+
+/* Depth_Map_Transformation / Primitive_Detection constructors (src/rgbd_slam.cpp:48-57). */
+int cape_create(const cape_config* cfg, cape_handle* out);
+void cape_destroy(cape_handle h);
+int cape_get_layout(cape_handle h, cape_layout* out);
+
+/*
+ * Replaces, for a batch of frames: get_organized_cloud_array (depth_map_transformation.hpp:36-39) followed by
+ * find_primitives (primitive_detection.hpp:41-44).  `depth_dev` is a DEVICE pointer to n_frames row-major
+ * float32 images in millimetres (0 = invalid), already resident in HBM.  Asynchronous on `stream`.
+ * Results stay on the device until fetched (cape_copy_results) or gathered (cape_device_results).
+ */
+int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* stream);
+
+/* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
+ * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
+int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);
+
+/* Device pointers to the results of the last cape_extract (valid until the next call / destroy):
+ * records: n_frames x cape_frame_record ; plane_labels / cyl_labels: n_frames x cells int32
+ * (_gridPlaneSegmentMap / _gridCylinderSegMap, primitive_detection.hpp:212-214) ; boundary: n_frames x
+ * boundary_capacity x 3 doubles (compute_plane_segment_boundary, primitive_detection.cpp:650-703). */
+int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, int32_t** cyl_labels, double** boundary);
+
+/* Synchronous D2H of the results of the last cape_extract.  Any pointer may be NULL. */
+int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
+                      int32_t* cyl_labels, double* boundary);
+
+/* Debug / parity: per-cell stats of one frame of the last batch (synchronous). */
+int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* cells_out);
+
+/* show_statistics (primitive_detection.hpp:46-49): stage timings from HIP events. */
+int cape_enable_timing(cape_handle h, int32_t enable);
+int cape_get_timings(cape_handle h, cape_timings* out);
+/* duration in ms of the last stage A / stage B kernel launches (needs timing enabled; synchronises) */
+int cape_last_kernel_ms(cape_handle h, float* stage_a_ms, float* stage_b_ms);
+
+/* Debug / parity: evaluate device scalar math (f64 sqrt / div, ocml acos / atan2, the eigen-solver and plane fit)
+ * on host operands so tests can compare gfx950 results with the CPU oracle bit for bit.  `a`,`b`,`out` are HOST
+ * pointers; EIGEN3: a = n x 6 (m00 m10 m11 m20 m21 m22), out = n x 12 ; FIT_PLANE: a = n x 10 (9 sums, count),
+ * out = n x 10 (normal[3], d, centroid[3], mse, score, planar). */
+enum
+{
+    CAPE_DEBUG_SQRT = 0, CAPE_DEBUG_DIV = 1, CAPE_DEBUG_ACOS = 2, CAPE_DEBUG_ATAN2 = 3, CAPE_DEBUG_QUANT = 4,
+    CAPE_DEBUG_SQRTF = 5, CAPE_DEBUG_EIGEN3 = 6, CAPE_DEBUG_FIT_PLANE = 7
+};
+int cape_debug_eval(int op, const double* a, const double* b, double* out, int n);
+
+const char* cape_last_error(void);
+const char* cape_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPE_HIP_H */

@@ -1,0 +1,469 @@
+// C ABI of libcape_hip (see include/cape_hip.h).  Host side only: buffer ownership, constant tables, launches.
+// There is no CPU fallback: without a HIP device cape_create fails with CAPE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "cape_internal.h"
+
+namespace cape {
+void launch_cell_fit(const StageAParams& p, int nFrames, hipStream_t stream);
+void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
+size_t grow_lds_bytes(int cells);
+} // namespace cape
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define CAPE_HIP_TRY(expr)                                                                                   \
+    do                                                                                                       \
+    {                                                                                                        \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            return fail(CAPE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+    } while (0)
+
+constexpr int kRngTable = 40000; // upper bound on RANSAC draws per frame (cylinder section)
+
+} // namespace
+
+struct cape_handle_s
+{
+    cape_config cfg{};
+    int hCells = 0, vCells = 0, cells = 0, boundaryCap = 0;
+    // constants
+    double* acol = nullptr;
+    double* brow = nullptr;
+    float* ratioCol = nullptr;
+    float* ratioRow = nullptr;
+    double* rng = nullptr;
+    // per-frame scratch (stage A -> stage B)
+    double* cellSums = nullptr;
+    double* cellPlane = nullptr;
+    double* cellScore = nullptr;
+    float* cellTol = nullptr;
+    uint32_t* cellFlags = nullptr;
+    int32_t* cellBins = nullptr;
+    // results
+    cape_frame_record* records = nullptr;
+    int32_t* planeLabels = nullptr;
+    int32_t* cylLabels = nullptr;
+    double* boundary = nullptr;
+    // host staging for cape_extract_host
+    float* depthStage = nullptr;
+    // timing
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing = false;
+    bool evValid = false;
+    cape_timings tm{};
+    int lastFrames = 0;
+    cape::StageAParams pa{};
+    cape::StageBParams pb{};
+};
+
+namespace {
+
+// Matrix3d::inverse as Eigen evaluates it (cofactor method); for K = [[fx,0,cx],[0,fy,cy],[0,0,1]] this yields
+// k00 = fy*invdet, k02 = -(cx*fy)*invdet, k11 = fx*invdet, k12 = -(fx*cy)*invdet with invdet = 1/(fx*fy)
+// (reference src/coordinates/point_coordinates.cpp:79-83, Parameters::get_camera_1_intrinsics parameters.hpp:144-149)
+void inverse_intrinsics(double fx, double fy, double cx, double cy, double& k00, double& k02, double& k11, double& k12)
+{
+    const double m[3][3] = {{fx, 0.0, cx}, {0.0, fy, cy}, {0.0, 0.0, 1.0}};
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    };
+    const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const double det = (c00 * m[0][0] + c10 * m[1][0]) + c20 * m[2][0];
+    const double invdet = 1.0 / det;
+    k00 = c00 * invdet;
+    k02 = c20 * invdet;
+    k11 = cof(1, 1) * invdet;
+    k12 = cof(2, 1) * invdet;
+}
+
+template <typename T> hipError_t dalloc(T*& p, size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)); }
+
+void free_all(cape_handle_s* h)
+{
+    (void)hipFree(h->acol);
+    (void)hipFree(h->brow);
+    (void)hipFree(h->ratioCol);
+    (void)hipFree(h->ratioRow);
+    (void)hipFree(h->rng);
+    (void)hipFree(h->cellSums);
+    (void)hipFree(h->cellPlane);
+    (void)hipFree(h->cellScore);
+    (void)hipFree(h->cellTol);
+    (void)hipFree(h->cellFlags);
+    (void)hipFree(h->cellBins);
+    (void)hipFree(h->records);
+    (void)hipFree(h->planeLabels);
+    (void)hipFree(h->cylLabels);
+    (void)hipFree(h->boundary);
+    (void)hipFree(h->depthStage);
+    for (auto& e : h->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+}
+
+} // namespace
+
+extern "C" {
+
+const char* cape_last_error(void) { return g_lastError.c_str(); }
+const char* cape_version(void) { return "cape_hip 0.1 (gfx950)"; }
+
+int cape_create(const cape_config* cfg, cape_handle* out)
+{
+    if (!cfg || !out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % CAPE_CELL_SIZE || cfg->height % CAPE_CELL_SIZE ||
+        cfg->width > 1280 || cfg->height > 1280 || cfg->max_batch <= 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "width/height must be positive multiples of 20, <= 1280; max_batch > 0");
+    if (!(cfg->fx > 0) || !(cfg->fy > 0))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "focal lengths must be positive");
+    if (cfg->flags & CAPE_FLAG_CYLINDERS)
+        return fail(CAPE_ERR_UNSUPPORTED, "cylinder RANSAC is not available in this build");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CAPE_ERR_NO_DEVICE, "no HIP device: libcape_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    CAPE_HIP_TRY(hipSetDevice(cfg->device));
+
+    cape_handle_s* h = new (std::nothrow) cape_handle_s();
+    if (!h)
+        return fail(CAPE_ERR_HIP, "out of host memory");
+    h->cfg = *cfg;
+    h->hCells = cfg->width / CAPE_CELL_SIZE;
+    h->vCells = cfg->height / CAPE_CELL_SIZE;
+    h->cells = h->hCells * h->vCells;
+    h->boundaryCap = cfg->boundary_capacity > 0 ? cfg->boundary_capacity : 2 * h->cells;
+    const size_t B = (size_t)cfg->max_batch, C = (size_t)h->cells;
+
+#define CAPE_ALLOC(expr)                                                                                     \
+    do                                                                                                       \
+    {                                                                                                        \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+        {                                                                                                    \
+            free_all(h);                                                                                     \
+            delete h;                                                                                        \
+            return fail(CAPE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+        }                                                                                                    \
+    } while (0)
+
+    CAPE_ALLOC(dalloc(h->acol, cfg->width));
+    CAPE_ALLOC(dalloc(h->brow, cfg->height));
+    CAPE_ALLOC(dalloc(h->ratioCol, h->hCells));
+    CAPE_ALLOC(dalloc(h->ratioRow, h->vCells));
+    CAPE_ALLOC(dalloc(h->rng, kRngTable));
+    CAPE_ALLOC(dalloc(h->cellSums, B * C * cape::kSumStride));
+    CAPE_ALLOC(dalloc(h->cellPlane, B * C * cape::kPlaneStride));
+    CAPE_ALLOC(dalloc(h->cellScore, B * C));
+    CAPE_ALLOC(dalloc(h->cellTol, B * C));
+    CAPE_ALLOC(dalloc(h->cellFlags, B * C));
+    CAPE_ALLOC(dalloc(h->cellBins, B * C));
+    CAPE_ALLOC(dalloc(h->records, B));
+    CAPE_ALLOC(dalloc(h->planeLabels, B * C));
+    CAPE_ALLOC(dalloc(h->cylLabels, B * C));
+    CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
+    for (auto& e : h->ev)
+        CAPE_ALLOC(hipEventCreate(&e));
+
+    // ---- constant tables
+    double k00, k02, k11, k12;
+    inverse_intrinsics(cfg->fx, cfg->fy, cfg->cx, cfg->cy, k00, k02, k11, k12);
+    std::vector<double> acol(cfg->width), brow(cfg->height);
+    // transform_screen_to_camera: K^-1[:, :2] * [u v] + K^-1[:, 2] with k01 = k10 = 0
+    for (int u = 0; u < cfg->width; ++u)
+        acol[u] = (k00 * (double)u + 0.0) + k02;
+    for (int v = 0; v < cfg->height; ++v)
+        brow[v] = (0.0 + k11 * (double)v) + k12;
+    auto ratios = [](const std::vector<double>& t, int ncell) {
+        std::vector<float> r(ncell, 1.0f);
+        for (int c = 0; c < ncell; ++c)
+        {
+            double mx = 0.0, mn = 0.0;
+            for (int i = 0; i < CAPE_CELL_SIZE; ++i)
+            {
+                const double a = std::fabs(t[c * CAPE_CELL_SIZE + i]);
+                if (a > 0.0)
+                {
+                    mx = (a > mx) ? a : mx;
+                    mn = (mn == 0.0 || a < mn) ? a : mn;
+                }
+            }
+            // rounded up so the device-side guard stays conservative
+            r[c] = (mn > 0.0) ? std::nextafter((float)(mx / mn), INFINITY) : 1.0f;
+        }
+        return r;
+    };
+    const std::vector<float> rc = ratios(acol, h->hCells), rr = ratios(brow, h->vCells);
+    std::vector<double> rng(kRngTable);
+    {
+        // utils::Random (src/utils/random.hpp:17-30) under MAKE_DETERMINISTIC: mt19937(0) + uniform_real_distribution
+        std::mt19937 engine(0u);
+        std::uniform_real_distribution<double> dist(0.0, 1.0);
+        for (auto& v : rng)
+            v = dist(engine);
+    }
+    CAPE_ALLOC(hipMemcpy(h->acol, acol.data(), acol.size() * sizeof(double), hipMemcpyHostToDevice));
+    CAPE_ALLOC(hipMemcpy(h->brow, brow.data(), brow.size() * sizeof(double), hipMemcpyHostToDevice));
+    CAPE_ALLOC(hipMemcpy(h->ratioCol, rc.data(), rc.size() * sizeof(float), hipMemcpyHostToDevice));
+    CAPE_ALLOC(hipMemcpy(h->ratioRow, rr.data(), rr.size() * sizeof(float), hipMemcpyHostToDevice));
+    CAPE_ALLOC(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
+    CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
+
+    // ---- kernel parameter blocks
+    cape::StageAParams& a = h->pa;
+    a.W = cfg->width;
+    a.H = cfg->height;
+    a.hCells = h->hCells;
+    a.vCells = h->vCells;
+    a.cells = h->cells;
+    a.segsPerRow = (h->hCells + 31) / 32;
+    a.bandsPerFrame = h->vCells * a.segsPerRow;
+    a.pairsPerFrame = (a.bandsPerFrame + 1) / 2;
+    a.acol = h->acol;
+    a.brow = h->brow;
+    a.ratio_col = h->ratioCol;
+    a.ratio_row = h->ratioRow;
+    a.cell_sums = h->cellSums;
+    a.cell_plane = h->cellPlane;
+    a.cell_score = h->cellScore;
+    a.cell_tol = h->cellTol;
+    a.cell_flags = h->cellFlags;
+    // primitive_detection.cpp:189-190 ; parameters.hpp:75 maximumPlaneAngleForMerge_d = 18.0f
+    a.sinMerge = sinf(static_cast<float>(18.0f * M_PI / 180.0));
+    // plane_segment.hpp:33-34 ; parameters.hpp:72 minimumZeroDepthProportion = 0.7f
+    a.minZeroPointCount = static_cast<int>(std::floor(static_cast<float>(400) * 0.7f));
+
+    cape::StageBParams& b = h->pb;
+    b.W = cfg->width;
+    b.H = cfg->height;
+    b.hCells = h->hCells;
+    b.vCells = h->vCells;
+    b.cells = h->cells;
+    b.acol = h->acol;
+    b.brow = h->brow;
+    b.cell_sums = h->cellSums;
+    b.cell_plane = h->cellPlane;
+    b.cell_score = h->cellScore;
+    b.cell_tol = h->cellTol;
+    b.cell_flags = h->cellFlags;
+    b.cell_bins = h->cellBins;
+    b.records = h->records;
+    b.plane_labels = h->planeLabels;
+    b.cyl_labels = h->cylLabels;
+    b.boundary = h->boundary;
+    b.boundaryCapacity = h->boundaryCap;
+    b.flags = cfg->flags;
+    b.cosMerge = std::cos(static_cast<double>(18.0f) * M_PI / 180.0); // plane_segment.cpp:324
+    b.planeSeedCount = static_cast<int>(static_cast<unsigned>((0.8 / 100.0) * h->cells));
+    b.minCellActivated = static_cast<int>(static_cast<unsigned>((0.65 / 100.0) * h->cells));
+    b.rngTable = h->rng;
+    b.rngCount = kRngTable;
+    // cylinder_segment.cpp:132
+    b.ransacMaxIterations = static_cast<int>(static_cast<unsigned>(logf(1.0f - 0.8f) / logf(1.0f - powf(0.33f, 3.0f))));
+
+    if (cape::grow_lds_bytes(h->cells) > 160 * 1024)
+    {
+        free_all(h);
+        delete h;
+        return fail(CAPE_ERR_UNSUPPORTED, "cell grid too large for the LDS-resident grow kernel");
+    }
+    *out = h;
+    return CAPE_OK;
+}
+
+void cape_destroy(cape_handle h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->cfg.device);
+    free_all(h);
+    delete h;
+}
+
+int cape_get_layout(cape_handle h, cape_layout* out)
+{
+    if (!h || !out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    out->h_cells = h->hCells;
+    out->v_cells = h->vCells;
+    out->cells = h->cells;
+    out->boundary_capacity = h->boundaryCap;
+    out->frame_record_bytes = sizeof(cape_frame_record);
+    return CAPE_OK;
+}
+
+int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* stream_)
+{
+    if (!h || !depth_dev || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
+    if (n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
+    h->lastFrames = n_frames;
+    if (n_frames == 0)
+        return CAPE_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    h->pa.depth = depth_dev;
+    h->pb.depth = depth_dev;
+    if (h->timing)
+        CAPE_HIP_TRY(hipEventRecord(h->ev[0], stream));
+    cape::launch_cell_fit(h->pa, n_frames, stream);
+    if (h->timing)
+        CAPE_HIP_TRY(hipEventRecord(h->ev[1], stream));
+    cape::launch_grow(h->pb, n_frames, stream);
+    if (h->timing)
+    {
+        CAPE_HIP_TRY(hipEventRecord(h->ev[2], stream));
+        h->evValid = true;
+    }
+    CAPE_HIP_TRY(hipGetLastError());
+    return CAPE_OK;
+}
+
+int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream_)
+{
+    if (!h || !depth_host || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
+    if (n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t bytes = (size_t)h->cfg.max_batch * h->cfg.width * h->cfg.height * sizeof(float);
+    if (!h->depthStage)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), bytes));
+    CAPE_HIP_TRY(hipMemcpyAsync(h->depthStage, depth_host, (size_t)n_frames * h->cfg.width * h->cfg.height * sizeof(float),
+                                hipMemcpyHostToDevice, stream));
+    return cape_extract(h, h->depthStage, n_frames, stream_);
+}
+
+int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, int32_t** cyl_labels, double** boundary)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (records)
+        *records = h->records;
+    if (plane_labels)
+        *plane_labels = h->planeLabels;
+    if (cyl_labels)
+        *cyl_labels = h->cylLabels;
+    if (boundary)
+        *boundary = h->boundary;
+    return CAPE_OK;
+}
+
+int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
+                      int32_t* cyl_labels, double* boundary)
+{
+    if (!h || n_frames < 0 || n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    const size_t n = (size_t)n_frames, C = (size_t)h->cells;
+    if (records)
+        CAPE_HIP_TRY(hipMemcpy(records, h->records, n * sizeof(cape_frame_record), hipMemcpyDeviceToHost));
+    if (plane_labels)
+        CAPE_HIP_TRY(hipMemcpy(plane_labels, h->planeLabels, n * C * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cyl_labels)
+        CAPE_HIP_TRY(hipMemcpy(cyl_labels, h->cylLabels, n * C * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (boundary)
+        CAPE_HIP_TRY(hipMemcpy(boundary, h->boundary, n * (size_t)h->boundaryCap * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return CAPE_OK;
+}
+
+int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* out)
+{
+    if (!h || !out || frame < 0 || frame >= h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame");
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    const size_t C = (size_t)h->cells, off = (size_t)frame * C;
+    std::vector<double> sums(C * cape::kSumStride), plane(C * cape::kPlaneStride), score(C);
+    std::vector<float> tol(C);
+    std::vector<uint32_t> flags(C);
+    std::vector<int32_t> bins(C);
+    CAPE_HIP_TRY(hipMemcpy(sums.data(), h->cellSums + off * cape::kSumStride, sums.size() * 8, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(plane.data(), h->cellPlane + off * cape::kPlaneStride, plane.size() * 8, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(score.data(), h->cellScore + off, C * 8, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(tol.data(), h->cellTol + off, C * 4, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(flags.data(), h->cellFlags + off, C * 4, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(bins.data(), h->cellBins + off, C * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < C; ++i)
+    {
+        cape_cell_stats& o = out[i];
+        for (int k = 0; k < 9; ++k)
+            o.sums[k] = sums[i * cape::kSumStride + k];
+        const double* p = &plane[i * cape::kPlaneStride];
+        o.normal[0] = p[0]; o.normal[1] = p[1]; o.normal[2] = p[2];
+        o.d = p[3];
+        o.centroid[0] = p[4]; o.centroid[1] = p[5]; o.centroid[2] = p[6];
+        o.mse = p[7];
+        o.score = score[i];
+        o.tol = tol[i];
+        o.point_count = flags[i] & cape::kCountMask;
+        o.bin = bins[i];
+        o.planar = (flags[i] & cape::kFlagPlanar) ? 1u : 0u;
+        o.inorder = (flags[i] & cape::kFlagInorder) ? 1u : 0u;
+        o.pad = 0;
+    }
+    return CAPE_OK;
+}
+
+int cape_enable_timing(cape_handle h, int32_t enable)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    h->timing = enable != 0;
+    h->evValid = false;
+    return CAPE_OK;
+}
+
+int cape_last_kernel_ms(cape_handle h, float* a_ms, float* b_ms)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->evValid)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "timing not enabled or no extract since it was enabled");
+    CAPE_HIP_TRY(hipEventSynchronize(h->ev[2]));
+    float a = 0, b = 0;
+    CAPE_HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    CAPE_HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (a_ms)
+        *a_ms = a;
+    if (b_ms)
+        *b_ms = b;
+    h->tm.cell_fit_s += a * 1e-3;
+    h->tm.grow_s += b * 1e-3;
+    h->tm.total_s += (a + b) * 1e-3;
+    h->tm.frames += (uint64_t)h->lastFrames;
+    h->tm.calls += 1;
+    h->evValid = false;
+    return CAPE_OK;
+}
+
+int cape_get_timings(cape_handle h, cape_timings* out)
+{
+    if (!h || !out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    *out = h->tm;
+    return CAPE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,710 @@
+// Stage B -- histogram-seeded region growing, plane merge and boundary candidates: ONE WAVEFRONT PER FRAME.
+//
+// Replaces, per frame: Primitive_Detection::init_histogram, grow_planes_and_cylinders, grow_plane_segment_at_seed,
+// region_growing, add_plane_segment_to_features, merge_planes, get_connected_components_matrix,
+// add_planes_to_primitives, compute_plane_segment_boundary and add_cylinders_to_primitives
+// (reference src/features/primitives/primitive_detection.cpp:239-776) plus Histogram<20> (histogram.hpp).
+//
+// The seed loop is sequential by construction (every seed consumes cells and histogram counts), so a frame gets
+// one 64-lane wave and thousands of frames are in flight.  Inside the wave:
+//   * the cell grid is held as bit rows: lane r owns row r of the 32x24 (u32) or 64x48 (u64) grid;
+//   * the recursive DFS of region_growing is directed-graph reachability: the merge predicate of every directed
+//     cell edge (parent plane vs child plane, child tolerance) is evaluated once per frame into four edge masks,
+//     and growing a region is label propagation on bit rows (shift/and/or + lane shuffles) iterated with a
+//     wave-wide vote until nothing changes;
+//   * arg-max over the 400 histogram bins / arg-min MSE over the candidates are wave reductions with the
+//     reference's first-index tie-breaks; moment sums of a region are accumulated in ascending cell order by nine
+//     lanes (one per sum), because region sums are not exact and the order is observable.
+// No workgroup barrier is needed: all cross-lane traffic is wave-synchronous (LDS + ballots).
+#include <hip/hip_runtime.h>
+
+#include "cape_device.h"
+#include "cape_internal.h"
+
+namespace cape {
+
+constexpr int kHistBins = 400;
+constexpr int kSegDoubles = 20; // LDS plane-segment record: sums[9], n, normal[3], d, centroid[3], mse, score, planar
+
+// wave-synchronous ordering point for LDS traffic between lanes of the single wave of this workgroup
+#define CAPE_WAVE_SYNC() __syncthreads()
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const unsigned w = __shfl_xor(v, o);
+        v = (w > v) ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const unsigned long long w = __shfl_xor(v, o);
+        v = (w < v) ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v |= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive prefix sum over lanes
+__device__ __forceinline__ int wave_scan_i32(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const int w = __shfl_up(v, o);
+        if (lane >= o)
+            v += w;
+    }
+    return v;
+}
+
+template <typename MaskT> __device__ __forceinline__ int popc(MaskT m);
+template <> __device__ __forceinline__ int popc<uint32_t>(uint32_t m) { return __popc(m); }
+template <> __device__ __forceinline__ int popc<unsigned long long>(unsigned long long m) { return __popcll(m); }
+template <typename MaskT> __device__ __forceinline__ int ctz(MaskT m);
+template <> __device__ __forceinline__ int ctz<uint32_t>(uint32_t m) { return __ffs(m) - 1; }
+template <> __device__ __forceinline__ int ctz<unsigned long long>(unsigned long long m) { return __ffsll(m) - 1; }
+
+template <typename MaskT> __device__ __forceinline__ MaskT shfl_mask(MaskT v, int src)
+{
+    return (MaskT)__shfl((unsigned long long)v, src);
+}
+
+// 3x3 morphology on bit rows.  up/dn are the neighbouring rows (0 outside the grid).
+template <typename MaskT> __device__ __forceinline__ MaskT row3(MaskT x, MaskT widthMask) { return (x | (x << 1) | (x >> 1)) & widthMask; }
+
+template <typename MaskT> struct Rows
+{
+    // neighbour rows of a per-lane row mask
+    static __device__ __forceinline__ MaskT up(MaskT v, int lane) // row r-1
+    {
+        const MaskT w = (MaskT)__shfl_up((unsigned long long)v, 1);
+        return lane > 0 ? w : (MaskT)0;
+    }
+    static __device__ __forceinline__ MaskT dn(MaskT v, int lane, int vCells) // row r+1
+    {
+        const MaskT w = (MaskT)__shfl_down((unsigned long long)v, 1);
+        return (lane + 1 < vCells) ? w : (MaskT)0;
+    }
+};
+
+struct SegRec // uniform (all lanes hold the same values)
+{
+    double S[9];
+    double n; // point count (exact integer in f64)
+    double nx, ny, nz, d;
+    double cx, cy, cz;
+    double mse, score;
+    double planar;
+};
+
+__device__ __forceinline__ void seg_store(double* lds, const SegRec& s)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        lds[k] = s.S[k];
+    lds[9] = s.n;
+    lds[10] = s.nx; lds[11] = s.ny; lds[12] = s.nz; lds[13] = s.d;
+    lds[14] = s.cx; lds[15] = s.cy; lds[16] = s.cz;
+    lds[17] = s.mse; lds[18] = s.score; lds[19] = s.planar;
+}
+__device__ __forceinline__ void seg_load(const double* lds, SegRec& s)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        s.S[k] = lds[k];
+    s.n = lds[9];
+    s.nx = lds[10]; s.ny = lds[11]; s.nz = lds[12]; s.d = lds[13];
+    s.cx = lds[14]; s.cy = lds[15]; s.cz = lds[16];
+    s.mse = lds[17]; s.score = lds[18]; s.planar = lds[19];
+}
+
+// Matrix3d::inverse, cofactor method -> Plane_Segment::get_point_cloud_covariance
+__device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
+{
+    // hessian {{Sxs,Sxy,Szx},{Sxy,Sys,Syz},{Szx,Syz,Szs}}
+    const double m[3][3] = {{S[3], S[6], S[8]}, {S[6], S[4], S[7]}, {S[8], S[7], S[5]}};
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    };
+    const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+    const double det = (c00 * m[0][0] + c10 * m[1][0]) + c20 * m[2][0];
+    const double invdet = 1.0 / det;
+    r[0] = c00 * invdet;
+    r[1] = c10 * invdet;
+    r[2] = c20 * invdet;
+    r[3] = cof(0, 1) * invdet;
+    r[4] = cof(1, 1) * invdet;
+    r[5] = cof(2, 1) * invdet;
+    r[6] = cof(0, 2) * invdet;
+    r[7] = cof(1, 2) * invdet;
+    r[8] = cof(2, 2) * invdet;
+}
+
+template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel(StageBParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.x;
+    const int C = p.cells, HC = p.hCells, VC = p.vCells;
+    const size_t cellBase = (size_t)frame * C;
+
+    // ---- LDS carve (all offsets multiples of 16)
+    double* s_mse = reinterpret_cast<double*>(smem);                              // C f64
+    double* s_seg = s_mse + C;                                                    // CAPE_MAX_PLANES x 20 f64
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_seg + CAPE_MAX_PLANES * kSegDoubles); // 64 u64
+    int* s_hist = reinterpret_cast<int*>(s_adj + CAPE_MAX_PLANES);                // 400 i32
+    short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
+    unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
+    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
+    unsigned char* s_cyl = s_lab + C;                                             // C u8  cylinder labels
+    unsigned char* s_mlab = s_cyl + C;                                            // 64 u8 merge labels
+
+    const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
+
+    for (int i = lane; i < kHistBins; i += 64)
+        s_hist[i] = 0;
+    for (int i = lane; i < CAPE_MAX_PLANES; i += 64)
+    {
+        s_adj[i] = 0ull;
+        s_mlab[i] = (unsigned char)i;
+    }
+    CAPE_WAVE_SYNC();
+
+    uint32_t status = 0;
+
+    // =========================================================================================
+    // init_histogram (primitive_detection.cpp:239-265, histogram.hpp:35-62)
+    // =========================================================================================
+    int nPlanarLocal = 0;
+    for (int i = lane; i < C; i += 64)
+    {
+        const uint32_t fl = p.cell_flags[cellBase + i];
+        const double* pl = p.cell_plane + (cellBase + i) * kPlaneStride;
+        s_mse[i] = pl[7];
+        s_lab[i] = 0;
+        s_cyl[i] = 0;
+        int bin = -1;
+        if (fl & kFlagPlanar)
+        {
+            const double nx = pl[0], ny = pl[1], nz = pl[2];
+            const double theta = acos(-nz);
+            const double phi = atan2(nx, ny);
+            constexpr double kPi = 3.14159265358979323846;
+            const double tx = 19.0 * (theta - 0.0) / kPi;
+            const int xQ = (int)floor(tx);
+            int yQ = 0;
+            double ty = 0.5;
+            if (xQ > 0)
+            {
+                ty = 19.0 * (phi - (-kPi)) / (kPi - (-kPi));
+                yQ = (int)floor(ty);
+            }
+            bin = yQ * 20 + xQ;
+            atomicAdd(&s_hist[bin], 1);
+            ++nPlanarLocal;
+            // libm tie guard: ocml vs glibc acos/atan2 may differ in the last ulp
+            if (fabs(tx - rint(tx)) < 1e-9 || (xQ > 0 && fabs(ty - rint(ty)) < 1e-9))
+                status |= CAPE_FRAME_BIN_NEAR_EDGE;
+        }
+        s_bins[i] = (short)bin;
+        p.cell_bins[cellBase + i] = bin;
+        if (fl & kFlagInorder)
+            status |= CAPE_FRAME_INORDER_CELLS;
+    }
+    const int nPlanar = wave_sum_i32(nPlanarLocal);
+    CAPE_WAVE_SYNC();
+
+    // =========================================================================================
+    // bit rows: unassigned mask and the four directed edge masks (region_growing's predicate,
+    // primitive_detection.cpp:802 with plane_segment.cpp:322-326), lane r <- row r
+    //   EL bit c : parent (r,c-1) -> child (r,c)      ER bit c : parent (r,c+1) -> child (r,c)
+    //   EU bit c : parent (r-1,c) -> child (r,c)      ED bit c : parent (r+1,c) -> child (r,c)
+    // =========================================================================================
+    MaskT U = 0, EL = 0, ER = 0, EU = 0, ED = 0;
+    {
+        double unx = 0, uny = 0, unz = 0, ud = 0, ucx = 0, ucy = 0, ucz = 0, utol = 0; // row above, same column
+        for (int r = 0; r < VC; ++r)
+        {
+            const bool in = lane < HC;
+            const int ci = r * HC + (in ? lane : 0);
+            const double* pl = p.cell_plane + (cellBase + ci) * kPlaneStride;
+            const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3], cx = pl[4], cy = pl[5], cz = pl[6];
+            const double tol = (double)p.cell_tol[cellBase + ci];
+            const bool planar = in && (p.cell_flags[cellBase + ci] & kFlagPlanar);
+            // left neighbour (lane - 1)
+            const double lnx = __shfl_up(nx, 1), lny = __shfl_up(ny, 1), lnz = __shfl_up(nz, 1), ld = __shfl_up(d, 1);
+            const double lcx = __shfl_up(cx, 1), lcy = __shfl_up(cy, 1), lcz = __shfl_up(cz, 1), ltol = __shfl_up(tol, 1);
+            const bool hasL = in && lane > 0;
+            const bool l2m = hasL && can_be_merged(lnx, lny, lnz, ld, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
+            const bool m2l = hasL && can_be_merged(nx, ny, nz, d, lnx, lny, lnz, lcx, lcy, lcz, ltol, p.cosMerge);
+            const bool hasU = in && r > 0;
+            const bool u2m = hasU && can_be_merged(unx, uny, unz, ud, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
+            const bool m2u = hasU && can_be_merged(nx, ny, nz, d, unx, uny, unz, ucx, ucy, ucz, utol, p.cosMerge);
+            const unsigned long long bU = __ballot(planar);
+            const unsigned long long bL2M = __ballot(l2m);
+            const unsigned long long bM2L = __ballot(m2l);
+            const unsigned long long bU2M = __ballot(u2m);
+            const unsigned long long bM2U = __ballot(m2u);
+            if (lane == r)
+            {
+                U = (MaskT)bU;
+                EL = (MaskT)bL2M;
+                ER = (MaskT)(bM2L >> 1);
+                EU = (MaskT)bU2M;
+            }
+            if (lane == r - 1)
+                ED = (MaskT)bM2U;
+            unx = nx; uny = ny; unz = nz; ud = d; ucx = cx; ucy = cy; ucz = cz; utol = tol;
+        }
+    }
+
+    // =========================================================================================
+    // grow_planes_and_cylinders (primitive_detection.cpp:267-310)
+    // =========================================================================================
+    int untried = nPlanar;
+    int nSeg = 0;      // _planeSegments.size()
+    int nCylLabels = 0;
+    int nSeeds = 0;
+    const double* sumsBase = p.cell_sums + cellBase * kSumStride;
+    const int maxSeedIters = 4 * C + 1024; // the loop provably terminates (every iteration burns a histogram count)
+
+    while (untried > 0 && nSeeds < maxSeedIters)
+    {
+        // ---- Histogram::get_points_from_most_frequent_bin (histogram.hpp:69-98): first index of the greatest count
+        unsigned key = 0;
+        for (int b = lane; b < kHistBins; b += 64)
+        {
+            const int h = s_hist[b];
+            const unsigned k = ((unsigned)h << 16) | (unsigned)(0xFFFF - b);
+            key = (h > 0 && k > key) ? k : key;
+        }
+        key = wave_max_u32(key);
+        if (key == 0)
+            break; // mostFrequentBin = -1 -> empty candidate list -> size < planeSeedCount
+        const int bin = 0xFFFF - (int)(key & 0xFFFFu);
+
+        // ---- candidates = cells with _bins == bin ; seed = first strict minimum of MSE (:285-298)
+        int candLocal = 0;
+        unsigned long long bestLocal = ~0ull; // (mse bits) ; mse >= 0 so the bit pattern orders like the value
+        int bestIdxLocal = 0x7FFFFFFF;
+        for (int i = lane; i < C; i += 64)
+        {
+            if (s_bins[i] == (short)bin)
+            {
+                ++candLocal;
+                const unsigned long long mb = (unsigned long long)__double_as_longlong(s_mse[i]);
+                if (mb < bestLocal)
+                {
+                    bestLocal = mb;
+                    bestIdxLocal = i;
+                }
+            }
+        }
+        const int cand = wave_sum_i32(candLocal);
+        if (cand < p.planeSeedCount || cand == 0)
+            break;
+        const unsigned long long bestAll = wave_min_u64(bestLocal);
+        const unsigned idxKey = (bestLocal == bestAll) ? (unsigned)(0x7FFFFFFF - bestIdxLocal) : 0u;
+        const int seed = 0x7FFFFFFF - (int)wave_max_u32(idxKey);
+        if (__longlong_as_double((long long)bestAll) >= kDblMax)
+            break; // "invalid seed" (:299-304)
+        ++nSeeds;
+
+        // ---- grow_plane_segment_at_seed (:312-389)
+        const int sy = seed / HC, sx = seed - sy * HC;
+        const double* spl = p.cell_plane + (cellBase + seed) * kPlaneStride;
+        const double snx = spl[0], sny = spl[1], snz = spl[2], sd = spl[3];
+        const double scx = spl[4], scy = spl[5], scz = spl[6];
+        const double stol = (double)p.cell_tol[cellBase + seed];
+        // newPlaneSegment(planeToGrow): the copy re-normalises the normal (plane_coordinates.hpp:24-27)
+        double pnx = snx, pny = sny, pnz = snz;
+        normalize3(pnx, pny, pnz);
+        const MaskT seedRowU = shfl_mask<MaskT>(U, sy);
+        const bool seedUnassigned = (seedRowU >> sx) & (MaskT)1;
+        const bool seedOK = seedUnassigned && can_be_merged(pnx, pny, pnz, sd, snx, sny, snz, scx, scy, scz, stol, p.cosMerge);
+
+        // ---- region_growing (:778-818) as label propagation on bit rows
+        MaskT act = 0;
+        if (seedOK)
+        {
+            if (lane == sy)
+                act = (MaskT)1 << sx;
+            for (;;)
+            {
+                MaskT a = act;
+                for (;;)
+                {
+                    const MaskT na = a | (U & (((MaskT)(a << 1) & EL) | ((MaskT)(a >> 1) & ER)));
+                    if (na == a)
+                        break;
+                    a = na;
+                }
+                const MaskT up = Rows<MaskT>::up(a, lane);
+                const MaskT dn = Rows<MaskT>::dn(a, lane, VC);
+                a |= U & ((up & EU) | (dn & ED));
+                const bool changed = (a != act);
+                act = a;
+                if (!__any(changed))
+                    break;
+            }
+        }
+
+        // ---- activated cell list in ascending cell index (row-major)
+        const int rowCnt = popc<MaskT>(act);
+        const int incl = wave_scan_i32(rowCnt, lane);
+        const int total = __shfl(incl, 63);
+        {
+            int pos = incl - rowCnt;
+            MaskT m = act;
+            while (m)
+            {
+                const int c = ctz<MaskT>(m);
+                s_list[pos++] = (unsigned short)(lane * HC + c);
+                m &= m - 1;
+            }
+        }
+        CAPE_WAVE_SYNC();
+
+        // ---- expand_segment over activated cells in ascending order (:341-360): lanes 0..8 own one sum each, lane 9
+        //      the point count.  The seed's own sums are counted twice (copy :325 + expand of the seed itself).
+        const int ql = lane < 10 ? lane : 0;
+        double acc = sumsBase[(size_t)seed * kSumStride + ql];
+        {
+            int i = 0;
+            for (; i + 4 <= total; i += 4)
+            {
+                const int c0 = s_list[i], c1 = s_list[i + 1], c2 = s_list[i + 2], c3 = s_list[i + 3];
+                const double v0 = sumsBase[(size_t)c0 * kSumStride + ql];
+                const double v1 = sumsBase[(size_t)c1 * kSumStride + ql];
+                const double v2 = sumsBase[(size_t)c2 * kSumStride + ql];
+                const double v3 = sumsBase[(size_t)c3 * kSumStride + ql];
+                acc += v0;
+                acc += v1;
+                acc += v2;
+                acc += v3;
+            }
+            for (; i < total; ++i)
+                acc += sumsBase[(size_t)s_list[i] * kSumStride + ql];
+        }
+
+        // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
+        for (int i = lane; i < total; i += 64)
+        {
+            const int cidx = s_list[i];
+            atomicSub(&s_hist[s_bins[cidx]], 1);
+            s_bins[cidx] = 1; // quirk: 1, not -1
+        }
+        CAPE_WAVE_SYNC();
+        if (lane == 0 && s_hist[1] < 0)
+            s_hist[1] = 0; // "if != 0: -= 1" saturates; only bin 1 can be over-decremented
+        U &= ~act;
+        untried -= total;
+
+        if (total == 0 || total < p.minCellActivated)
+        {
+            if (lane == 0)
+            {
+                const int b = s_bins[seed];
+                if (s_hist[b] != 0)
+                    s_hist[b] -= 1;
+                s_bins[seed] = 1;
+            }
+            CAPE_WAVE_SYNC();
+            continue;
+        }
+        CAPE_WAVE_SYNC();
+
+        SegRec ns;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            ns.S[k] = __shfl(acc, k);
+        ns.n = __shfl(acc, 9);
+        PlaneFit f;
+        fit_plane(ns.S, (uint32_t)ns.n, f);
+        if (!f.planar)
+            continue; // "Plane segment is not planar after merge"
+
+        if (f.score > 100)
+        {
+            // add_plane_segment_to_features (:391-411): push_back copies the segment (one more normalisation)
+            if (nSeg >= CAPE_MAX_PLANES)
+            {
+                status |= CAPE_FRAME_PLANE_OVERFLOW;
+                break;
+            }
+            ns.nx = f.nx; ns.ny = f.ny; ns.nz = f.nz; ns.d = f.d;
+            normalize3(ns.nx, ns.ny, ns.nz);
+            ns.cx = f.cx; ns.cy = f.cy; ns.cz = f.cz;
+            ns.mse = f.mse; ns.score = f.score; ns.planar = 1.0;
+            if (lane == 0)
+                seg_store(s_seg + nSeg * kSegDoubles, ns);
+            ++nSeg;
+            for (int i = lane; i < total; i += 64)
+                s_lab[s_list[i]] = (unsigned char)nSeg;
+            CAPE_WAVE_SYNC();
+        }
+        else if (total > 5 && (p.flags & CAPE_FLAG_CYLINDERS))
+        {
+            // cylinder_fitting (:478-501) -- device RANSAC lands in a later revision; until then the call is refused
+            // at cape_create (CAPE_ERR_UNSUPPORTED), so this branch is unreachable.
+        }
+    }
+
+    // =========================================================================================
+    // merge_planes (:503-560) with get_connected_components_matrix (:736-776)
+    // =========================================================================================
+    for (int i = lane; i < C; i += 64)
+    {
+        const int r = i / HC, c = i - r * HC;
+        if (r >= VC - 1 || c >= HC - 1)
+            continue; // last row / last column never act as sources
+        const int a = s_lab[i];
+        if (a <= 0)
+            continue;
+        const int b = s_lab[i + 1];
+        const int dwn = s_lab[i + HC];
+        if (b > 0 && a != b)
+        {
+            atomicOr(&s_adj[a - 1], 1ull << (b - 1));
+            atomicOr(&s_adj[b - 1], 1ull << (a - 1));
+        }
+        if (dwn > 0 && a != dwn)
+        {
+            atomicOr(&s_adj[a - 1], 1ull << (dwn - 1));
+            atomicOr(&s_adj[dwn - 1], 1ull << (a - 1));
+        }
+    }
+    CAPE_WAVE_SYNC();
+
+    for (int row = 0; row < nSeg; ++row)
+    {
+        const int planeId = s_mlab[row];
+        SegRec A;
+        seg_load(s_seg + planeId * kSegDoubles, A);
+        if (A.planar == 0.0)
+            continue;
+        bool expanded = false;
+        const unsigned long long conn = s_adj[row];
+        for (int col = row + 1; col < nSeg; ++col)
+        {
+            if (!((conn >> col) & 1ull))
+                continue;
+            SegRec B;
+            seg_load(s_seg + col * kSegDoubles, B);
+            if (B.planar == 0.0)
+                continue;
+            // planeToExpand keeps its (stale) normal / d inside the row loop
+            if (can_be_merged(A.nx, A.ny, A.nz, A.d, B.nx, B.ny, B.nz, B.cx, B.cy, B.cz, 50.0, p.cosMerge))
+            {
+                A.S[0] += B.S[0]; A.S[1] += B.S[1]; A.S[2] += B.S[2];
+                A.S[3] += B.S[3]; A.S[4] += B.S[4]; A.S[5] += B.S[5];
+                A.S[6] += B.S[6]; A.S[7] += B.S[7]; A.S[8] += B.S[8];
+                A.n += B.n;
+                if (lane == 0)
+                    s_mlab[col] = (unsigned char)planeId;
+                expanded = true;
+            }
+        }
+        if (expanded)
+        {
+            PlaneFit f;
+            fit_plane(A.S, (uint32_t)A.n, f);
+            A.cx = f.cx; A.cy = f.cy; A.cz = f.cz;
+            A.planar = f.planar ? 1.0 : 0.0;
+            if (f.planar) // on a degenerate refit fit_plane returns before touching normal / d / mse / score
+            {
+                A.nx = f.nx; A.ny = f.ny; A.nz = f.nz; A.d = f.d;
+                A.mse = f.mse; A.score = f.score;
+            }
+            if (lane == 0)
+                seg_store(s_seg + planeId * kSegDoubles, A);
+        }
+        CAPE_WAVE_SYNC();
+    }
+
+    // =========================================================================================
+    // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
+    // =========================================================================================
+    cape_frame_record* rec = p.records + frame;
+    double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
+    const float* depthF = p.depth + (size_t)frame * p.W * p.H;
+    int nBoundary = 0;
+    int nPlanesOut = 0;
+    for (int pi = 0; pi < nSeg; ++pi)
+    {
+        SegRec A;
+        seg_load(s_seg + pi * kSegDoubles, A);
+        const int mlabel = s_mlab[pi];
+        uint32_t isOutput = 0, bOff = (uint32_t)nBoundary, bCnt = 0;
+        double onx = 0, ony = 0, onz = 0;
+        double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (mlabel == pi && A.planar != 0.0)
+        {
+            // label set of the merge group: j >= pi with planeMergeLabels[j] == pi
+            unsigned long long group = 0;
+            for (int j = pi; j < nSeg; ++j)
+                if (s_mlab[j] == mlabel)
+                    group |= 1ull << j;
+            // lane r builds row r of the mask
+            MaskT M = 0;
+            if (lane < VC)
+            {
+                for (int c = 0; c < HC; ++c)
+                {
+                    const int l = s_lab[lane * HC + c];
+                    if (l > 0 && ((group >> (l - 1)) & 1ull))
+                        M |= (MaskT)1 << c;
+                }
+            }
+            const MaskT Mup = Rows<MaskT>::up(M, lane), Mdn = Rows<MaskT>::dn(M, lane, VC);
+            // erode, 3x3 cross, BORDER_CONSTANT 0 ; dilate, 3x3 square, border ignored
+            const MaskT ero = M & (MaskT)(M << 1) & (MaskT)(M >> 1) & Mup & Mdn;
+            const MaskT dil = row3<MaskT>(M, widthMask) | row3<MaskT>(Mup, widthMask) | row3<MaskT>(Mdn, widthMask);
+            const MaskT ring = dil & ~ero;
+
+            const double maxBoundaryDistance = 3 * sqrt(A.mse);
+            for (int r = 0; r < VC; ++r)
+            {
+                const MaskT ringRow = shfl_mask<MaskT>(ring, r);
+                if (ringRow == 0)
+                    continue;
+                bool hit = false;
+                double px = 0, py = 0, pz = 0;
+                if (lane < HC && ((ringRow >> lane) & (MaskT)1))
+                {
+                    const int centerX = lane * kCell + kCell / 2;
+                    const int centerY = r * kCell + kCell / 2;
+                    const double dpt = (double)depthF[(size_t)centerY * p.W + centerX];
+                    if (dpt > 0)
+                    {
+                        px = dpt * p.acol[centerX];
+                        py = dpt * p.brow[centerY];
+                        pz = dpt;
+                        const double dist = dot3(A.nx, A.ny, A.nz, px, py, pz) + A.d;
+                        hit = fabs(dist) < maxBoundaryDistance;
+                    }
+                }
+                const unsigned long long hb = __ballot(hit);
+                if (hit)
+                {
+                    const int pos = nBoundary + __popcll(hb & ((1ull << lane) - 1ull));
+                    if (pos < p.boundaryCapacity)
+                    {
+                        bnd[(size_t)pos * 3 + 0] = px;
+                        bnd[(size_t)pos * 3 + 1] = py;
+                        bnd[(size_t)pos * 3 + 2] = pz;
+                    }
+                }
+                nBoundary += __popcll(hb);
+                bCnt += (uint32_t)__popcll(hb);
+            }
+            if (nBoundary > p.boundaryCapacity)
+            {
+                status |= CAPE_FRAME_BOUNDARY_OVERFLOW;
+            }
+            if (bCnt >= 3)
+            {
+                isOutput = 1;
+                ++nPlanesOut;
+                onx = A.nx; ony = A.ny; onz = A.nz;
+                normalize3(onx, ony, onz); // Plane::_parametrization(planeSeg.get_normal(), d), shape_primitives.cpp:49
+                inverse3_sym(A.S, cov);
+            }
+            else
+            {
+                // rejected plane: its candidate points are dropped (reference: `continue` before emplace_back)
+                nBoundary = (int)bOff;
+                bCnt = 0;
+            }
+        }
+        if (lane == 0)
+        {
+            cape_plane_segment* o = &rec->segments[pi];
+            o->normal[0] = A.nx; o->normal[1] = A.ny; o->normal[2] = A.nz;
+            o->d = A.d;
+            o->centroid[0] = A.cx; o->centroid[1] = A.cy; o->centroid[2] = A.cz;
+            o->mse = A.mse;
+            o->score = A.score;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                o->sums[k] = A.S[k];
+            o->out_normal[0] = onx; o->out_normal[1] = ony; o->out_normal[2] = onz;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                o->cov[k] = cov[k];
+            o->point_count = (uint32_t)A.n;
+            o->merge_label = (uint32_t)mlabel;
+            o->planar = A.planar != 0.0 ? 1u : 0u;
+            o->is_output = isOutput;
+            o->boundary_offset = bOff;
+            o->boundary_count = bCnt;
+        }
+    }
+
+    // =========================================================================================
+    // label grids + header
+    // =========================================================================================
+    for (int i = lane; i < C; i += 64)
+    {
+        p.plane_labels[cellBase + i] = (int32_t)s_lab[i];
+        p.cyl_labels[cellBase + i] = (int32_t)s_cyl[i];
+    }
+    // fold the per-lane status bits
+    status = wave_or_u32(status);
+    if (lane == 0)
+    {
+        rec->header.n_plane_segments = nSeg;
+        rec->header.n_planes = nPlanesOut;
+        rec->header.n_cylinder_labels = nCylLabels;
+        rec->header.n_cylinders = 0;
+        rec->header.n_boundary_points = nBoundary < p.boundaryCapacity ? nBoundary : p.boundaryCapacity;
+        rec->header.n_seeds = nSeeds;
+        rec->header.status = status;
+        rec->header.n_planar_cells = nPlanar;
+    }
+}
+
+size_t grow_lds_bytes(int cells)
+{
+    size_t b = 0;
+    b += (size_t)cells * 8;                        // s_mse
+    b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
+    b += (size_t)CAPE_MAX_PLANES * 8;               // s_adj
+    b += (size_t)kHistBins * 4;                     // s_hist
+    b += (size_t)cells * 2;                         // s_bins
+    b += (size_t)cells * 2;                         // s_list
+    b += (size_t)cells * 2;                         // s_lab + s_cyl
+    b += 64;                                        // s_mlab
+    return (b + 15) & ~(size_t)15;
+}
+
+void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
+{
+    const size_t lds = grow_lds_bytes(p.cells);
+    if (p.hCells <= 32)
+        hipLaunchKernelGGL(cape_grow_kernel<uint32_t>, dim3(nFrames), dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL(cape_grow_kernel<unsigned long long>, dim3(nFrames), dim3(64), lds, stream, p);
+}
+
+} // namespace cape

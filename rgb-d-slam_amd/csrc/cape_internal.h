@@ -1,0 +1,68 @@
+// Internal device/host shared layouts of libcape_hip (not part of the C ABI).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/cape_hip.h"
+
+namespace cape {
+
+// Per-cell scratch written by stage A (cell fit) and read by stage B (grow).  HBM layout, per frame:
+//   cell_sums  [cells][10] f64 : Sx Sy Sz Sxs Sys Szs Sxy Syz Szx, point count (as f64) -- 80 B/cell, AoS so that
+//                                the ordered region accumulation reads one cell with a single 80-byte request
+//   cell_plane [cells][8]  f64 : nx ny nz d cx cy cz mse                               -- 64 B/cell
+//   cell_score [cells]     f64
+//   cell_tol   [cells]     f32 : _cellDistanceTols
+//   cell_flags [cells]     u32 : point count | inorder << 30 | planar << 31
+constexpr int kSumStride = 10;
+constexpr int kPlaneStride = 8;
+constexpr uint32_t kFlagPlanar = 1u << 31;
+constexpr uint32_t kFlagInorder = 1u << 30;
+constexpr uint32_t kCountMask = (1u << 30) - 1;
+
+struct StageAParams
+{
+    const float* depth; // frames x H x W
+    int W, H, hCells, vCells, cells;
+    int segsPerRow;     // ceil(hCells / 32): 640-pixel wide band segments per cell row
+    int bandsPerFrame;  // vCells * segsPerRow
+    int pairsPerFrame;  // ceil(bandsPerFrame / 2): workgroups per frame
+    const double* acol; // [W]  fl(fl(k00*u) + k02)
+    const double* brow; // [H]  fl(fl(k11*v) + k12)
+    const float* ratio_col; // [hCells] max|a| / min nonzero |a| over the cell's columns (exactness guard)
+    const float* ratio_row; // [vCells]
+    double* cell_sums;
+    double* cell_plane;
+    double* cell_score;
+    float* cell_tol;
+    uint32_t* cell_flags;
+    float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
+    int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
+};
+
+struct StageBParams
+{
+    const float* depth;
+    int W, H, hCells, vCells, cells;
+    const double* acol;
+    const double* brow;
+    const double* cell_sums;
+    const double* cell_plane;
+    const double* cell_score;
+    const float* cell_tol;
+    const uint32_t* cell_flags;
+    int32_t* cell_bins; // debug: Histogram::_bins after init_histogram
+    cape_frame_record* records;
+    int32_t* plane_labels;
+    int32_t* cyl_labels;
+    double* boundary;
+    int boundaryCapacity;
+    uint32_t flags;
+    double cosMerge;       // cos(18 * pi / 180), plane_segment.cpp:324
+    int planeSeedCount;    // uint(0.008 * cells), primitive_detection.cpp:278-279
+    int minCellActivated;  // uint(0.0065 * cells), primitive_detection.cpp:362-363
+    const double* rngTable; // first rngCount doubles of uniform_real_distribution(mt19937(0)), random.hpp:17-30
+    int rngCount;
+    int ransacMaxIterations; // 43
+};
+
+} // namespace cape

@@ -1,0 +1,224 @@
+"""ctypes binding of libcape_hip.so (the C ABI in include/cape_hip.h).
+
+This module is plumbing for tests and bench.py: it owns no algorithm.  It fails loudly when the HIP library
+is missing -- there is no CPU fallback anywhere in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # rgb-d-slam_amd/
+REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcape_hip.so")
+
+CAPE_MAX_PLANES = 64
+CAPE_MAX_CYLINDERS = 32
+CAPE_FLAG_CYLINDERS = 1
+
+FRAME_PLANE_OVERFLOW = 1 << 0
+FRAME_BOUNDARY_OVERFLOW = 1 << 1
+FRAME_CYL_OVERFLOW = 1 << 2
+FRAME_BIN_NEAR_EDGE = 1 << 3
+FRAME_INORDER_CELLS = 1 << 4
+FRAME_RNG_EXHAUSTED = 1 << 5
+
+
+class CapeError(RuntimeError):
+    pass
+
+
+class cape_config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_double), ("fy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("flags", C.c_uint32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("boundary_capacity", C.c_int32)]
+
+
+class cape_layout(C.Structure):
+    _fields_ = [("h_cells", C.c_int32), ("v_cells", C.c_int32), ("cells", C.c_int32),
+                ("boundary_capacity", C.c_int32), ("frame_record_bytes", C.c_uint64)]
+
+
+class cape_timings(C.Structure):
+    _fields_ = [("cell_fit_s", C.c_double), ("grow_s", C.c_double), ("total_s", C.c_double),
+                ("frames", C.c_uint64), ("calls", C.c_uint64)]
+
+
+# numpy mirrors of the record structs (natural C alignment; checked against frame_record_bytes at create)
+PLANE_SEGMENT_DTYPE = np.dtype([
+    ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"), ("score", "<f8"),
+    ("sums", "<f8", 9), ("out_normal", "<f8", 3), ("cov", "<f8", 9),
+    ("point_count", "<u4"), ("merge_label", "<u4"), ("planar", "<u4"), ("is_output", "<u4"),
+    ("boundary_offset", "<u4"), ("boundary_count", "<u4")], align=True)
+CYLINDER_DTYPE = np.dtype([("axis", "<f8", 3), ("radius", "<f8"), ("kept", "<u4"), ("region", "<u4")], align=True)
+HEADER_DTYPE = np.dtype([
+    ("n_plane_segments", "<i4"), ("n_planes", "<i4"), ("n_cylinder_labels", "<i4"), ("n_cylinders", "<i4"),
+    ("n_boundary_points", "<i4"), ("n_seeds", "<i4"), ("status", "<u4"), ("n_planar_cells", "<i4")], align=True)
+FRAME_RECORD_DTYPE = np.dtype([
+    ("header", HEADER_DTYPE), ("segments", PLANE_SEGMENT_DTYPE, CAPE_MAX_PLANES),
+    ("cylinders", CYLINDER_DTYPE, CAPE_MAX_CYLINDERS)], align=True)
+CELL_STATS_DTYPE = np.dtype([
+    ("sums", "<f8", 9), ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"),
+    ("score", "<f8"), ("tol", "<f4"), ("point_count", "<u4"), ("bin", "<i4"), ("planar", "<u4"),
+    ("inorder", "<u4"), ("pad", "<u4")], align=True)
+
+EXPORTED_SYMBOLS = [
+    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_host", "cape_device_results",
+    "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings", "cape_last_kernel_ms",
+    "cape_last_error", "cape_version", "cape_debug_eval",
+]
+DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
+
+_lib = None
+
+
+def load_library():
+    """dlopen libcape_hip.so; raises CapeError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CapeError(f"{LIB_PATH} is missing: build it with `make -C rgb-d-slam_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.cape_create.argtypes = [C.POINTER(cape_config), C.POINTER(vp)]
+    L.cape_destroy.argtypes = [vp]
+    L.cape_destroy.restype = None
+    L.cape_get_layout.argtypes = [vp, C.POINTER(cape_layout)]
+    L.cape_extract.argtypes = [vp, vp, C.c_int32, vp]
+    L.cape_extract_host.argtypes = [vp, vp, C.c_int32, vp]
+    L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    L.cape_copy_cell_stats.argtypes = [vp, C.c_int32, vp]
+    L.cape_enable_timing.argtypes = [vp, C.c_int32]
+    L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
+    L.cape_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
+    L.cape_last_error.restype = C.c_char_p
+    L.cape_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(L, code, what):
+    if code != 0:
+        raise CapeError(f"{what} failed ({code}): {L.cape_last_error().decode()}")
+
+
+class FrameResults:
+    """Host copy of one batch: records (structured array), label grids, boundary points."""
+
+    def __init__(self, records, plane_labels, cyl_labels, boundary):
+        self.records = records
+        self.plane_labels = plane_labels
+        self.cyl_labels = cyl_labels
+        self.boundary = boundary
+
+    def segments(self, f):
+        n = int(self.records["header"]["n_plane_segments"][f])
+        return self.records["segments"][f][:n]
+
+    def planes(self, f):
+        s = self.segments(f)
+        return s[s["is_output"] == 1]
+
+    def boundary_points(self, f, seg):
+        o, c = int(seg["boundary_offset"]), int(seg["boundary_count"])
+        return self.boundary[f, o:o + c]
+
+
+class Extractor:
+    """Thin owner of a cape_handle (mirrors the ctor pair of reference src/rgbd_slam.cpp:48-57)."""
+
+    def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=False, device=0,
+                 max_batch=64, boundary_capacity=0):
+        self.L = load_library()
+        cfg = cape_config(width, height, fx, fy, cx, cy, CAPE_FLAG_CYLINDERS if cylinders else 0, device, max_batch,
+                          boundary_capacity)
+        self.h = C.c_void_p()
+        _check(self.L, self.L.cape_create(C.byref(cfg), C.byref(self.h)), "cape_create")
+        lay = cape_layout()
+        _check(self.L, self.L.cape_get_layout(self.h, C.byref(lay)), "cape_get_layout")
+        assert lay.frame_record_bytes == FRAME_RECORD_DTYPE.itemsize, (lay.frame_record_bytes, FRAME_RECORD_DTYPE.itemsize)
+        self.width, self.height, self.max_batch = width, height, max_batch
+        self.cells, self.h_cells, self.v_cells = lay.cells, lay.h_cells, lay.v_cells
+        self.boundary_capacity = lay.boundary_capacity
+        self.record_bytes = int(lay.frame_record_bytes)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.cape_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- launches ------------------------------------------------------------------------------
+    def extract_device(self, depth_ptr, n_frames, stream=0):
+        """depth_ptr: integer device address of n_frames x H x W float32 (e.g. torch_tensor.data_ptr())."""
+        _check(self.L, self.L.cape_extract(self.h, C.c_void_p(depth_ptr), n_frames, C.c_void_p(stream)), "cape_extract")
+
+    def extract_host(self, depth, stream=0):
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        if d.ndim == 2:
+            d = d[None]
+        assert d.shape[1:] == (self.height, self.width)
+        _check(self.L, self.L.cape_extract_host(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0], C.c_void_p(stream)),
+               "cape_extract_host")
+        return d.shape[0]
+
+    # ---- results -------------------------------------------------------------------------------
+    def device_pointers(self):
+        rec, pl, cl, bd = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self.L, self.L.cape_device_results(self.h, C.byref(rec), C.byref(pl), C.byref(cl), C.byref(bd)),
+               "cape_device_results")
+        return rec.value, pl.value, cl.value, bd.value
+
+    def results(self, n_frames, with_boundary=True):
+        rec = np.zeros(n_frames, FRAME_RECORD_DTYPE)
+        pl = np.zeros((n_frames, self.cells), np.int32)
+        cl = np.zeros((n_frames, self.cells), np.int32)
+        bd = np.zeros((n_frames, self.boundary_capacity, 3), np.float64) if with_boundary else None
+        _check(self.L, self.L.cape_copy_results(self.h, n_frames, rec.ctypes.data_as(C.c_void_p),
+                                                pl.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p),
+                                                bd.ctypes.data_as(C.c_void_p) if with_boundary else None),
+               "cape_copy_results")
+        return FrameResults(rec, pl, cl, bd)
+
+    def cell_stats(self, frame):
+        out = np.zeros(self.cells, CELL_STATS_DTYPE)
+        _check(self.L, self.L.cape_copy_cell_stats(self.h, frame, out.ctypes.data_as(C.c_void_p)), "cape_copy_cell_stats")
+        return out
+
+    # ---- timing --------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        _check(self.L, self.L.cape_enable_timing(self.h, 1 if on else 0), "cape_enable_timing")
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(self.L, self.L.cape_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "cape_last_kernel_ms")
+        return a.value, b.value
+
+    def timings(self):
+        t = cape_timings()
+        _check(self.L, self.L.cape_get_timings(self.h, C.byref(t)), "cape_get_timings")
+        return dict(cell_fit_s=t.cell_fit_s, grow_s=t.grow_s, total_s=t.total_s, frames=t.frames, calls=t.calls)
+
+
+def debug_eval(op, a, b=None):
+    """Evaluate device scalar math on host operands (parity tests)."""
+    L = load_library()
+    a = np.ascontiguousarray(a, np.float64)
+    n = a.shape[0]
+    out_w = {"eigen3": 12, "fit_plane": 10}.get(op, 1)
+    out = np.zeros((n, out_w) if out_w > 1 else n, np.float64)
+    bb = np.ascontiguousarray(b, np.float64) if b is not None else None
+    _check(L, L.cape_debug_eval(DEBUG_OPS[op], a.ctypes.data_as(C.c_void_p),
+                                bb.ctypes.data_as(C.c_void_p) if bb is not None else None,
+                                out.ctypes.data_as(C.c_void_p), n), "cape_debug_eval")
+    return out

@@ -1,0 +1,155 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Contract (SURVEY.md 8a 'parity observables'): integers / labels / flags bit-exact; every f64/f32 observable
+bit-exact against the oracle as well (same IEEE operation sequence, contraction off) -- tolerance 0.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCENES = [("room", 0, 0), ("room", 3, 17), ("tumlike", 1, 0), ("tumlike", 2, 5), ("tunnel", 0, 0), ("tunnel", 4, 9)]
+
+
+def _intr(scene, scale=1.0):
+    from cape_amd import synth
+
+    base = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+    return {k: v * scale for k, v in base.items()}
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def compare_frame(orc_res, ex, res, f, check_cells=True):
+    """orc_res: OracleResult ; ex: Extractor ; res: FrameResults ; f: frame index in the batch."""
+    if check_cells:
+        cs = ex.cell_stats(f)
+        assert np.array_equal(cs["planar"], orc_res.planar), "planar flags"
+        assert np.array_equal(cs["point_count"], orc_res.n), "point counts"
+        assert np.array_equal(_bits(cs["sums"]), _bits(orc_res.sums)), "cell sums (bitwise)"
+        assert np.array_equal(_bits(cs["centroid"]), _bits(orc_res.centroid)), "centroid"
+        assert np.array_equal(_bits(cs["normal"]), _bits(orc_res.normal)), "normal"
+        assert np.array_equal(_bits(cs["d"]), _bits(orc_res.d)), "d"
+        assert np.array_equal(_bits(cs["mse"]), _bits(orc_res.mse)), "mse"
+        assert np.array_equal(_bits(cs["score"]), _bits(orc_res.score)), "score"
+        assert np.array_equal(_bits(cs["tol"]), _bits(orc_res.tol)), "tolerances (f32 bitwise)"
+        assert np.array_equal(cs["bin"], orc_res.bins), "histogram bins"
+    hdr = res.records["header"][f]
+    assert hdr["n_seeds"] == len(orc_res.seeds), "seed loop length"
+    assert np.array_equal(res.plane_labels[f], orc_res.plane_labels), "plane label grid (bit-exact)"
+    assert np.array_equal(res.cyl_labels[f], orc_res.cyl_labels), "cylinder label grid (bit-exact)"
+    segs = res.segments(f)
+    assert len(segs) == len(orc_res.segments)
+    if len(segs):
+        o = orc_res.segments
+        assert np.array_equal(segs["merge_label"], orc_res.merge_labels), "planeMergeLabels"
+        assert np.array_equal(_bits(segs["normal"]), _bits(o[:, 0:3])), "segment normal"
+        assert np.array_equal(_bits(segs["d"]), _bits(o[:, 3])), "segment d"
+        assert np.array_equal(_bits(segs["centroid"]), _bits(o[:, 4:7])), "segment centroid"
+        assert np.array_equal(_bits(segs["mse"]), _bits(o[:, 7])), "segment mse"
+        assert np.array_equal(_bits(segs["score"]), _bits(o[:, 8])), "segment score"
+        assert np.array_equal(_bits(segs["sums"]), _bits(o[:, 9:18])), "segment sums"
+        assert np.array_equal(segs["point_count"], o[:, 18].astype(np.uint32)), "segment n"
+        assert np.array_equal(segs["planar"], o[:, 19].astype(np.uint32)), "segment planar"
+    planes = res.planes(f)
+    assert len(planes) == len(orc_res.planes) == hdr["n_planes"]
+    for k, pl in enumerate(planes):
+        o = orc_res.planes[k]
+        assert np.array_equal(_bits(pl["out_normal"]), _bits(o[0:3])), "plane normal"
+        assert _bits(pl["d"]) == _bits(o[3:4])[0], "plane d"
+        assert np.array_equal(_bits(pl["cov"]), _bits(o[10:19])), "point cloud covariance"
+        b_gpu = res.boundary_points(f, pl)
+        b_orc = orc_res.boundary[k]
+        # the reference's point order is nondeterministic (parallel forEach): compare as sets
+        assert sorted(map(tuple, _bits(b_gpu).tolist())) == sorted(map(tuple, _bits(b_orc).tolist())), "boundary points"
+
+
+@pytest.mark.parametrize("scene,seed,frame", SCENES)
+def test_frame_parity_640(oracle_mod, scene, seed, frame):
+    from cape_amd import Extractor, synth
+
+    depth = synth.SCENES[scene](seed=seed, frame=frame)
+    intr = _intr(scene)
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    r = orc.run(depth)
+    ex = Extractor(640, 480, cylinders=False, max_batch=4, **intr)
+    n = ex.extract_host(depth)
+    res = ex.results(n)
+    compare_frame(r, ex, res, 0)
+    ex.close()
+
+
+def test_batch_matches_single_frames(oracle_mod):
+    """A batch is frames processed independently: every frame of a mixed batch equals its own oracle run."""
+    from cape_amd import Extractor, synth
+
+    frames = np.stack([synth.room(seed=5, frame=i * 7) for i in range(6)])
+    frames[2] = 0.0                      # empty frame (all invalid)
+    frames[4, :, 320:] = 0.0             # half-empty frame
+    intr = _intr("room")
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    ex = Extractor(640, 480, cylinders=False, max_batch=8, **intr)
+    n = ex.extract_host(frames)
+    res = ex.results(n)
+    for f in range(n):
+        compare_frame(orc.run(frames[f]), ex, res, f)
+    assert res.records["header"]["n_plane_segments"][2] == 0
+    ex.close()
+
+
+def test_edge_inputs(oracle_mod):
+    """NaN / negative / huge depths, ragged holes, constant depth (degenerate scatter -> rejected cells)."""
+    from cape_amd import Extractor, synth
+
+    rng = np.random.default_rng(7)
+    base = synth.tumlike(seed=3, frame=1)
+    a = base.copy()
+    a[rng.random(a.shape) < 0.35] = 0.0          # ragged: 35 % holes
+    b = base.copy()
+    b[100:140, 200:260] = np.nan
+    b[300:330, 50:90] = -5.0
+    b[10:12, :] = 65535.0
+    c = np.full_like(base, 1500.0)               # fronto-parallel, noise-free: det == 0 -> no planar cell
+    d = base.copy()
+    d[:, ::2] *= 1.6                             # violent discontinuities in every cell
+    frames = np.stack([a, b, c, d])
+    intr = _intr("tumlike")
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    ex = Extractor(640, 480, cylinders=False, max_batch=4, **intr)
+    n = ex.extract_host(frames)
+    res = ex.results(n)
+    for f in range(n):
+        compare_frame(orc.run(frames[f]), ex, res, f)
+    ex.close()
+
+
+def test_parity_1280x960(oracle_mod):
+    from cape_amd import Extractor, synth
+
+    intr = _intr("room", 2.0)
+    depth = synth.room(seed=2, frame=11, width=1280, height=960)
+    orc = oracle_mod.Oracle(1280, 960, cylinders=False, **intr)
+    ex = Extractor(1280, 960, cylinders=False, max_batch=2, **intr)
+    n = ex.extract_host(depth)
+    res = ex.results(n)
+    compare_frame(orc.run(depth), ex, res, 0)
+    ex.close()
+
+
+def test_inorder_guard_path(oracle_mod):
+    """Intrinsics with a near-zero column factor force the exactness guard onto the in-order path; still bit-exact."""
+    from cape_amd import Extractor, synth
+
+    intr = dict(fx=550.0, fy=550.0, cx=320.0000001, cy=240.0000001)
+    depth = synth.room(seed=9, frame=3)
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    ex = Extractor(640, 480, cylinders=False, max_batch=1, **intr)
+    n = ex.extract_host(depth)
+    res = ex.results(n)
+    cs = ex.cell_stats(0)
+    assert cs["inorder"].sum() > 0
+    compare_frame(orc.run(depth), ex, res, 0)
+    ex.close()
