@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/s of CAPE primitive extraction on MI355X (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[1], "640x480 synthetic planar-room depth stream, 1xMI355X, plane extraction
+only".  A *step* is one pass of the hot path (stage A cell fit + stage B grow/merge/boundary) over one batch of
+`--frames` synthetic frames that are already resident in HBM.  With N>1 (one process per GPU, launched by
+torch.distributed.run) every rank runs the same per-GPU batch on its own stream of frames (weak scaling) and the
+per-frame primitive lists are exchanged with one RCCL all-gather per step.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description) with two extra objects:
+  roofline     -- the dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the
+                  launch stream, inside the timed region) against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm, NOT the product) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rgb-d-slam_amd", "python"))
+
+HBM_PEAK_BYTES_S = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak BW, spec
+
+
+class _DevMem:
+    """Expose a raw device allocation of libcape_hip to torch (no copy) for the RCCL gather."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(unique_frames, intr, budget_s=12.0):
+    """Oracle (port of the reference CPU path) on this host: 1 thread (how the reference runs it), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
+
+    import numpy as np
+
+    import cape_oracle_py as O
+
+    H, W = unique_frames.shape[1:]
+    orc = O.Oracle(W, H, cylinders=False, **intr)
+    orc.run_many(unique_frames[:2])  # warm-up
+    t0 = time.perf_counter()
+    orc.run_many(unique_frames[:8])
+    per_frame = (time.perf_counter() - t0) / 8
+    n = int(max(32, min(4000, budget_s * 0.5 / per_frame)))
+    reps = -(-n // unique_frames.shape[0])
+    sample = np.concatenate([unique_frames] * reps)[:n]
+    t0 = time.perf_counter()
+    orc.run_many(sample)
+    dt1 = time.perf_counter() - t0
+    # frame-parallel over all host cores (BASELINE.md mode B), same sample
+    cores = os.cpu_count() or 1
+    oracles = [O.Oracle(W, H, cylinders=False, **intr) for _ in range(cores)]
+    chunks = np.array_split(sample, cores)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as pool:
+        list(pool.map(lambda a: a[0].run_many(a[1]), zip(oracles, chunks)))
+    dtn = time.perf_counter() - t0
+    return {
+        "value": n / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{n} frames of the same room stream, oracle/libcape_oracle.so (g++ -O2 -ffp-contract=off), "
+                  f"{dt1:.1f} s single thread",
+        "all_cores": {"value": n / dtn, "cores": cores, "seconds": dtn},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per step per GPU (resident in HBM)")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated per GPU, tiled to --frames")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--scene", default="room")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    W, H, B = args.width, args.height, args.frames
+    scale = W / 640.0
+    base_intr = synth.TUM_FR1_INTRINSICS if args.scene == "tumlike" else synth.DEFAULT_INTRINSICS
+    intr = {k: v * scale for k, v in base_intr.items()}
+
+    # ---- synthetic stream, resident in HBM before the timed region
+    U = min(args.unique, B)
+    unique = synth.stream(args.scene, seed=100 + rank, n_frames=U, width=W, height=H)
+    reps = -(-B // U)
+    depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
+    torch.cuda.synchronize()
+
+    ex = Extractor(W, H, cylinders=False, device=local_rank, max_batch=B, **intr)
+    stream = torch.cuda.current_stream().cuda_stream
+    summ_bytes = B * SUMMARY_DTYPE.itemsize
+    gathered = None
+    summ_t = None
+    if world > 1:
+        summ_t = torch.as_tensor(_DevMem(ex.summaries_pointer(), summ_bytes), device="cuda")
+        gathered = torch.empty(world * summ_bytes, dtype=torch.uint8, device="cuda")
+
+    def step():
+        ex.extract_device(depth.data_ptr(), B, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, summ_t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ex.reset_timings()
+    ex.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ex.enable_timing(False)
+    tm = ex.timings()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        frames_total = world * B * args.steps
+        cells = (W // 20) * (H // 20)
+        a_ms = 1e3 * tm["cell_fit_s"] / max(1, tm["calls"])
+        b_ms = 1e3 * tm["grow_s"] / max(1, tm["calls"])
+        # algorithmic bytes per launch (DESIGN.md "Measurement"): stage A reads each depth pixel once and writes
+        # 160 B of per-cell statistics; stage B reads those statistics once and writes label grids + primitive lists
+        bytes_a = B * (W * H * 4 + cells * 160)
+        bytes_b = B * (cells * 160 + 2 * cells * 4 + 32 * 128)
+        if a_ms >= b_ms:
+            dom, dom_ms, dom_bytes = "cape_cell_fit_kernel", a_ms, bytes_a
+        else:
+            dom, dom_ms, dom_bytes = "cape_grow_kernel", b_ms, bytes_b
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("kernel") == dom and tj.get("frames_per_launch") == B and tj.get("width") == W:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        e2e_bytes_per_frame = W * H * 4 + 2 * cells * 4 + 32 * 128  # 1 239 040 B at 640x480
+        out = {
+            "metric": "depth frames/s primitive extraction (640x480)" if (W, H) == (640, 480)
+                      else f"depth frames/s primitive extraction ({W}x{H})",
+            "value": frames_total / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])",
+                "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene,
+                "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
+                "stage_a_ms": a_ms, "stage_b_ms": b_ms,
+                "end_to_end_GBps": frames_total / world * e2e_bytes_per_frame / elapsed / 1e9,
+                "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(unique, intr)
+        print(json.dumps(out), flush=True)
+
+    ex.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

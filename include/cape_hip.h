@@ -120,6 +120,32 @@ typedef struct cape_frame_record
     cape_cylinder cylinders[CAPE_MAX_CYLINDERS];
 } cape_frame_record;
 
+/* Compact per-frame primitive list: what plane_container / cylinder_container hold after find_primitives
+ * (shape_primitives.hpp:129-130), without polygons.  This is the payload of the multi-GPU gather
+ * (SURVEY.md 8e): 1296 bytes per frame; the full cape_frame_record, label grids and boundary points stay on the
+ * producing GPU. */
+#define CAPE_SUMMARY_PLANES 16
+#define CAPE_SUMMARY_CYLINDERS 8
+typedef struct cape_primitive_summary
+{
+    int32_t n_planes;       /* may exceed CAPE_SUMMARY_PLANES: only the first 16 are listed */
+    int32_t n_cylinders;
+    uint32_t status;        /* CAPE_FRAME_* */
+    int32_t n_plane_segments;
+    struct
+    {
+        double normal[3];   /* Plane::get_normal() */
+        double d;           /* Plane::get_d() */
+        double centroid[3];
+        double mse;
+    } planes[CAPE_SUMMARY_PLANES];
+    struct
+    {
+        double axis[3];
+        double radius;
+    } cylinders[CAPE_SUMMARY_CYLINDERS];
+} cape_primitive_summary;
+
 /* Per-cell statistics (debug / parity access to Primitive_Detection::_planeGrid, _cellDistanceTols,
  * Histogram::_bins; primitive_detection.hpp:205-218).  One struct per cell, cell-row-major. */
 typedef struct cape_cell_stats
@@ -146,7 +172,7 @@ typedef struct cape_timings
     double grow_s;          /* _growTime + _mergeTime + _refineTime : stage B kernel */
     double total_s;
     uint64_t frames;
-    uint64_t calls;
+    uint64_t calls;         /* number of cape_extract calls folded into the sums (= launches of each kernel) */
 } cape_timings;
 
 typedef struct cape_layout
@@ -178,6 +204,8 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
  * (_gridPlaneSegmentMap / _gridCylinderSegMap, primitive_detection.hpp:212-214) ; boundary: n_frames x
  * boundary_capacity x 3 doubles (compute_plane_segment_boundary, primitive_detection.cpp:650-703). */
 int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, int32_t** cyl_labels, double** boundary);
+/* Device pointer to n_frames x cape_primitive_summary of the last cape_extract (the gather payload). */
+int cape_device_summaries(cape_handle h, void** summaries);
 
 /* Synchronous D2H of the results of the last cape_extract.  Any pointer may be NULL. */
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
@@ -186,11 +214,12 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
 /* Debug / parity: per-cell stats of one frame of the last batch (synchronous). */
 int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* cells_out);
 
-/* show_statistics (primitive_detection.hpp:46-49): stage timings from HIP events. */
+/* show_statistics (primitive_detection.hpp:46-49): stage timings from HIP events recorded on the caller's stream
+ * around each kernel of every cape_extract made while timing is enabled.  cape_get_timings synchronises the
+ * pending events, folds them into the running sums and returns the sums; cape_reset_timings zeroes them. */
 int cape_enable_timing(cape_handle h, int32_t enable);
 int cape_get_timings(cape_handle h, cape_timings* out);
-/* duration in ms of the last stage A / stage B kernel launches (needs timing enabled; synchronises) */
-int cape_last_kernel_ms(cape_handle h, float* stage_a_ms, float* stage_b_ms);
+int cape_reset_timings(cape_handle h);
 
 /* Debug / parity: evaluate device scalar math (f64 sqrt / div, ocml acos / atan2, the eigen-solver and plane fit)
  * on host operands so tests can compare gfx950 results with the CPU oracle bit for bit.  `a`,`b`,`out` are HOST

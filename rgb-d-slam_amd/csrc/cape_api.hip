@@ -59,15 +59,21 @@ struct cape_handle_s
     int32_t* cellBins = nullptr;
     // results
     cape_frame_record* records = nullptr;
+    cape_primitive_summary* summaries = nullptr;
     int32_t* planeLabels = nullptr;
     int32_t* cylLabels = nullptr;
     double* boundary = nullptr;
     // host staging for cape_extract_host
     float* depthStage = nullptr;
-    // timing
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // timing: one event triple per timed cape_extract, folded lazily by cape_get_timings
+    struct EvTriple
+    {
+        hipEvent_t e[3];
+        int frames;
+    };
+    std::vector<EvTriple> evPool;   // created on demand, reused
+    size_t evPending = 0;           // triples [0, evPending) hold unread measurements
     bool timing = false;
-    bool evValid = false;
     cape_timings tm{};
     int lastFrames = 0;
     cape::StageAParams pa{};
@@ -111,13 +117,34 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cellFlags);
     (void)hipFree(h->cellBins);
     (void)hipFree(h->records);
+    (void)hipFree(h->summaries);
     (void)hipFree(h->planeLabels);
     (void)hipFree(h->cylLabels);
     (void)hipFree(h->boundary);
     (void)hipFree(h->depthStage);
-    for (auto& e : h->ev)
-        if (e)
-            (void)hipEventDestroy(e);
+    for (auto& t : h->evPool)
+        for (auto& e : t.e)
+            if (e)
+                (void)hipEventDestroy(e);
+}
+
+int fold_timings(cape_handle_s* h)
+{
+    for (size_t i = 0; i < h->evPending; ++i)
+    {
+        auto& t = h->evPool[i];
+        CAPE_HIP_TRY(hipEventSynchronize(t.e[2]));
+        float a = 0, b = 0;
+        CAPE_HIP_TRY(hipEventElapsedTime(&a, t.e[0], t.e[1]));
+        CAPE_HIP_TRY(hipEventElapsedTime(&b, t.e[1], t.e[2]));
+        h->tm.cell_fit_s += a * 1e-3;
+        h->tm.grow_s += b * 1e-3;
+        h->tm.total_s += (a + b) * 1e-3;
+        h->tm.frames += (uint64_t)t.frames;
+        h->tm.calls += 1;
+    }
+    h->evPending = 0;
+    return CAPE_OK;
 }
 
 } // namespace
@@ -181,11 +208,10 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellFlags, B * C));
     CAPE_ALLOC(dalloc(h->cellBins, B * C));
     CAPE_ALLOC(dalloc(h->records, B));
+    CAPE_ALLOC(dalloc(h->summaries, B));
     CAPE_ALLOC(dalloc(h->planeLabels, B * C));
     CAPE_ALLOC(dalloc(h->cylLabels, B * C));
     CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
-    for (auto& e : h->ev)
-        CAPE_ALLOC(hipEventCreate(&e));
 
     // ---- constant tables
     double k00, k02, k11, k12;
@@ -230,6 +256,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(hipMemcpy(h->ratioRow, rr.data(), rr.size() * sizeof(float), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
+    CAPE_ALLOC(hipMemset(h->summaries, 0, B * sizeof(cape_primitive_summary)));
 
     // ---- kernel parameter blocks
     cape::StageAParams& a = h->pa;
@@ -270,6 +297,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cell_flags = h->cellFlags;
     b.cell_bins = h->cellBins;
     b.records = h->records;
+    b.summaries = h->summaries;
     b.plane_labels = h->planeLabels;
     b.cyl_labels = h->cylLabels;
     b.boundary = h->boundary;
@@ -326,16 +354,37 @@ int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     h->pa.depth = depth_dev;
     h->pb.depth = depth_dev;
-    if (h->timing)
-        CAPE_HIP_TRY(hipEventRecord(h->ev[0], stream));
-    cape::launch_cell_fit(h->pa, n_frames, stream);
-    if (h->timing)
-        CAPE_HIP_TRY(hipEventRecord(h->ev[1], stream));
-    cape::launch_grow(h->pb, n_frames, stream);
+    cape_handle_s::EvTriple* t = nullptr;
     if (h->timing)
     {
-        CAPE_HIP_TRY(hipEventRecord(h->ev[2], stream));
-        h->evValid = true;
+        if (h->evPending == h->evPool.size())
+        {
+            if (h->evPool.size() >= 4096)
+            {
+                const int rc = fold_timings(h); // synchronises; keeps the pool bounded
+                if (rc != CAPE_OK)
+                    return rc;
+            }
+            else
+            {
+                cape_handle_s::EvTriple nt{};
+                for (auto& e : nt.e)
+                    CAPE_HIP_TRY(hipEventCreate(&e));
+                h->evPool.push_back(nt);
+            }
+        }
+        t = &h->evPool[h->evPending];
+        t->frames = n_frames;
+        CAPE_HIP_TRY(hipEventRecord(t->e[0], stream));
+    }
+    cape::launch_cell_fit(h->pa, n_frames, stream);
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[1], stream));
+    cape::launch_grow(h->pb, n_frames, stream);
+    if (t)
+    {
+        CAPE_HIP_TRY(hipEventRecord(t->e[2], stream));
+        h->evPending += 1;
     }
     CAPE_HIP_TRY(hipGetLastError());
     return CAPE_OK;
@@ -426,35 +475,19 @@ int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* out)
     return CAPE_OK;
 }
 
+int cape_device_summaries(cape_handle h, void** summaries)
+{
+    if (!h || !summaries)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    *summaries = h->summaries;
+    return CAPE_OK;
+}
+
 int cape_enable_timing(cape_handle h, int32_t enable)
 {
     if (!h)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
     h->timing = enable != 0;
-    h->evValid = false;
-    return CAPE_OK;
-}
-
-int cape_last_kernel_ms(cape_handle h, float* a_ms, float* b_ms)
-{
-    if (!h)
-        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
-    if (!h->evValid)
-        return fail(CAPE_ERR_INVALID_ARGUMENT, "timing not enabled or no extract since it was enabled");
-    CAPE_HIP_TRY(hipEventSynchronize(h->ev[2]));
-    float a = 0, b = 0;
-    CAPE_HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    CAPE_HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    if (a_ms)
-        *a_ms = a;
-    if (b_ms)
-        *b_ms = b;
-    h->tm.cell_fit_s += a * 1e-3;
-    h->tm.grow_s += b * 1e-3;
-    h->tm.total_s += (a + b) * 1e-3;
-    h->tm.frames += (uint64_t)h->lastFrames;
-    h->tm.calls += 1;
-    h->evValid = false;
     return CAPE_OK;
 }
 
@@ -462,8 +495,20 @@ int cape_get_timings(cape_handle h, cape_timings* out)
 {
     if (!h || !out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = fold_timings(h);
+    if (rc != CAPE_OK)
+        return rc;
     *out = h->tm;
     return CAPE_OK;
+}
+
+int cape_reset_timings(cape_handle h)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    const int rc = fold_timings(h);
+    h->tm = cape_timings{};
+    return rc;
 }
 
 } // extern "C"

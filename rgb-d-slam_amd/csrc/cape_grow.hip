@@ -546,6 +546,7 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
     // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
     // =========================================================================================
     cape_frame_record* rec = p.records + frame;
+    cape_primitive_summary* sum = p.summaries + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
     const float* depthF = p.depth + (size_t)frame * p.W * p.H;
     int nBoundary = 0;
@@ -658,6 +659,14 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
             o->is_output = isOutput;
             o->boundary_offset = bOff;
             o->boundary_count = bCnt;
+            if (isOutput && nPlanesOut <= CAPE_SUMMARY_PLANES)
+            {
+                auto& sp = sum->planes[nPlanesOut - 1];
+                sp.normal[0] = onx; sp.normal[1] = ony; sp.normal[2] = onz;
+                sp.d = A.d;
+                sp.centroid[0] = A.cx; sp.centroid[1] = A.cy; sp.centroid[2] = A.cz;
+                sp.mse = A.mse;
+            }
         }
     }
 
@@ -681,6 +690,10 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
         rec->header.n_seeds = nSeeds;
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
+        sum->n_planes = nPlanesOut;
+        sum->n_cylinders = 0;
+        sum->status = status;
+        sum->n_plane_segments = nSeg;
     }
 }
 

@@ -52,6 +52,7 @@ struct StageBParams
     const uint32_t* cell_flags;
     int32_t* cell_bins; // debug: Histogram::_bins after init_histogram
     cape_frame_record* records;
+    cape_primitive_summary* summaries;
     int32_t* plane_labels;
     int32_t* cyl_labels;
     double* boundary;

@@ -58,6 +58,11 @@ HEADER_DTYPE = np.dtype([
 FRAME_RECORD_DTYPE = np.dtype([
     ("header", HEADER_DTYPE), ("segments", PLANE_SEGMENT_DTYPE, CAPE_MAX_PLANES),
     ("cylinders", CYLINDER_DTYPE, CAPE_MAX_CYLINDERS)], align=True)
+SUMMARY_DTYPE = np.dtype([
+    ("n_planes", "<i4"), ("n_cylinders", "<i4"), ("status", "<u4"), ("n_plane_segments", "<i4"),
+    ("planes", np.dtype([("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8")]), 16),
+    ("cylinders", np.dtype([("axis", "<f8", 3), ("radius", "<f8")]), 8)], align=True)
+assert SUMMARY_DTYPE.itemsize == 1296
 CELL_STATS_DTYPE = np.dtype([
     ("sums", "<f8", 9), ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"),
     ("score", "<f8"), ("tol", "<f4"), ("point_count", "<u4"), ("bin", "<i4"), ("planar", "<u4"),
@@ -65,7 +70,8 @@ CELL_STATS_DTYPE = np.dtype([
 
 EXPORTED_SYMBOLS = [
     "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_host", "cape_device_results",
-    "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings", "cape_last_kernel_ms",
+    "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
+    "cape_reset_timings",
     "cape_last_error", "cape_version", "cape_debug_eval",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
@@ -94,7 +100,8 @@ def load_library():
     L.cape_copy_cell_stats.argtypes = [vp, C.c_int32, vp]
     L.cape_enable_timing.argtypes = [vp, C.c_int32]
     L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
-    L.cape_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.cape_reset_timings.argtypes = [vp]
+    L.cape_device_summaries.argtypes = [vp, C.POINTER(vp)]
     L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
     L.cape_last_error.restype = C.c_char_p
     L.cape_version.restype = C.c_char_p
@@ -199,10 +206,13 @@ class Extractor:
     def enable_timing(self, on=True):
         _check(self.L, self.L.cape_enable_timing(self.h, 1 if on else 0), "cape_enable_timing")
 
-    def last_kernel_ms(self):
-        a, b = C.c_float(0), C.c_float(0)
-        _check(self.L, self.L.cape_last_kernel_ms(self.h, C.byref(a), C.byref(b)), "cape_last_kernel_ms")
-        return a.value, b.value
+    def reset_timings(self):
+        _check(self.L, self.L.cape_reset_timings(self.h), "cape_reset_timings")
+
+    def summaries_pointer(self):
+        p = C.c_void_p()
+        _check(self.L, self.L.cape_device_summaries(self.h, C.byref(p)), "cape_device_summaries")
+        return p.value
 
     def timings(self):
         t = cape_timings()
