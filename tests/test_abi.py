@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a box without a GPU, exports every function include/cape_hip.h declares, and its
+record layouts match the numpy mirrors used by the tests.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "cape_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cape_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import cape_amd
+
+    lib = cape_amd.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in cape_hip.h but not exported"
+    assert set(cape_amd.EXPORTED_SYMBOLS) == set(declared)
+
+
+def test_struct_sizes_match_header():
+    import cape_amd
+
+    assert cape_amd.PLANE_SEGMENT_DTYPE.itemsize == 30 * 8 + 6 * 4
+    assert cape_amd.CYLINDER_DTYPE.itemsize == 40
+    assert cape_amd.HEADER_DTYPE.itemsize == 32
+    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 32 * 40
+    assert cape_amd.SUMMARY_DTYPE.itemsize == 1296
+    assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device cape_create must fail with CAPE_ERR_NO_DEVICE (-2), never compute on the CPU."""
+    import pytest
+    import torch
+
+    import cape_amd
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = cape_amd.load_library()
+    cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0)
+    h = C.c_void_p()
+    assert lib.cape_create(C.byref(cfg), C.byref(h)) == -2
+    assert b"no CPU fallback" in lib.cape_last_error()
+    bad = cape_amd.cape_config(641, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0)
+    assert lib.cape_create(C.byref(bad), C.byref(h)) == -1
+
+
+def test_product_never_touches_oracle():
+    """The product tree must not reference oracle/ (SURVEY / task rule: the oracle is the checker only)."""
+    pkg = os.path.join(ROOT, "rgb-d-slam_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "cape_oracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
