@@ -15,7 +15,7 @@
 namespace cape {
 void launch_cell_fit(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
-size_t grow_lds_bytes(int cells);
+size_t grow_lds_bytes(int cells, bool cylinders);
 } // namespace cape
 
 namespace {
@@ -50,6 +50,7 @@ struct cape_handle_s
     float* ratioCol = nullptr;
     float* ratioRow = nullptr;
     double* rng = nullptr;
+    double* cylScratch = nullptr;
     // per-frame scratch (stage A -> stage B)
     double* cellSums = nullptr;
     double* cellPlane = nullptr;
@@ -110,6 +111,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->ratioCol);
     (void)hipFree(h->ratioRow);
     (void)hipFree(h->rng);
+    (void)hipFree(h->cylScratch);
     (void)hipFree(h->cellSums);
     (void)hipFree(h->cellPlane);
     (void)hipFree(h->cellScore);
@@ -164,8 +166,6 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "width/height must be positive multiples of 20, <= 1280; max_batch > 0");
     if (!(cfg->fx > 0) || !(cfg->fy > 0))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "focal lengths must be positive");
-    if (cfg->flags & CAPE_FLAG_CYLINDERS)
-        return fail(CAPE_ERR_UNSUPPORTED, "cylinder RANSAC is not available in this build");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -207,6 +207,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellTol, B * C));
     CAPE_ALLOC(dalloc(h->cellFlags, B * C));
     CAPE_ALLOC(dalloc(h->cellBins, B * C));
+    if (cfg->flags & CAPE_FLAG_CYLINDERS)
+        CAPE_ALLOC(dalloc(h->cylScratch, B * C * 6));
     CAPE_ALLOC(dalloc(h->records, B));
     CAPE_ALLOC(dalloc(h->summaries, B));
     CAPE_ALLOC(dalloc(h->planeLabels, B * C));
@@ -306,12 +308,13 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cosMerge = std::cos(static_cast<double>(18.0f) * M_PI / 180.0); // plane_segment.cpp:324
     b.planeSeedCount = static_cast<int>(static_cast<unsigned>((0.8 / 100.0) * h->cells));
     b.minCellActivated = static_cast<int>(static_cast<unsigned>((0.65 / 100.0) * h->cells));
+    b.cylScratch = h->cylScratch;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;
     // cylinder_segment.cpp:132
     b.ransacMaxIterations = static_cast<int>(static_cast<unsigned>(logf(1.0f - 0.8f) / logf(1.0f - powf(0.33f, 3.0f))));
 
-    if (cape::grow_lds_bytes(h->cells) > 160 * 1024)
+    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0) > 160 * 1024)
     {
         free_all(h);
         delete h;

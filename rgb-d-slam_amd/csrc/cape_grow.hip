@@ -18,6 +18,7 @@
 // No workgroup barrier is needed: all cross-lane traffic is wave-synchronous (LDS + ballots).
 #include <hip/hip_runtime.h>
 
+#include "cape_cylinder.h"
 #include "cape_device.h"
 #include "cape_internal.h"
 
@@ -160,7 +161,7 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
     r[8] = cof(2, 2) * invdet;
 }
 
-template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel(StageBParams p)
+template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_grow_kernel(StageBParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -178,6 +179,11 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
     unsigned char* s_cyl = s_lab + C;                                             // C u8  cylinder labels
     unsigned char* s_mlab = s_cyl + C;                                            // 64 u8 merge labels
+    // cylinder RANSAC scratch (carved only when CAPE_FLAG_CYLINDERS is set, see grow_lds_bytes)
+    unsigned short* s_ids = reinterpret_cast<unsigned short*>(s_mlab + 64);       // C u16 idsLeft
+    unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
+    unsigned char* s_cur = s_idmask + C;                                          // C u8
+    unsigned char* s_best = s_cur + C;                                            // C u8
 
     const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
 
@@ -283,7 +289,9 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
     // =========================================================================================
     int untried = nPlanar;
     int nSeg = 0;      // _planeSegments.size()
-    int nCylLabels = 0;
+    int nCylLabels = 0; // cylinder2regionMap.size()
+    int nCylFits = 0;   // _cylinderSegments.size()
+    int rngPos = 0;     // draws consumed from the per-frame mt19937(0) stream
     int nSeeds = 0;
     const double* sumsBase = p.cell_sums + cellBase * kSumStride;
     const int maxSeedIters = 4 * C + 1024; // the loop provably terminates (every iteration burns a histogram count)
@@ -463,10 +471,38 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
                 s_lab[s_list[i]] = (unsigned char)nSeg;
             CAPE_WAVE_SYNC();
         }
-        else if (total > 5 && (p.flags & CAPE_FLAG_CYLINDERS))
+        else if (CYL && total > 5)
         {
-            // cylinder_fitting (:478-501) -- device RANSAC lands in a later revision; until then the call is refused
-            // at cape_create (CAPE_ERR_UNSUPPORTED), so this branch is unreachable.
+            // cylinder_fitting (:478-501) ; CYL == false is the "plane-only" mode (region dropped, cells stay consumed)
+            CylCtx cc;
+            cc.p = &p;
+            cc.lane = lane;
+            cc.cellBase = cellBase;
+            cc.C = C;
+            cc.s_list = s_list;
+            cc.total = total;
+            cc.s_dist = s_mse; // borrowed; restored below
+            cc.s_ids = s_ids;
+            cc.s_idmask = s_idmask;
+            cc.s_cur = s_cur;
+            cc.s_best = s_best;
+            cc.scratch = p.cylScratch + cellBase * 6;
+            cc.s_seg = s_seg;
+            cc.s_lab = s_lab;
+            cc.s_cyl = s_cyl;
+            cc.rec = p.records + frame;
+            bool planeOverflow = false;
+            cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
+            ++nCylFits;
+            CAPE_WAVE_SYNC();
+            for (int i = lane; i < C; i += 64)
+                s_mse[i] = p.cell_plane[(cellBase + i) * kPlaneStride + 7];
+            CAPE_WAVE_SYNC();
+            if (planeOverflow)
+            {
+                status |= CAPE_FRAME_PLANE_OVERFLOW;
+                break;
+            }
         }
     }
 
@@ -671,6 +707,49 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
     }
 
     // =========================================================================================
+    // add_cylinders_to_primitives (:705-734): open (dilate, erode) + erode with the 3x3 cross, default borders
+    // =========================================================================================
+    int nCylOut = 0;
+    for (int ci = 0; ci < nCylLabels; ++ci)
+    {
+        MaskT M = 0;
+        if (lane < VC)
+            for (int c = 0; c < HC; ++c)
+                if (s_cyl[lane * HC + c] == ci + 1)
+                    M |= (MaskT)1 << c;
+        const MaskT allRow = (lane < VC) ? widthMask : (MaskT)0;
+        const MaskT firstCol = (MaskT)1, lastCol = (MaskT)1 << (HC - 1);
+        auto dilate = [&](MaskT x) {
+            const MaskT up = Rows<MaskT>::up(x, lane), dn = Rows<MaskT>::dn(x, lane, VC);
+            return (MaskT)((x | (MaskT)(x << 1) | (MaskT)(x >> 1) | up | dn) & allRow);
+        };
+        auto erode = [&](MaskT x) { // outside the grid never erodes (morphologyDefaultBorderValue)
+            const MaskT up = Rows<MaskT>::up(x, lane) | (lane == 0 ? widthMask : (MaskT)0);
+            const MaskT dn = Rows<MaskT>::dn(x, lane, VC) | (lane == VC - 1 ? widthMask : (MaskT)0);
+            return (MaskT)(x & ((MaskT)(x << 1) | firstCol) & ((MaskT)(x >> 1) | lastCol) & up & dn & allRow);
+        };
+        const MaskT e2 = erode(erode(dilate(M)));
+        const int ones = wave_sum_i32(popc<MaskT>(e2));
+        const bool kept = ones > 0 && ones < C; // max > 0 and min < max
+        if (kept)
+        {
+            if (lane == 0)
+            {
+                rec->cylinders[ci].kept = 1;
+                if (nCylOut < CAPE_SUMMARY_CYLINDERS)
+                {
+                    auto& sc = sum->cylinders[nCylOut];
+                    sc.axis[0] = rec->cylinders[ci].axis[0];
+                    sc.axis[1] = rec->cylinders[ci].axis[1];
+                    sc.axis[2] = rec->cylinders[ci].axis[2];
+                    sc.radius = __builtin_nan("");
+                }
+            }
+            ++nCylOut;
+        }
+    }
+
+    // =========================================================================================
     // label grids + header
     // =========================================================================================
     for (int i = lane; i < C; i += 64)
@@ -685,19 +764,19 @@ template <typename MaskT> __global__ __launch_bounds__(64) void cape_grow_kernel
         rec->header.n_plane_segments = nSeg;
         rec->header.n_planes = nPlanesOut;
         rec->header.n_cylinder_labels = nCylLabels;
-        rec->header.n_cylinders = 0;
+        rec->header.n_cylinders = nCylOut;
         rec->header.n_boundary_points = nBoundary < p.boundaryCapacity ? nBoundary : p.boundaryCapacity;
         rec->header.n_seeds = nSeeds;
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
         sum->n_planes = nPlanesOut;
-        sum->n_cylinders = 0;
+        sum->n_cylinders = nCylOut;
         sum->status = status;
         sum->n_plane_segments = nSeg;
     }
 }
 
-size_t grow_lds_bytes(int cells)
+size_t grow_lds_bytes(int cells, bool cylinders)
 {
     size_t b = 0;
     b += (size_t)cells * 8;                        // s_mse
@@ -708,16 +787,29 @@ size_t grow_lds_bytes(int cells)
     b += (size_t)cells * 2;                         // s_list
     b += (size_t)cells * 2;                         // s_lab + s_cyl
     b += 64;                                        // s_mlab
+    if (cylinders)
+        b += (size_t)cells * 2 + (size_t)cells * 3; // s_ids + s_idmask / s_cur / s_best
     return (b + 15) & ~(size_t)15;
 }
 
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
 {
-    const size_t lds = grow_lds_bytes(p.cells);
+    const size_t lds = grow_lds_bytes(p.cells, (p.flags & CAPE_FLAG_CYLINDERS) != 0);
+    const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
     if (p.hCells <= 32)
-        hipLaunchKernelGGL(cape_grow_kernel<uint32_t>, dim3(nFrames), dim3(64), lds, stream, p);
+    {
+        if (cyl)
+            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, true>), dim3(nFrames), dim3(64), lds, stream, p);
+        else
+            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, false>), dim3(nFrames), dim3(64), lds, stream, p);
+    }
     else
-        hipLaunchKernelGGL(cape_grow_kernel<unsigned long long>, dim3(nFrames), dim3(64), lds, stream, p);
+    {
+        if (cyl)
+            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, true>), dim3(nFrames), dim3(64), lds, stream, p);
+        else
+            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, false>), dim3(nFrames), dim3(64), lds, stream, p);
+    }
 }
 
 } // namespace cape

@@ -64,6 +64,7 @@ struct StageBParams
     const double* rngTable; // first rngCount doubles of uniform_real_distribution(mt19937(0)), random.hpp:17-30
     int rngCount;
     int ransacMaxIterations; // 43
+    double* cylScratch;      // [frames][cells][6] projected normals / centroids (only with CAPE_FLAG_CYLINDERS)
 };
 
 } // namespace cape

@@ -87,6 +87,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise CapeError(f"{LIB_PATH} is missing: build it with `make -C rgb-d-slam_amd/csrc` "
                         "(or __graft_entry__.build()); there is no CPU fallback")
+    # A process must talk to ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64; if torch is going
+    # to be used in this process (bench.py, the multi-GPU gather) it has to be loaded first so that libcape_hip
+    # binds to the same runtime instead of bringing /opt/rocm's copy in beside it.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional plumbing; the library itself only needs a HIP runtime
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.cape_create.argtypes = [C.POINTER(cape_config), C.POINTER(vp)]

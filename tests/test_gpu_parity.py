@@ -54,6 +54,14 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert np.array_equal(_bits(segs["sums"]), _bits(o[:, 9:18])), "segment sums"
         assert np.array_equal(segs["point_count"], o[:, 18].astype(np.uint32)), "segment n"
         assert np.array_equal(segs["planar"], o[:, 19].astype(np.uint32)), "segment planar"
+    # cylinders (axis bitwise vs the oracle; radius NaN by the reference's quirk)
+    assert hdr["n_cylinders"] == len(orc_res.cylinders), "cylinder container size"
+    kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+    kept = kept[kept["kept"] == 1]
+    assert len(kept) == len(orc_res.cylinders)
+    if len(kept):
+        assert np.array_equal(_bits(kept["axis"]), _bits(orc_res.cylinders[:, 0:3])), "cylinder axis"
+        assert np.isnan(kept["radius"]).all()
     planes = res.planes(f)
     assert len(planes) == len(orc_res.planes) == hdr["n_planes"]
     for k, pl in enumerate(planes):
@@ -155,7 +163,8 @@ def test_inorder_guard_path(oracle_mod):
     ex.close()
 
 
-GOLDEN_PLANE_ONLY = ["tumlike_s1_planeonly", "room_s0_f0_planeonly", "room_s3_f17_planeonly", "room_1280_s2_f11_planeonly"]
+GOLDEN_PLANE_ONLY = ["tumlike_s1_planeonly", "room_s0_f0_planeonly", "room_s3_f17_planeonly", "room_1280_s2_f11_planeonly",
+                     "tunnel_s0_f0_cyl", "tunnel_s4_f9_cyl", "tumlike_s2_f5_cyl"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_PLANE_ONLY)
@@ -235,3 +244,53 @@ def test_streamed_batch_properties():
     assert (hdr["n_planes"] == hdr["n_planes"][0]).all() and (hdr["n_planes"] >= 2).all()
     assert (r1.records["header"]["status"] & 0x7).max() == 0  # no overflow bits
     ex.close()
+
+
+CYL_SCENES = [("tunnel", 0, 0), ("tunnel", 4, 9), ("tunnel", 7, 123), ("tumlike", 2, 5), ("room", 1, 4)]
+
+
+@pytest.mark.parametrize("scene,seed,frame", CYL_SCENES)
+def test_frame_parity_with_cylinders(oracle_mod, scene, seed, frame):
+    """BASELINE.json configs[2]: planes + cylinder RANSAC, RNG stream restarted per frame (mt19937(0))."""
+    from cape_amd import Extractor, synth
+
+    depth = synth.SCENES[scene](seed=seed, frame=frame)
+    intr = _intr(scene)
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    r = orc.run(depth)
+    ex = Extractor(640, 480, cylinders=True, max_batch=2, **intr)
+    n = ex.extract_host(np.stack([depth, depth]))
+    res = ex.results(n)
+    compare_frame(r, ex, res, 0)
+    compare_frame(r, ex, res, 1)  # same frame twice in one batch: per-frame RNG restart
+    if scene == "tunnel":
+        assert res.records["header"]["n_cylinders"][0] >= 1
+    ex.close()
+
+
+def test_cylinders_noisy_and_1280(oracle_mod):
+    """Harder RANSAC inputs: bumpy tunnel (several sub-segments / plane-vs-cylinder model selection) and 1280x960."""
+    from cape_amd import Extractor, synth
+
+    rng = np.random.default_rng(11)
+    d = synth.tunnel(seed=3, frame=40)
+    d2 = d.copy()
+    d2[:, 200:440] *= np.float32(1.04)      # a second, slightly larger "pipe" section
+    d3 = d.copy()
+    d3 += (rng.standard_normal(d.shape) * 6).astype(np.float32) * (d > 0)
+    frames = np.stack([d, d2, d3])
+    intr = _intr("tunnel")
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    ex = Extractor(640, 480, cylinders=True, max_batch=4, **intr)
+    n = ex.extract_host(frames)
+    res = ex.results(n)
+    for f in range(n):
+        compare_frame(orc.run(frames[f]), ex, res, f)
+    ex.close()
+    big = synth.tunnel(seed=1, frame=2, width=1280, height=960)
+    intr2 = _intr("tunnel", 2.0)
+    orc2 = oracle_mod.Oracle(1280, 960, cylinders=True, **intr2)
+    ex2 = Extractor(1280, 960, cylinders=True, max_batch=1, **intr2)
+    ex2.extract_host(big)
+    compare_frame(orc2.run(big), ex2, ex2.results(1), 0)
+    ex2.close()
