@@ -93,6 +93,7 @@ def main():
     import torch.distributed as dist
 
     from cape_amd import SUMMARY_DTYPE, Extractor, synth
+    from cape_amd.dist import gather_summaries
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -116,16 +117,14 @@ def main():
     ex = Extractor(W, H, cylinders=False, device=local_rank, max_batch=B, **intr)
     stream = torch.cuda.current_stream().cuda_stream
     summ_bytes = B * SUMMARY_DTYPE.itemsize
-    gathered = None
     summ_t = None
     if world > 1:
         summ_t = torch.as_tensor(_DevMem(ex.summaries_pointer(), summ_bytes), device="cuda")
-        gathered = torch.empty(world * summ_bytes, dtype=torch.uint8, device="cuda")
 
     def step():
         ex.extract_device(depth.data_ptr(), B, stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, summ_t)
+            return gather_summaries(summ_t, world)  # one RCCL all-gather per batch
 
     for _ in range(args.warmup):
         step()

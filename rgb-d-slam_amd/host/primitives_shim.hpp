@@ -1,0 +1,151 @@
+// Host-side mirror of the reference's `primitives` library interface (namespace rgbd_slam::features::primitives)
+// on top of the C ABI in include/cape_hip.h.  Same class names, method names, argument meaning and error
+// behaviour (everything noexcept, failures are logged through a callback and the frame yields no primitives) as
+//   Depth_Map_Transformation  reference src/features/primitives/depth_map_transformation.hpp:15-57
+//   Primitive_Detection       reference src/features/primitives/primitive_detection.hpp:27-241
+//   Plane / Cylinder          reference src/features/primitives/shape_primitives.hpp:31-130
+// so that src/rgbd_slam.cpp:48-57,109-112,291-297,335 compile against it unchanged once the Eigen / OpenCV
+// overloads below are enabled (they are compiled only where those headers exist; this image has neither, so the
+// POD views are what the tests exercise).  See INTEGRATION.md.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/cape_hip.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>) && __has_include(<opencv2/core.hpp>)
+#define CAPE_HAVE_EIGEN_OPENCV 1
+#include <Eigen/Dense>
+#include <opencv2/core.hpp>
+#endif
+#endif
+
+namespace rgbd_slam {
+
+using uint = unsigned int;
+
+// Stand-in for the process-global camera parameters of the reference (src/parameters.hpp:119-191): intrinsics are
+// read once, when the first detector is constructed (the reference caches them in function-local statics).
+class Parameters
+{
+  public:
+    static void load_defaut() noexcept { set_camera_1(640, 480, 550.0, 550.0, 320.0, 240.0); } // parameters.cpp:59-74
+    static void set_camera_1(uint width, uint height, double fx, double fy, double cx, double cy) noexcept;
+    static bool is_valid() noexcept;
+    static void get_camera_1(uint& width, uint& height, double& fx, double& fy, double& cx, double& cy) noexcept;
+};
+
+namespace outputs {
+// outputs::log / log_warning / log_error (src/outputs/logger.cpp:21-65) collapse into one callback; level 0 info,
+// 1 warning, 2 error.  Default: stderr.
+using log_callback = std::function<void(int level, const std::string& message)>;
+void set_log_callback(log_callback cb);
+} // namespace outputs
+
+namespace features::primitives {
+
+// row-major float32 depth image in millimetres (what cv::Mat_<float> holds), not owned
+struct DepthImageView
+{
+    const float* data = nullptr;
+    int rows = 0, cols = 0;
+    size_t step = 0; // elements per row (>= cols)
+};
+
+// Plane, shape_primitives.hpp:73-126.  The boundary polygon of the reference (CameraPolygon, Boost.Geometry) is the
+// "next" row N1 of SURVEY.md 8(f); the plane carries the boundary candidate points the polygon is fitted to.
+class Plane
+{
+  public:
+    using vector3 = std::array<double, 3>;
+    using matrix33 = std::array<double, 9>; // row-major
+
+    Plane(const cape_plane_segment& seg, const double* boundaryPoints /* 3 x count */) noexcept;
+
+    [[nodiscard]] vector3 get_normal() const noexcept { return _normal; }
+    [[nodiscard]] double get_d() const noexcept { return _d; }
+    [[nodiscard]] std::array<double, 4> get_parametrization() const noexcept { return {_normal[0], _normal[1], _normal[2], _d}; }
+    [[nodiscard]] vector3 get_center() const noexcept { return {_normal[0] * (-_d), _normal[1] * (-_d), _normal[2] * (-_d)}; }
+    [[nodiscard]] matrix33 get_point_cloud_covariance() const noexcept { return _pointCloudCovariance; }
+    [[nodiscard]] const std::vector<vector3>& get_boundary_points() const noexcept { return _boundaryPoints; }
+    // shape_primitives.cpp:66-86 (20 degrees, 100 mm; parameters.hpp:92-95)
+    [[nodiscard]] bool is_normal_similar(const Plane& prim) const noexcept;
+    [[nodiscard]] bool is_distance_similar(const Plane& prim) const noexcept;
+
+  private:
+    vector3 _normal;
+    double _d;
+    matrix33 _pointCloudCovariance;
+    std::vector<vector3> _boundaryPoints;
+};
+
+// Cylinder, shape_primitives.hpp:31-68 (public data members as in the reference)
+class Cylinder
+{
+  public:
+    explicit Cylinder(const cape_cylinder& c) noexcept : _normal {c.axis[0], c.axis[1], c.axis[2]}, _radius(c.radius) {}
+    [[nodiscard]] bool is_similar(const Cylinder& prim) const noexcept;
+    std::array<double, 3> _normal;
+    double _radius;
+};
+
+using cylinder_container = std::vector<Cylinder>;
+using plane_container = std::vector<Plane>;
+
+// depth_map_transformation.hpp:15-57.  The organised cloud exists in the reference only to feed find_primitives
+// (src/rgbd_slam.cpp:109-121); the native path back-projects inside the cell-fit kernel, so this class only
+// validates sizes.  rectify_depth (dataset-specific pre-step) is not part of the path.
+class Depth_Map_Transformation
+{
+  public:
+    Depth_Map_Transformation(const uint width, const uint height, const uint cellSize);
+    [[nodiscard]] bool get_organized_cloud_array(const DepthImageView& depthImage) noexcept;
+#ifdef CAPE_HAVE_EIGEN_OPENCV
+    [[nodiscard]] bool get_organized_cloud_array(const cv::Mat_<float>& depthImage, Eigen::MatrixXf& organizedCloudArray) noexcept;
+#endif
+  private:
+    uint _width, _height, _cellSize;
+};
+
+// primitive_detection.hpp:27-241
+class Primitive_Detection
+{
+  public:
+    Primitive_Detection(const uint width, const uint height);
+    ~Primitive_Detection();
+    Primitive_Detection(const Primitive_Detection&) = delete;
+    Primitive_Detection& operator=(const Primitive_Detection&) = delete;
+
+    // find_primitives(depthMatrix, depthImage, planeContainer, primitiveContainer): depthMatrix is not needed
+    void find_primitives(const DepthImageView& depthImage, plane_container& planeContainer,
+                         cylinder_container& primitiveContainer) noexcept;
+#ifdef CAPE_HAVE_EIGEN_OPENCV
+    void find_primitives(const Eigen::MatrixXf& depthMatrix, const cv::Mat_<float>& depthImage,
+                         plane_container& planeContainer, cylinder_container& primitiveContainer) noexcept;
+#endif
+    // batch extension (frames are independent: SURVEY.md 8e): depth = n_frames contiguous images on the host
+    void find_primitives_batch(const float* depth, int n_frames, std::vector<plane_container>& planes,
+                               std::vector<cylinder_container>& cylinders) noexcept;
+
+    void show_statistics(const double meanFrameTreatmentDuration, const uint frameCount,
+                         const bool shouldDisplayDetails = false) const noexcept;
+
+    [[nodiscard]] bool is_ready() const noexcept { return _handle != nullptr; }
+
+  private:
+    cape_handle _handle = nullptr;
+    uint _width, _height;
+    int _cells = 0, _boundaryCapacity = 0;
+    int _maxBatch = 0;
+    mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
+    std::vector<cape_frame_record> _records;
+    std::vector<double> _boundary;
+    void collect(int frame, plane_container& planes, cylinder_container& cylinders) const;
+};
+
+} // namespace features::primitives
+} // namespace rgbd_slam

@@ -1,0 +1,44 @@
+// Drives the host-side mirror of the reference interface the way src/rgbd_slam.cpp:48-57,109-112,291-297 does and
+// prints the primitives as hex doubles; tests/test_gpu_host_shim.py compares them with the CPU oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../rgb-d-slam_amd/host/primitives_shim.hpp"
+
+using namespace rgbd_slam;
+using namespace rgbd_slam::features::primitives;
+
+int main(int argc, char** argv)
+{
+    if (argc < 8)
+        return 2;
+    const uint W = std::atoi(argv[2]), H = std::atoi(argv[3]);
+    Parameters::set_camera_1(W, H, std::atof(argv[4]), std::atof(argv[5]), std::atof(argv[6]), std::atof(argv[7]));
+    std::vector<float> depth(static_cast<size_t>(W) * H);
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(depth.data(), sizeof(float), depth.size(), f) != depth.size())
+        return 3;
+    std::fclose(f);
+
+    Depth_Map_Transformation depthOps(W, H, 20);
+    Primitive_Detection detector(W, H);
+    if (!detector.is_ready())
+        return 4;
+    const DepthImageView img {depth.data(), static_cast<int>(H), static_cast<int>(W), W};
+    if (!depthOps.get_organized_cloud_array(img))
+        return 5;
+    plane_container planes;
+    cylinder_container cylinders;
+    detector.find_primitives(img, planes, cylinders);
+    std::printf("planes %zu cylinders %zu\n", planes.size(), cylinders.size());
+    for (const Plane& p : planes)
+    {
+        const auto n = p.get_normal();
+        std::printf("P %a %a %a %a %zu\n", n[0], n[1], n[2], p.get_d(), p.get_boundary_points().size());
+    }
+    for (const Cylinder& c : cylinders)
+        std::printf("C %a %a %a\n", c._normal[0], c._normal[1], c._normal[2]);
+    detector.show_statistics(0.01, 1, true);
+    return 0;
+}
