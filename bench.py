@@ -98,8 +98,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # CAPE_BENCH_FORCE_GATHER=1 exercises the RCCL gather path on a single GPU (validation only)
+    use_dist = world > 1 or os.environ.get("CAPE_BENCH_FORCE_GATHER") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     W, H, B = args.width, args.height, args.frames
@@ -118,18 +121,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     summ_bytes = B * SUMMARY_DTYPE.itemsize
     summ_t = None
-    if world > 1:
+    if use_dist:
         summ_t = torch.as_tensor(_DevMem(ex.summaries_pointer(), summ_bytes), device="cuda")
 
     def step():
         ex.extract_device(depth.data_ptr(), B, stream)
-        if world > 1:
+        if use_dist:
             return gather_summaries(summ_t, world)  # one RCCL all-gather per batch
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ex.reset_timings()
@@ -138,7 +141,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -146,7 +149,7 @@ def main():
     tm = ex.timings()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -204,11 +207,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(unique, intr)
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
 
     ex.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

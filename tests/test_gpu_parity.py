@@ -294,3 +294,27 @@ def test_cylinders_noisy_and_1280(oracle_mod):
     ex2.extract_host(big)
     compare_frame(orc2.run(big), ex2, ex2.results(1), 0)
     ex2.close()
+
+
+def test_summaries_visible_to_torch_without_copy():
+    """The gather payload: torch wraps libcape_hip's device buffer through __cuda_array_interface__ (bench.py)."""
+    import torch
+    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+
+    class DevMem:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    frames = synth.stream("tumlike", seed=1, n_frames=3)
+    ex = Extractor(640, 480, cylinders=False, max_batch=3, **synth.TUM_FR1_INTRINSICS)
+    ex.extract_host(frames)
+    res = ex.results(3)
+    t = torch.as_tensor(DevMem(ex.summaries_pointer(), 3 * SUMMARY_DTYPE.itemsize), device="cuda")
+    s = np.frombuffer(t.cpu().numpy().tobytes(), dtype=SUMMARY_DTYPE)
+    assert np.array_equal(s["n_planes"], res.records["header"]["n_planes"])
+    for f in range(3):
+        pl = res.planes(f)
+        k = min(len(pl), 16)
+        assert np.array_equal(s["planes"]["normal"][f, :k], pl["out_normal"][:k])
+        assert np.array_equal(s["planes"]["d"][f, :k], pl["d"][:k])
+    ex.close()
