@@ -156,16 +156,21 @@ def main():
     if rank == 0:
         frames_total = world * B * args.steps
         cells = (W // 20) * (H // 20)
-        a_ms = 1e3 * tm["cell_fit_s"] / max(1, tm["calls"])
-        b_ms = 1e3 * tm["grow_s"] / max(1, tm["calls"])
-        # algorithmic bytes per launch (DESIGN.md "Measurement"): stage A reads each depth pixel once and writes
-        # 160 B of per-cell statistics; stage B reads those statistics once and writes label grids + primitive lists
-        bytes_a = B * (W * H * 4 + cells * 160)
-        bytes_b = B * (cells * 160 + 2 * cells * 4 + 32 * 128)
-        if a_ms >= b_ms:
-            dom, dom_ms, dom_bytes = "cape_cell_fit_kernel", a_ms, bytes_a
-        else:
-            dom, dom_ms, dom_bytes = "cape_grow_kernel", b_ms, bytes_b
+        calls = max(1, tm["calls"])
+        a1_ms = 1e3 * tm["cell_moments_s"] / calls
+        a2_ms = 1e3 * tm["cell_plane_s"] / calls
+        b_ms = 1e3 * tm["grow_s"] / calls
+        # algorithmic bytes per launch (DESIGN.md "Measurement"):
+        #   A1 cell moments : reads every depth pixel once, writes 96 B per cell (10 f64 sums + 16 B hand-over)
+        #   A2 cell plane   : reads those 96 B, writes 88 B per cell (plane, score, tolerance, flags, bin)
+        #   B  grow         : reads 168 B per cell (sums + plane + tol/flags/bin), writes label grids + primitive lists
+        kernels = {
+            "cape_cell_moments_kernel": (a1_ms, B * (W * H * 4 + cells * 96)),
+            "cape_cell_plane_kernel": (a2_ms, B * (cells * (96 + 88))),
+            "cape_grow_kernel": (b_ms, B * (cells * 168 + 2 * cells * 4 + 32 * 128)),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -200,7 +205,7 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
-                "stage_a_ms": a_ms, "stage_b_ms": b_ms,
+                "kernel_ms": {"cape_cell_moments_kernel": a1_ms, "cape_cell_plane_kernel": a2_ms, "cape_grow_kernel": b_ms},
                 "end_to_end_GBps": frames_total / world * e2e_bytes_per_frame / elapsed / 1e9,
                 "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
             },

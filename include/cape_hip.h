@@ -168,7 +168,9 @@ typedef struct cape_timings
 {
     /* mirrors the reference's stage buckets (primitive_detection.hpp:233-239), from HIP events, seconds,
      * accumulated over calls made with CAPE timing enabled */
-    double cell_fit_s;      /* _initTime : back-projection + per-cell PCA (stage A kernel) */
+    double cell_fit_s;      /* _initTime : back-projection + per-cell PCA (stage A = the two kernels below) */
+    double cell_moments_s;  /*   A1 cape_cell_moments_kernel (streaming pass over the depth image) */
+    double cell_plane_s;    /*   A2 cape_cell_plane_kernel (per-cell plane fit, tolerance, histogram bin) */
     double grow_s;          /* _growTime + _mergeTime + _refineTime : stage B kernel */
     double total_s;
     uint64_t frames;

@@ -13,7 +13,8 @@
 #include "cape_internal.h"
 
 namespace cape {
-void launch_cell_fit(const StageAParams& p, int nFrames, hipStream_t stream);
+void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
+void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders);
 } // namespace cape
@@ -58,6 +59,7 @@ struct cape_handle_s
     float* cellTol = nullptr;
     uint32_t* cellFlags = nullptr;
     int32_t* cellBins = nullptr;
+    cape::CellAux* cellAux = nullptr;
     // results
     cape_frame_record* records = nullptr;
     cape_primitive_summary* summaries = nullptr;
@@ -69,7 +71,7 @@ struct cape_handle_s
     // timing: one event triple per timed cape_extract, folded lazily by cape_get_timings
     struct EvTriple
     {
-        hipEvent_t e[3];
+        hipEvent_t e[4];
         int frames;
     };
     std::vector<EvTriple> evPool;   // created on demand, reused
@@ -118,6 +120,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cellTol);
     (void)hipFree(h->cellFlags);
     (void)hipFree(h->cellBins);
+    (void)hipFree(h->cellAux);
     (void)hipFree(h->records);
     (void)hipFree(h->summaries);
     (void)hipFree(h->planeLabels);
@@ -135,13 +138,16 @@ int fold_timings(cape_handle_s* h)
     for (size_t i = 0; i < h->evPending; ++i)
     {
         auto& t = h->evPool[i];
-        CAPE_HIP_TRY(hipEventSynchronize(t.e[2]));
-        float a = 0, b = 0;
-        CAPE_HIP_TRY(hipEventElapsedTime(&a, t.e[0], t.e[1]));
-        CAPE_HIP_TRY(hipEventElapsedTime(&b, t.e[1], t.e[2]));
-        h->tm.cell_fit_s += a * 1e-3;
+        CAPE_HIP_TRY(hipEventSynchronize(t.e[3]));
+        float a1 = 0, a2 = 0, b = 0;
+        CAPE_HIP_TRY(hipEventElapsedTime(&a1, t.e[0], t.e[1]));
+        CAPE_HIP_TRY(hipEventElapsedTime(&a2, t.e[1], t.e[2]));
+        CAPE_HIP_TRY(hipEventElapsedTime(&b, t.e[2], t.e[3]));
+        h->tm.cell_moments_s += a1 * 1e-3;
+        h->tm.cell_plane_s += a2 * 1e-3;
+        h->tm.cell_fit_s += (a1 + a2) * 1e-3;
         h->tm.grow_s += b * 1e-3;
-        h->tm.total_s += (a + b) * 1e-3;
+        h->tm.total_s += (a1 + a2 + b) * 1e-3;
         h->tm.frames += (uint64_t)t.frames;
         h->tm.calls += 1;
     }
@@ -207,6 +213,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellTol, B * C));
     CAPE_ALLOC(dalloc(h->cellFlags, B * C));
     CAPE_ALLOC(dalloc(h->cellBins, B * C));
+    CAPE_ALLOC(dalloc(h->cellAux, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * 6));
     CAPE_ALLOC(dalloc(h->records, B));
@@ -279,6 +286,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     a.cell_score = h->cellScore;
     a.cell_tol = h->cellTol;
     a.cell_flags = h->cellFlags;
+    a.cell_bins = h->cellBins;
+    a.cell_aux = h->cellAux;
     // primitive_detection.cpp:189-190 ; parameters.hpp:75 maximumPlaneAngleForMerge_d = 18.0f
     a.sinMerge = sinf(static_cast<float>(18.0f * M_PI / 180.0));
     // plane_segment.hpp:33-34 ; parameters.hpp:72 minimumZeroDepthProportion = 0.7f
@@ -380,13 +389,16 @@ int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* 
         t->frames = n_frames;
         CAPE_HIP_TRY(hipEventRecord(t->e[0], stream));
     }
-    cape::launch_cell_fit(h->pa, n_frames, stream);
+    cape::launch_cell_moments(h->pa, n_frames, stream);
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[1], stream));
+    cape::launch_cell_plane(h->pa, n_frames, stream);
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[2], stream));
     cape::launch_grow(h->pb, n_frames, stream);
     if (t)
     {
-        CAPE_HIP_TRY(hipEventRecord(t->e[2], stream));
+        CAPE_HIP_TRY(hipEventRecord(t->e[3], stream));
         h->evPending += 1;
     }
     CAPE_HIP_TRY(hipGetLastError());

@@ -1,18 +1,22 @@
-// Stage A -- fused back-projection + per-cell PCA ("cell fit") for gfx950.
+// Stage A -- fused back-projection + per-cell PCA for gfx950, as two kernels:
 //
-// Replaces, per frame: Depth_Map_Transformation::get_organized_cloud_array (reference
-// src/features/primitives/depth_map_transformation.cpp:89-142), Plane_Segment::init_plane_segment
-// (plane_segment.cpp:102-168) for every cell, and the tolerance loop of
-// Primitive_Detection::init_planar_cell_fitting (primitive_detection.cpp:187-237).  The 3.7 MB organised
-// cloud of the reference is never materialised: the row-major depth image is read once.
+//   A1 cape_cell_moments_kernel : the HBM/FP64-issue bound streaming pass.  Reads the row-major depth image once,
+//      back-projects on the fly and leaves, per cell, the nine moment sums + count, the result of the continuity
+//      cross scan and the exactness verdict.  Replaces Depth_Map_Transformation::get_organized_cloud_array
+//      (reference src/features/primitives/depth_map_transformation.cpp:89-142) and the scan + accumulation part of
+//      Plane_Segment::init_plane_segment (plane_segment.cpp:44-152).  The 3.7 MB organised cloud is never built.
+//   A2 cape_cell_plane_kernel   : one lane per cell, every lane busy: validity gates, Plane_Segment::fit_plane
+//      (plane_segment.cpp:155-168, 205-284), the merge tolerance of init_planar_cell_fitting
+//      (primitive_detection.cpp:201-220) and the histogram bin of init_histogram (primitive_detection.cpp:253-254 +
+//      histogram.hpp:48-54).  Splitting it off keeps the long dependent f64 chains (eigen-solver, div, sqrt) out of
+//      the streaming workgroups, whose LDS and wave slots are then released as soon as the band is summed.
 //
-// Mapping: one 320-thread workgroup = two "bands" (a band = 20 image rows x 640 pixels = 32 cells).  Thread t
-// owns float4 column q = t % 160 of band t / 160 and walks the band's 20 rows, so every wave-level load is a
-// contiguous 16 B/lane row segment of the row-major image.  A float4 never straddles a cell (20 = 5 float4).
-// Per-thread partial moment sums (f64) meet in LDS; 5 partials make one cell.  The sums are exact in f64 for
-// any summation order when the addends' exponent span is < 21 bits; a per-cell z-range guard
-// decides whether that holds, otherwise the cell is redone in the reference's pixel order.  The first wave then
-// runs the per-cell continuity scan + plane fit for the 64 cells of the workgroup.
+// A1 mapping: one 320-thread workgroup = two "bands" (band = 20 image rows x 640 pixels = 32 cells).  Thread t owns
+// float4 column q = t % 160 of band t / 160 and walks the band's 20 rows, so every wave-level load is a contiguous
+// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded five
+// at a time, one group ahead of the arithmetic.  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
+// The sums are exact in f64 for ANY summation order when the addends' exponent span is < 21 bits;
+// a per-cell z-range guard decides whether that holds, otherwise A2 redoes the cell in the reference's pixel order.
 #include <hip/hip_runtime.h>
 
 #include "cape_device.h"
@@ -24,28 +28,50 @@ constexpr int kThreadsA = 320;
 constexpr int kBandThreads = 160;
 constexpr int kPartStride = 11; // 10 f64 per thread, padded against LDS bank conflicts
 
-__device__ __forceinline__ void acc_px(float zr, double a, double b, double (&S)[9], uint32_t& n, float& zmin, float& zmax)
+struct PxAcc
 {
-    const bool valid = zr > 0.0f; // depth_map_transformation.cpp:124 / plane_segment.cpp:134
-    const float z = valid ? zr : 0.0f;
-    n += valid ? 1u : 0u;
-    zmax = fmaxf(zmax, z);
-    zmin = valid ? fminf(zmin, z) : zmin;
+    double S[9];
+    uint32_t n;
+    float zmin, zmax;
+};
+
+// One pixel of plane_segment.cpp:131-152 on top of depth_map_transformation.cpp:123-138.
+__device__ __forceinline__ void acc_px(float zr, double a, double b, PxAcc& A)
+{
+    const bool valid = zr > 0.0f;       // `if (z > 0)` ; NaN is invalid
+    const float z = valid ? zr : 0.0f;  // invalid pixels add +0 to every sum
+    A.n += valid ? 1u : 0u;
     const double zd = (double)z;
-    // ScreenCoordinate::to_camera_coordinates (point_coordinates.cpp:150-167): x = z * fl(fl(k00*u) + k02), then the
-    // cloud stores static_cast<float> (depth_map_transformation.cpp:133-135)
+    // ScreenCoordinate::to_camera_coordinates (point_coordinates.cpp:150-167): x = z * fl(fl(k00*u) + k02) in f64, the
+    // cloud stores static_cast<float>(x) (depth_map_transformation.cpp:133-135)
     const float x = (float)(zd * a);
     const float y = (float)(zd * b);
-    // plane_segment.cpp:142-150 : float values / float products widened into double accumulators
-    S[0] += (double)x;
-    S[1] += (double)y;
-    S[2] += zd;
-    S[3] += (double)(x * x);
-    S[4] += (double)(y * y);
-    S[5] += (double)(z * z);
-    S[6] += (double)(x * y);
-    S[7] += (double)(y * z);
-    S[8] += (double)(x * z);
+    // float values / float products widened into double accumulators (types.hpp:84: SQR on the operand's own type)
+    A.S[0] += (double)x;
+    A.S[1] += (double)y;
+    A.S[2] += zd;
+    A.S[3] += (double)(x * x);
+    A.S[4] += (double)(y * y);
+    A.S[5] += (double)(z * z);
+    A.S[6] += (double)(x * y);
+    A.S[7] += (double)(y * z);
+    A.S[8] += (double)(x * z);
+}
+
+__device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, double a2, double a3, double b, PxAcc& A)
+{
+    acc_px(v.x, a0, b, A);
+    acc_px(v.y, a1, b, A);
+    acc_px(v.z, a2, b, A);
+    acc_px(v.w, a3, b, A);
+    // z range of the valid pixels (exactness guard): invalid -> +inf for the min, 0 for the max
+    const float ix = v.x > 0.0f ? v.x : __builtin_huge_valf();
+    const float iy = v.y > 0.0f ? v.y : __builtin_huge_valf();
+    const float iz = v.z > 0.0f ? v.z : __builtin_huge_valf();
+    const float iw = v.w > 0.0f ? v.w : __builtin_huge_valf();
+    A.zmin = fminf(fminf(A.zmin, ix), fminf(iy, fminf(iz, iw)));
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); // fmaxf ignores NaN
+    A.zmax = fmaxf(A.zmax, mx);
 }
 
 // plane_segment.cpp:44-60
@@ -63,114 +89,132 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
     return true;
 }
 
-__global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p)
+__global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAParams p)
 {
-    __shared__ double s_part[kThreadsA * kPartStride];
-    __shared__ float s_zmin[kThreadsA];
-    __shared__ float s_zmax[kThreadsA];
-    __shared__ double s_sums[64 * 10];
+    // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
+    __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
+    __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
+    __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
+    __shared__ float s_corner[64 * 2];   // first and last pixel of every cell
 
     const int t = threadIdx.x;
     const int frame = blockIdx.x / p.pairsPerFrame;
     const int pair = blockIdx.x - frame * p.pairsPerFrame;
     const size_t frameOff = (size_t)frame * p.W * p.H;
 
-    // ------------------------------------------------------------------ streaming accumulation
-    {
-        const int bsel = t / kBandThreads;
-        const int q = t - bsel * kBandThreads;
-        const int band = pair * 2 + bsel;
-        const int cellRow = band / p.segsPerRow;
-        const int seg = band - cellRow * p.segsPerRow;
-        const int col0 = seg * 640 + q * 4;
-        const bool active = (band < p.bandsPerFrame) && (col0 < p.W);
+    const int bsel = t / kBandThreads;
+    const int q = t - bsel * kBandThreads;
+    const int band = pair * 2 + bsel;
+    const int cellRow = band / p.segsPerRow;
+    const int seg = band - cellRow * p.segsPerRow;
+    const int col0 = seg * 640 + q * 4;
+    const bool active = (band < p.bandsPerFrame) && (col0 < p.W);
+    const int cseg = q / 5;          // cell within the band segment
+    const int j = q - cseg * 5;      // float4 within the cell row
+    const int lcell = bsel * 32 + cseg;
 
-        double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t n = 0;
-        float zmin = __builtin_huge_valf(), zmax = 0.0f;
-        if (active)
-        {
-            const double a0 = p.acol[col0], a1 = p.acol[col0 + 1], a2 = p.acol[col0 + 2], a3 = p.acol[col0 + 3];
-            const float* base = p.depth + frameOff + (size_t)(cellRow * kCell) * p.W + col0;
-            const double* brow = p.brow + cellRow * kCell;
-#pragma unroll 1
-            for (int r0 = 0; r0 < kCell; r0 += 5)
+    // ------------------------------------------------------------------ streaming accumulation
+    PxAcc A;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        A.S[k] = 0.0;
+    A.n = 0;
+    A.zmin = __builtin_huge_valf();
+    A.zmax = 0.0f;
+    if (active)
+    {
+        const double a0 = p.acol[col0], a1 = p.acol[col0 + 1], a2 = p.acol[col0 + 2], a3 = p.acol[col0 + 3];
+        const float* base = p.depth + frameOff + (size_t)(cellRow * kCell) * p.W + col0;
+        const double* brow = p.brow + cellRow * kCell;
+        const size_t W = (size_t)p.W;
+
+        // rows in groups of kGroup, ping-pong buffered: the loads of group g+1 are in flight while group g is summed
+        constexpr int kGroup = 2, kGroups = kCell / kGroup;
+        float4 bufA[kGroup], bufB[kGroup];
+        auto load_group = [&](float4 (&buf)[kGroup], int g) {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+                buf[i] = *reinterpret_cast<const float4*>(base + (size_t)(kGroup * g + i) * W);
+        };
+        auto sum_group = [&](const float4 (&buf)[kGroup], int g) {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
             {
-                float4 v[5];
-                double b[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-                {
-                    v[i] = *reinterpret_cast<const float4*>(base + (size_t)(r0 + i) * p.W);
-                    b[i] = brow[r0 + i];
-                }
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-                {
-                    acc_px(v[i].x, a0, b[i], S, n, zmin, zmax);
-                    acc_px(v[i].y, a1, b[i], S, n, zmin, zmax);
-                    acc_px(v[i].z, a2, b[i], S, n, zmin, zmax);
-                    acc_px(v[i].w, a3, b[i], S, n, zmin, zmax);
-                }
+                const int r = kGroup * g + i;
+                acc_f4(buf[i], a0, a1, a2, a3, brow[r], A);
+                // samples for the continuity cross scan and the tolerance corners
+                if (r == kCell / 2)
+                    *reinterpret_cast<float4*>(&s_row[lcell * kCell + 4 * j]) = buf[i];
+                if (j == 2)
+                    s_col[lcell * kCell + r] = buf[i].z; // pixel column 10 of the cell
+                if (r == 0 && j == 0)
+                    s_corner[lcell * 2] = buf[i].x;
+                if (r == kCell - 1 && j == 4)
+                    s_corner[lcell * 2 + 1] = buf[i].w;
             }
+        };
+        load_group(bufA, 0);
+#pragma unroll 1
+        for (int g = 0; g < kGroups; g += 2)
+        {
+            load_group(bufB, g + 1);
+            sum_group(bufA, g);
+            if (g + 2 < kGroups)
+                load_group(bufA, g + 2);
+            sum_group(bufB, g + 1);
         }
+    }
+    {
         double* dst = s_part + t * kPartStride;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            dst[k] = S[k];
-        dst[9] = (double)n;
-        s_zmin[t] = zmin;
-        s_zmax[t] = zmax;
+            dst[k] = A.S[k];
+        dst[9] = (double)A.n;
+        reinterpret_cast<float2*>(dst + 10)[0] = make_float2(A.zmin, A.zmax);
     }
     __syncthreads();
 
     // ------------------------------------------------------------------ 5 partials -> one cell (exact, any order)
+    // 64 cells x 10 quantities = 640 tasks over 320 threads; results go straight to HBM (AoS [cell][10])
 #pragma unroll
     for (int e = t; e < 640; e += kThreadsA)
     {
         const int cell = e / 10;
         const int m = e - cell * 10;
-        const int bsel = cell >> 5;
-        const int cseg = cell & 31;
-        const double* src = s_part + (bsel * kBandThreads + cseg * 5) * kPartStride + m;
-        double acc = src[0];
-        acc += src[kPartStride];
-        acc += src[2 * kPartStride];
-        acc += src[3 * kPartStride];
-        acc += src[4 * kPartStride];
-        s_sums[cell * 10 + m] = acc;
+        const int cb = cell >> 5, cs = cell & 31;
+        const int bnd = pair * 2 + cb;
+        const int cr = bnd / p.segsPerRow;
+        const int sg = bnd - cr * p.segsPerRow;
+        const int cc = sg * 32 + cs;
+        if (bnd < p.bandsPerFrame && cc < p.hCells)
+        {
+            const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
+            double acc = src[0];
+            acc += src[kPartStride];
+            acc += src[2 * kPartStride];
+            acc += src[3 * kPartStride];
+            acc += src[4 * kPartStride];
+            p.cell_sums[((size_t)frame * p.cells + cr * p.hCells + cc) * kSumStride + m] = acc;
+        }
     }
-    __syncthreads();
 
-    // ------------------------------------------------------------------ per-cell fit: wave 0, one lane per cell
+    // ------------------------------------------------------------------ per-cell scans: wave 0, one lane per cell
     if (t >= 64)
         return;
-    const int bsel = t >> 5;
-    const int cseg = t & 31;
-    const int band = pair * 2 + bsel;
-    if (band >= p.bandsPerFrame)
+    const int fb = t >> 5, fs = t & 31;
+    const int fband = pair * 2 + fb;
+    if (fband >= p.bandsPerFrame)
         return;
-    const int cellRow = band / p.segsPerRow;
-    const int seg = band - cellRow * p.segsPerRow;
-    const int cellCol = seg * 32 + cseg;
-    if (cellCol >= p.hCells)
+    const int fRow = fband / p.segsPerRow;
+    const int fSeg = fband - fRow * p.segsPerRow;
+    const int fCol = fSeg * 32 + fs;
+    if (fCol >= p.hCells)
         return;
-    const int cell = cellRow * p.hCells + cellCol;
-    const size_t gcell = (size_t)frame * p.cells + cell;
 
-    const float* cellBase = p.depth + frameOff + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
-
-    // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219
     bool continuous = true;
+    // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219
     {
-        const float* rowp = cellBase + (size_t)(kCell / 2) * p.W;
-        float zr[kCell];
-#pragma unroll
-        for (int i = 0; i < kCell; i += 4)
-        {
-            const float4 v = *reinterpret_cast<const float4*>(rowp + i);
-            zr[i] = v.x; zr[i + 1] = v.y; zr[i + 2] = v.z; zr[i + 3] = v.w;
-        }
+        const float* zr = &s_row[t * kCell];
         float last = std_maxf(zr[0], zr[1]);
         if (last <= 0)
             continuous = false;
@@ -178,13 +222,9 @@ __global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p
         for (int i = 1; i < kCell; ++i)
             continuous = continuous && is_continuous(zr[i], last);
     }
-    // is_cell_vertical_continuous (:62-80): local col 10, idx 10, 30, ..., 370 (loop stops before 390)
+    // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
     {
-        const float* colp = cellBase + kCell / 2;
-        float zc[kCell - 1];
-#pragma unroll
-        for (int i = 0; i < kCell - 1; ++i)
-            zc[i] = colp[(size_t)i * p.W];
+        const float* zc = &s_col[t * kCell];
         float last = std_maxf(zc[0], zc[1]);
         if (last <= 0)
             continuous = false;
@@ -192,43 +232,81 @@ __global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p
         for (int i = 1; i < kCell - 1; ++i)
             continuous = continuous && is_continuous(zc[i], last);
     }
+    // exactness guard: all addends of every sum within 2^20 of each other (see header)
+    float zmin = __builtin_huge_valf(), zmax = 0.0f;
+    uint32_t n = 0;
+    {
+        const int pbase = fb * kBandThreads + fs * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            const float2 zr = reinterpret_cast<const float2*>(s_part + (pbase + k) * kPartStride + 10)[0];
+            zmin = fminf(zmin, zr.x);
+            zmax = fmaxf(zmax, zr.y);
+            n += (uint32_t)s_part[(pbase + k) * kPartStride + 9];
+        }
+    }
+    const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);
+    const bool exact_ok = (n == 0) || (zmax * rab <= 512.0f * zmin);
 
+    const size_t gcell = (size_t)frame * p.cells + fRow * p.hCells + fCol;
+    CellAux aux;
+    aux.z0 = s_corner[t * 2];
+    aux.z399 = s_corner[t * 2 + 1];
+    aux.flags = (n & kCountMask) | (continuous ? kAuxContinuous : 0u) | (exact_ok ? kAuxExact : 0u);
+    aux.pad = 0;
+    p.cell_aux[gcell] = aux;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A2: one lane per cell
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, int nFrames)
+{
+    const size_t gcell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gcell >= (size_t)nFrames * p.cells)
+        return;
+    const int frame = (int)(gcell / p.cells);
+    const int cell = (int)(gcell - (size_t)frame * p.cells);
+    const int cellRow = cell / p.hCells;
+    const int cellCol = cell - cellRow * p.hCells;
+
+    const CellAux aux = p.cell_aux[gcell];
+    uint32_t n = aux.flags & kCountMask;
+    const bool continuous = (aux.flags & kAuxContinuous) != 0;
+    const bool exact_ok = (aux.flags & kAuxExact) != 0;
+
+    double* os = p.cell_sums + gcell * kSumStride;
     double S[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
-        S[k] = s_sums[t * 10 + k];
-    uint32_t n = (uint32_t)s_sums[t * 10 + 9];
+        S[k] = os[k];
 
-    // exactness guard: all addends of every sum within 2^20 of each other (see header)
-    float zmin = __builtin_huge_valf(), zmax = 0.0f;
-    {
-        const int pbase = bsel * kBandThreads + cseg * 5;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-        {
-            zmin = fminf(zmin, s_zmin[pbase + j]);
-            zmax = fmaxf(zmax, s_zmax[pbase + j]);
-        }
-    }
-    const float rab = fmaxf(p.ratio_col[cellCol], p.ratio_row[cellRow]);
-    const bool exact_ok = (n == 0) || (zmax * rab <= 512.0f * zmin);
     uint32_t inorder = 0;
+    bool rewrite = false;
     if (!exact_ok && continuous && n >= (uint32_t)(kPts / 2))
     {
         // in-order path: the reference's pixel order (plane_segment.cpp:131-152)
         inorder = 1;
+        rewrite = true;
+        const float* cellBase = p.depth + (size_t)frame * p.W * p.H + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
+        PxAcc A;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            S[k] = 0.0;
-        uint32_t nn = 0;
-        float zmn = 0, zmx = 0;
+            A.S[k] = 0.0;
+        A.n = 0;
+        A.zmin = 0;
+        A.zmax = 0;
         for (int r = 0; r < kCell; ++r)
         {
             const double b = p.brow[cellRow * kCell + r];
             for (int c = 0; c < kCell; ++c)
-                acc_px(cellBase[(size_t)r * p.W + c], p.acol[cellCol * kCell + c], b, S, nn, zmn, zmx);
+                acc_px(cellBase[(size_t)r * p.W + c], p.acol[cellCol * kCell + c], b, A);
         }
-        n = nn;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            S[k] = A.S[k];
+        n = A.n;
     }
 
     PlaneFit f;
@@ -245,6 +323,7 @@ __global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p
         for (int k = 0; k < 9; ++k)
             S[k] = 0.0;
         n = 0;
+        rewrite = true;
     }
     else if (n >= (uint32_t)p.minZeroPointCount)
     {
@@ -252,13 +331,21 @@ __global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p
         const double qz = depth_quantization(f.cz);
         planar = f.mse <= qz * qz; // plane_segment.cpp:167
     }
+    if (rewrite)
+    {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            os[k] = S[k];
+        os[9] = (double)n;
+    }
 
-    // _cellDistanceTols (primitive_detection.cpp:201-220)
+    // _cellDistanceTols (primitive_detection.cpp:201-220): first and last cloud rows of the cell (zeros if invalid)
     float tol = 0.0f;
+    int bin = -1;
+    uint32_t nearEdge = 0;
     if (planar)
     {
-        const float z0 = cellBase[0];
-        const float z1 = cellBase[(size_t)(kCell - 1) * p.W + (kCell - 1)];
+        const float z0 = aux.z0, z1 = aux.z399;
         const int u0 = cellCol * kCell, v0 = cellRow * kCell;
         float x0 = 0, y0 = 0, zz0 = 0, x1 = 0, y1 = 0, zz1 = 0;
         if (z0 > 0)
@@ -276,25 +363,46 @@ __global__ __launch_bounds__(kThreadsA) void cape_cell_fit_kernel(StageAParams p
         const float dx = x1 - x0, dy = y1 - y0, dz = zz1 - zz0;
         const float diam = sqrtf(dx * dx + (dy * dy + dz * dz));
         tol = std_minf(50.0f, diam * p.sinMerge * sqrtf((float)n));
+
+        // init_histogram (primitive_detection.cpp:253-254) + Histogram::init_histogram (histogram.hpp:48-54)
+        const double theta = acos(-f.nz);
+        const double phi = atan2(f.nx, f.ny);
+        constexpr double kPi = 3.14159265358979323846;
+        const double tx = 19.0 * (theta - 0.0) / kPi;
+        const int xQ = (int)floor(tx);
+        int yQ = 0;
+        double ty = 0.5;
+        if (xQ > 0)
+        {
+            ty = 19.0 * (phi - (-kPi)) / (kPi - (-kPi));
+            yQ = (int)floor(ty);
+        }
+        bin = yQ * 20 + xQ;
+        // libm tie guard: ocml vs glibc acos/atan2 may differ in the last ulp
+        if (fabs(tx - rint(tx)) < 1e-9 || (xQ > 0 && fabs(ty - rint(ty)) < 1e-9))
+            nearEdge = 1;
     }
 
-    double* os = p.cell_sums + gcell * kSumStride;
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        os[k] = S[k];
-    os[9] = (double)n;
     double* op = p.cell_plane + gcell * kPlaneStride;
     op[0] = f.nx; op[1] = f.ny; op[2] = f.nz; op[3] = f.d;
     op[4] = f.cx; op[5] = f.cy; op[6] = f.cz; op[7] = f.mse;
     p.cell_score[gcell] = f.score;
     p.cell_tol[gcell] = tol;
-    p.cell_flags[gcell] = (n & kCountMask) | (inorder ? kFlagInorder : 0u) | (planar ? kFlagPlanar : 0u);
+    p.cell_bins[gcell] = bin;
+    p.cell_flags[gcell] = (n & kCountMask) | (nearEdge ? kFlagNearEdge : 0u) | (inorder ? kFlagInorder : 0u) |
+                          (planar ? kFlagPlanar : 0u);
 }
 
-void launch_cell_fit(const StageAParams& p, int nFrames, hipStream_t stream)
+void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
 {
     const int grid = nFrames * p.pairsPerFrame;
-    hipLaunchKernelGGL(cape_cell_fit_kernel, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    hipLaunchKernelGGL(cape_cell_moments_kernel, dim3(grid), dim3(kThreadsA), 0, stream, p);
+}
+
+void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream)
+{
+    const size_t cellsTotal = (size_t)nFrames * p.cells;
+    hipLaunchKernelGGL(cape_cell_plane_kernel, dim3((unsigned)((cellsTotal + 255) / 256)), dim3(256), 0, stream, p, nFrames);
 }
 
 } // namespace cape

@@ -209,31 +209,15 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         s_mse[i] = pl[7];
         s_lab[i] = 0;
         s_cyl[i] = 0;
-        int bin = -1;
+        const int bin = p.cell_bins[cellBase + i]; // computed by stage A2 (acos / atan2 of the cell normal)
         if (fl & kFlagPlanar)
         {
-            const double nx = pl[0], ny = pl[1], nz = pl[2];
-            const double theta = acos(-nz);
-            const double phi = atan2(nx, ny);
-            constexpr double kPi = 3.14159265358979323846;
-            const double tx = 19.0 * (theta - 0.0) / kPi;
-            const int xQ = (int)floor(tx);
-            int yQ = 0;
-            double ty = 0.5;
-            if (xQ > 0)
-            {
-                ty = 19.0 * (phi - (-kPi)) / (kPi - (-kPi));
-                yQ = (int)floor(ty);
-            }
-            bin = yQ * 20 + xQ;
             atomicAdd(&s_hist[bin], 1);
             ++nPlanarLocal;
-            // libm tie guard: ocml vs glibc acos/atan2 may differ in the last ulp
-            if (fabs(tx - rint(tx)) < 1e-9 || (xQ > 0 && fabs(ty - rint(ty)) < 1e-9))
-                status |= CAPE_FRAME_BIN_NEAR_EDGE;
         }
         s_bins[i] = (short)bin;
-        p.cell_bins[cellBase + i] = bin;
+        if (fl & kFlagNearEdge)
+            status |= CAPE_FRAME_BIN_NEAR_EDGE;
         if (fl & kFlagInorder)
             status |= CAPE_FRAME_INORDER_CELLS;
     }

@@ -12,12 +12,24 @@ namespace cape {
 //   cell_plane [cells][8]  f64 : nx ny nz d cx cy cz mse                               -- 64 B/cell
 //   cell_score [cells]     f64
 //   cell_tol   [cells]     f32 : _cellDistanceTols
-//   cell_flags [cells]     u32 : point count | inorder << 30 | planar << 31
+//   cell_flags [cells]     u32 : point count | near-edge << 29 | inorder << 30 | planar << 31
+//   cell_bins  [cells]     i32 : histogram bin (-1 if not planar)
+//   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts)
 constexpr int kSumStride = 10;
 constexpr int kPlaneStride = 8;
 constexpr uint32_t kFlagPlanar = 1u << 31;
 constexpr uint32_t kFlagInorder = 1u << 30;
-constexpr uint32_t kCountMask = (1u << 30) - 1;
+constexpr uint32_t kFlagNearEdge = 1u << 29;
+constexpr uint32_t kCountMask = (1u << 28) - 1;
+constexpr uint32_t kAuxContinuous = 1u << 31;
+constexpr uint32_t kAuxExact = 1u << 30;
+
+struct CellAux
+{
+    float z0, z399;  // depth of the cell's first / last pixel (cloud rows offset and offset+399)
+    uint32_t flags;  // valid pixel count | kAuxExact | kAuxContinuous
+    uint32_t pad;
+};
 
 struct StageAParams
 {
@@ -35,6 +47,8 @@ struct StageAParams
     double* cell_score;
     float* cell_tol;
     uint32_t* cell_flags;
+    int32_t* cell_bins;
+    CellAux* cell_aux;
     float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
 };
@@ -50,7 +64,7 @@ struct StageBParams
     const double* cell_score;
     const float* cell_tol;
     const uint32_t* cell_flags;
-    int32_t* cell_bins; // debug: Histogram::_bins after init_histogram
+    const int32_t* cell_bins; // Histogram::_bins right after init_histogram (written by stage A2)
     cape_frame_record* records;
     cape_primitive_summary* summaries;
     int32_t* plane_labels;

@@ -41,7 +41,8 @@ class cape_layout(C.Structure):
 
 
 class cape_timings(C.Structure):
-    _fields_ = [("cell_fit_s", C.c_double), ("grow_s", C.c_double), ("total_s", C.c_double),
+    _fields_ = [("cell_fit_s", C.c_double), ("cell_moments_s", C.c_double), ("cell_plane_s", C.c_double),
+                ("grow_s", C.c_double), ("total_s", C.c_double),
                 ("frames", C.c_uint64), ("calls", C.c_uint64)]
 
 
@@ -224,7 +225,8 @@ class Extractor:
     def timings(self):
         t = cape_timings()
         _check(self.L, self.L.cape_get_timings(self.h, C.byref(t)), "cape_get_timings")
-        return dict(cell_fit_s=t.cell_fit_s, grow_s=t.grow_s, total_s=t.total_s, frames=t.frames, calls=t.calls)
+        return dict(cell_fit_s=t.cell_fit_s, cell_moments_s=t.cell_moments_s, cell_plane_s=t.cell_plane_s,
+                    grow_s=t.grow_s, total_s=t.total_s, frames=t.frames, calls=t.calls)
 
 
 def debug_eval(op, a, b=None):
