@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--scene", default="room")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +118,7 @@ def main():
     depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()
 
-    ex = Extractor(W, H, cylinders=False, device=local_rank, max_batch=B, **intr)
+    ex = Extractor(W, H, cylinders=False, device=local_rank, max_batch=B, sub_batches=args.sub_batches, **intr)
     stream = torch.cuda.current_stream().cuda_stream
     summ_bytes = B * SUMMARY_DTYPE.itemsize
     summ_t = None
@@ -157,6 +158,7 @@ def main():
         frames_total = world * B * args.steps
         cells = (W // 20) * (H // 20)
         calls = max(1, tm["calls"])
+        fpl = tm["frames"] / calls  # frames per kernel launch (= B unless the batch is cut in sub-batches)
         a1_ms = 1e3 * tm["cell_moments_s"] / calls
         a2_ms = 1e3 * tm["cell_plane_s"] / calls
         b_ms = 1e3 * tm["grow_s"] / calls
@@ -165,9 +167,9 @@ def main():
         #   A2 cell plane   : reads those 96 B, writes 88 B per cell (plane, score, tolerance, flags, bin)
         #   B  grow         : reads 168 B per cell (sums + plane + tol/flags/bin), writes label grids + primitive lists
         kernels = {
-            "cape_cell_moments_kernel": (a1_ms, B * (W * H * 4 + cells * 96)),
-            "cape_cell_plane_kernel": (a2_ms, B * (cells * (96 + 88))),
-            "cape_grow_kernel": (b_ms, B * (cells * 168 + 2 * cells * 4 + 32 * 128)),
+            "cape_cell_moments_kernel": (a1_ms, fpl * (W * H * 4 + cells * 96)),
+            "cape_cell_plane_kernel": (a2_ms, fpl * (cells * (96 + 88))),
+            "cape_grow_kernel": (b_ms, fpl * (cells * 168 + 2 * cells * 4 + 32 * 128)),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
@@ -177,7 +179,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel") == dom and tj.get("frames_per_launch") == B and tj.get("width") == W:
+                if tj.get("kernel") == dom and tj.get("frames_per_launch") == fpl and tj.get("width") == W:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -198,7 +200,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])",
-                "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene,
+                "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene, "sub_batches": args.sub_batches,
                 "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
             },
             "roofline": {

@@ -23,8 +23,8 @@ extern "C" {
 #endif
 
 #define CAPE_CELL_SIZE 20          /* parameters::detection::depthMapPatchSize_px, src/parameters.hpp:79-80 */
-#define CAPE_MAX_PLANES 64         /* capacity of _planeSegments per frame (reference: unbounded std::vector) */
-#define CAPE_MAX_CYLINDERS 32      /* capacity of cylinder2regionMap per frame */
+#define CAPE_MAX_PLANES 32         /* capacity of _planeSegments per frame (reference: unbounded std::vector) */
+#define CAPE_MAX_CYLINDERS 16      /* capacity of cylinder2regionMap per frame */
 
 typedef enum cape_status
 {
@@ -67,6 +67,10 @@ typedef struct cape_config
     int32_t device;     /* HIP device ordinal */
     int32_t max_batch;  /* frames per cape_extract call (sizes the per-frame scratch and result buffers) */
     int32_t boundary_capacity; /* boundary points per frame; 0 = 2 * cells */
+    int32_t sub_batches; /* 0/1: the whole batch runs kernel after kernel on the caller's stream.  k > 1: the batch is
+                            cut in k sub-batches that alternate between two internal streams (forked from / joined
+                            into the caller's stream), so the latency-bound grow kernel of one sub-batch overlaps
+                            the streaming cell kernel of the next */
 } cape_config;
 
 typedef struct cape_handle_s* cape_handle;
@@ -233,6 +237,9 @@ enum
     CAPE_DEBUG_SQRTF = 5, CAPE_DEBUG_EIGEN3 = 6, CAPE_DEBUG_FIT_PLANE = 7
 };
 int cape_debug_eval(int op, const double* a, const double* b, double* out, int n);
+/* Debug: shader-clock ticks spent per phase of the grow kernel, n_frames x 16 (all zero unless the library was built
+ * with -DCAPE_B_PROFILE).  Synchronises. */
+int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out);
 
 const char* cape_last_error(void);
 const char* cape_version(void);

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock breakdown of the grow kernel (needs a -DCAPE_B_PROFILE build: CAPE_HIP_LIB=...libcape_prof.so)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rgb-d-slam_amd", "python"))
+import numpy as np
+import torch
+from cape_amd import Extractor, synth
+
+NAMES = ["hist prologue", "edge masks", "argmax+cands", "seed pick", "propagation", "list build", "ordered accum",
+         "hist removal", "region fit", "seed-loop tail", "merge", "boundary+records", "", "", "", ""]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+scene = sys.argv[2] if len(sys.argv) > 2 else "room"
+u = synth.stream(scene, seed=100, n_frames=16)
+d = torch.from_numpy(u).cuda().repeat(B // 16, 1, 1).contiguous()
+intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+ex = Extractor(640, 480, max_batch=B, **intr)
+ex.extract_device(d.data_ptr(), B, torch.cuda.current_stream().cuda_stream)
+cyc = ex.debug_cycles(B).astype(np.float64)
+tot = cyc.sum(1)
+print(f"frames {B}: mean ticks/frame {tot.mean():.0f} (s_memtime @100MHz => {tot.mean() / 100:.1f} us)  seeds/frame {ex.results(B, False).records['header']['n_seeds'].mean():.1f}")
+for k, nm in enumerate(NAMES):
+    if nm:
+        print(f"  {nm:18s} {cyc[:, k].mean():10.0f} ticks  {100 * cyc[:, k].mean() / tot.mean():5.1f} %")

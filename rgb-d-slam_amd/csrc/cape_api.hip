@@ -52,6 +52,7 @@ struct cape_handle_s
     float* ratioRow = nullptr;
     double* rng = nullptr;
     double* cylScratch = nullptr;
+    unsigned long long* debugCycles = nullptr;
     // per-frame scratch (stage A -> stage B)
     double* cellSums = nullptr;
     double* cellPlane = nullptr;
@@ -72,12 +73,19 @@ struct cape_handle_s
     struct EvTriple
     {
         hipEvent_t e[4];
+        hipEvent_t e2b = nullptr; // start of the A2 kernel when it runs on another stream than A1 (pipelined mode)
         int frames;
+        bool split = false;
     };
     std::vector<EvTriple> evPool;   // created on demand, reused
     size_t evPending = 0;           // triples [0, evPending) hold unread measurements
     bool timing = false;
     cape_timings tm{};
+    // sub-batch pipelining (cfg.sub_batches > 1)
+    hipStream_t pipeStream[2] = {nullptr, nullptr};
+    hipEvent_t pipeFork = nullptr;
+    hipEvent_t pipeJoin[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> pipeStage;
     int lastFrames = 0;
     cape::StageAParams pa{};
     cape::StageBParams pb{};
@@ -114,6 +122,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->ratioRow);
     (void)hipFree(h->rng);
     (void)hipFree(h->cylScratch);
+    (void)hipFree(h->debugCycles);
     (void)hipFree(h->cellSums);
     (void)hipFree(h->cellPlane);
     (void)hipFree(h->cellScore);
@@ -128,9 +137,109 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->boundary);
     (void)hipFree(h->depthStage);
     for (auto& t : h->evPool)
+    {
         for (auto& e : t.e)
             if (e)
                 (void)hipEventDestroy(e);
+        if (t.e2b)
+            (void)hipEventDestroy(t.e2b);
+    }
+    for (auto& e : h->pipeStage)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto& st : h->pipeStream)
+        if (st)
+            (void)hipStreamDestroy(st);
+    if (h->pipeFork)
+        (void)hipEventDestroy(h->pipeFork);
+    for (auto& e : h->pipeJoin)
+        if (e)
+            (void)hipEventDestroy(e);
+}
+
+// parameter blocks of a sub-batch that starts at frame f0
+void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::StageBParams& b)
+{
+    a = h->pa;
+    b = h->pb;
+    const size_t C = (size_t)h->cells, F = (size_t)f0;
+    const size_t px = F * (size_t)h->cfg.width * h->cfg.height;
+    a.depth += px;
+    b.depth += px;
+    a.cell_sums += F * C * cape::kSumStride;
+    a.cell_plane += F * C * cape::kPlaneStride;
+    a.cell_score += F * C;
+    a.cell_tol += F * C;
+    a.cell_flags += F * C;
+    a.cell_bins += F * C;
+    a.cell_aux += F * C;
+    b.cell_sums = a.cell_sums;
+    b.cell_plane = a.cell_plane;
+    b.cell_score = a.cell_score;
+    b.cell_tol = a.cell_tol;
+    b.cell_flags = a.cell_flags;
+    b.cell_bins = a.cell_bins;
+    b.records += F;
+    b.summaries += F;
+    b.plane_labels += F * C;
+    b.cyl_labels += F * C;
+    b.boundary += F * (size_t)h->boundaryCap * 3;
+    if (b.cylScratch)
+        b.cylScratch += F * C * 6;
+    b.debugCycles += F * 16;
+}
+
+int fold_timings(cape_handle_s* h);
+
+// next free event set for one timed kernel chain (creates / recycles on demand)
+int acquire_events(cape_handle_s* h, int frames, cape_handle_s::EvTriple** out)
+{
+    *out = nullptr;
+    if (!h->timing)
+        return CAPE_OK;
+    if (h->evPending == h->evPool.size())
+    {
+        if (h->evPool.size() >= 4096)
+        {
+            const int rc = fold_timings(h); // synchronises; keeps the pool bounded
+            if (rc != CAPE_OK)
+                return rc;
+        }
+        else
+        {
+            cape_handle_s::EvTriple nt{};
+            for (auto& e : nt.e)
+                CAPE_HIP_TRY(hipEventCreate(&e));
+            CAPE_HIP_TRY(hipEventCreate(&nt.e2b));
+            h->evPool.push_back(nt);
+        }
+    }
+    *out = &h->evPool[h->evPending];
+    (*out)->frames = frames;
+    (*out)->split = h->cfg.sub_batches > 1;
+    h->evPending += 1;
+    return CAPE_OK;
+}
+
+// one kernel chain (A1 -> A2 -> B) on `st`, optionally bracketed by timing events
+int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::StageBParams& b, int frames, hipStream_t st)
+{
+    cape_handle_s::EvTriple* t = nullptr;
+    const int rc = acquire_events(h, frames, &t);
+    if (rc != CAPE_OK)
+        return rc;
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[0], st));
+    cape::launch_cell_moments(a, frames, st);
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
+    cape::launch_cell_plane(a, frames, st);
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
+    cape::launch_grow(b, frames, st);
+    if (t)
+        CAPE_HIP_TRY(hipEventRecord(t->e[3], st));
+    return CAPE_OK;
 }
 
 int fold_timings(cape_handle_s* h)
@@ -141,7 +250,7 @@ int fold_timings(cape_handle_s* h)
         CAPE_HIP_TRY(hipEventSynchronize(t.e[3]));
         float a1 = 0, a2 = 0, b = 0;
         CAPE_HIP_TRY(hipEventElapsedTime(&a1, t.e[0], t.e[1]));
-        CAPE_HIP_TRY(hipEventElapsedTime(&a2, t.e[1], t.e[2]));
+        CAPE_HIP_TRY(hipEventElapsedTime(&a2, t.split ? t.e2b : t.e[1], t.e[2]));
         CAPE_HIP_TRY(hipEventElapsedTime(&b, t.e[2], t.e[3]));
         h->tm.cell_moments_s += a1 * 1e-3;
         h->tm.cell_plane_s += a2 * 1e-3;
@@ -216,6 +325,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellAux, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * 6));
+    CAPE_ALLOC(dalloc(h->debugCycles, B * 16));
+    CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * 16 * 8));
     CAPE_ALLOC(dalloc(h->records, B));
     CAPE_ALLOC(dalloc(h->summaries, B));
     CAPE_ALLOC(dalloc(h->planeLabels, B * C));
@@ -318,11 +429,20 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.planeSeedCount = static_cast<int>(static_cast<unsigned>((0.8 / 100.0) * h->cells));
     b.minCellActivated = static_cast<int>(static_cast<unsigned>((0.65 / 100.0) * h->cells));
     b.cylScratch = h->cylScratch;
+    b.debugCycles = h->debugCycles;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;
     // cylinder_segment.cpp:132
     b.ransacMaxIterations = static_cast<int>(static_cast<unsigned>(logf(1.0f - 0.8f) / logf(1.0f - powf(0.33f, 3.0f))));
 
+    if (cfg->sub_batches > 1)
+    {
+        for (auto& st : h->pipeStream)
+            CAPE_ALLOC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        CAPE_ALLOC(hipEventCreateWithFlags(&h->pipeFork, hipEventDisableTiming));
+        for (auto& e : h->pipeJoin)
+            CAPE_ALLOC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0) > 160 * 1024)
     {
         free_all(h);
@@ -366,40 +486,61 @@ int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     h->pa.depth = depth_dev;
     h->pb.depth = depth_dev;
-    cape_handle_s::EvTriple* t = nullptr;
-    if (h->timing)
+    if (h->cfg.sub_batches > 1 && n_frames >= 2 * h->cfg.sub_batches)
     {
-        if (h->evPending == h->evPool.size())
+        // fork: both internal streams wait for everything already enqueued on the caller's stream
+        CAPE_HIP_TRY(hipEventRecord(h->pipeFork, stream));
+        for (auto& st : h->pipeStream)
+            CAPE_HIP_TRY(hipStreamWaitEvent(st, h->pipeFork, 0));
+        // stream 0 runs the streaming kernel of every sub-batch back to back; stream 1 runs the per-cell fit and the
+        // grow kernel of sub-batch i as soon as its moments are done, i.e. underneath the moments of sub-batch i+1
+        const int k = h->cfg.sub_batches;
+        if ((int)h->pipeStage.size() < k)
         {
-            if (h->evPool.size() >= 4096)
-            {
-                const int rc = fold_timings(h); // synchronises; keeps the pool bounded
-                if (rc != CAPE_OK)
-                    return rc;
-            }
-            else
-            {
-                cape_handle_s::EvTriple nt{};
-                for (auto& e : nt.e)
-                    CAPE_HIP_TRY(hipEventCreate(&e));
-                h->evPool.push_back(nt);
-            }
+            const size_t old = h->pipeStage.size();
+            h->pipeStage.resize(k, nullptr);
+            for (size_t q = old; q < h->pipeStage.size(); ++q)
+                CAPE_HIP_TRY(hipEventCreateWithFlags(&h->pipeStage[q], hipEventDisableTiming));
         }
-        t = &h->evPool[h->evPending];
-        t->frames = n_frames;
-        CAPE_HIP_TRY(hipEventRecord(t->e[0], stream));
+        for (int i = 0; i < k; ++i)
+        {
+            const int f0 = (int)((long long)n_frames * i / k), f1 = (int)((long long)n_frames * (i + 1) / k);
+            cape::StageAParams a;
+            cape::StageBParams b;
+            offset_params(h, f0, a, b);
+            cape_handle_s::EvTriple* t = nullptr;
+            const int rc = acquire_events(h, f1 - f0, &t);
+            if (rc != CAPE_OK)
+                return rc;
+            if (t)
+                CAPE_HIP_TRY(hipEventRecord(t->e[0], h->pipeStream[0]));
+            cape::launch_cell_moments(a, f1 - f0, h->pipeStream[0]);
+            if (t)
+                CAPE_HIP_TRY(hipEventRecord(t->e[1], h->pipeStream[0]));
+            CAPE_HIP_TRY(hipEventRecord(h->pipeStage[i], h->pipeStream[0]));
+            CAPE_HIP_TRY(hipStreamWaitEvent(h->pipeStream[1], h->pipeStage[i], 0));
+            if (t)
+                CAPE_HIP_TRY(hipEventRecord(t->e2b, h->pipeStream[1]));
+            cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]);
+            if (t)
+                CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
+            cape::launch_grow(b, f1 - f0, h->pipeStream[1]);
+            if (t)
+                CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));
+        }
+        // join
+        for (int i = 0; i < 2; ++i)
+        {
+            CAPE_HIP_TRY(hipEventRecord(h->pipeJoin[i], h->pipeStream[i]));
+            CAPE_HIP_TRY(hipStreamWaitEvent(stream, h->pipeJoin[i], 0));
+        }
+        CAPE_HIP_TRY(hipGetLastError());
+        return CAPE_OK;
     }
-    cape::launch_cell_moments(h->pa, n_frames, stream);
-    if (t)
-        CAPE_HIP_TRY(hipEventRecord(t->e[1], stream));
-    cape::launch_cell_plane(h->pa, n_frames, stream);
-    if (t)
-        CAPE_HIP_TRY(hipEventRecord(t->e[2], stream));
-    cape::launch_grow(h->pb, n_frames, stream);
-    if (t)
     {
-        CAPE_HIP_TRY(hipEventRecord(t->e[3], stream));
-        h->evPending += 1;
+        const int rc = launch_chain(h, h->pa, h->pb, n_frames, stream);
+        if (rc != CAPE_OK)
+            return rc;
     }
     CAPE_HIP_TRY(hipGetLastError());
     return CAPE_OK;
@@ -495,6 +636,15 @@ int cape_device_summaries(cape_handle h, void** summaries)
     if (!h || !summaries)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
     *summaries = h->summaries;
+    return CAPE_OK;
+}
+
+int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out)
+{
+    if (!h || !out || n_frames < 0 || n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    CAPE_HIP_TRY(hipMemcpy(out, h->debugCycles, (size_t)n_frames * 16 * 8, hipMemcpyDeviceToHost));
     return CAPE_OK;
 }
 

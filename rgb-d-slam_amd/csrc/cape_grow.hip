@@ -26,6 +26,40 @@ namespace cape {
 
 constexpr int kHistBins = 400;
 constexpr int kSegDoubles = 20; // LDS plane-segment record: sums[9], n, normal[3], d, centroid[3], mse, score, planar
+constexpr int kChunk = 32;      // cells staged per step of the ordered moment accumulation
+
+// kernel-phase ablation for profiling experiments: -DCAPE_B_STOP_AT=k makes the wave leave after phase k
+#ifdef CAPE_B_STOP_AT
+#define CAPE_B_STOP(k)                                                                                       \
+    do                                                                                                       \
+    {                                                                                                        \
+        if ((k) == CAPE_B_STOP_AT)                                                                           \
+        {                                                                                                    \
+            if (lane == 0)                                                                                   \
+                p.records[frame].header.n_seeds = (int)U + (int)EL + (int)ER + (int)EU + (int)ED;            \
+            return;                                                                                          \
+        }                                                                                                    \
+    } while (0)
+#else
+#define CAPE_B_STOP(k)
+#endif
+
+// per-phase shader-clock accounting for profiling experiments (-DCAPE_B_PROFILE): slot k accumulates the ticks since
+// the previous CAPE_TICK
+#ifdef CAPE_B_PROFILE
+#define CAPE_TICK(k)                                                                                         \
+    do                                                                                                       \
+    {                                                                                                        \
+        const unsigned long long _now = __builtin_amdgcn_s_memtime();                                        \
+        if (lane == 0)                                                                                       \
+            p.debugCycles[(size_t)frame * 16 + (k)] += _now - _tick;                                         \
+        _tick = _now;                                                                                        \
+    } while (0)
+#define CAPE_TICK_INIT() unsigned long long _tick = __builtin_amdgcn_s_memtime()
+#else
+#define CAPE_TICK(k)
+#define CAPE_TICK_INIT()
+#endif
 
 // wave-synchronous ordering point for LDS traffic between lanes of the single wave of this workgroup
 #define CAPE_WAVE_SYNC() __syncthreads()
@@ -170,10 +204,10 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     const size_t cellBase = (size_t)frame * C;
 
     // ---- LDS carve (all offsets multiples of 16)
-    double* s_mse = reinterpret_cast<double*>(smem);                              // C f64
-    double* s_seg = s_mse + C;                                                    // CAPE_MAX_PLANES x 20 f64
-    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_seg + CAPE_MAX_PLANES * kSegDoubles); // 64 u64
-    int* s_hist = reinterpret_cast<int*>(s_adj + CAPE_MAX_PLANES);                // 400 i32
+    double* s_seg = reinterpret_cast<double*>(smem);                              // CAPE_MAX_PLANES x 20 f64
+    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunk * kSumStride); // 64 u64
+    int* s_hist = reinterpret_cast<int*>(s_adj + 64);                             // 400 i32
     short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
@@ -184,12 +218,13 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
+    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64 (MSAC costs)
 
     const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
 
     for (int i = lane; i < kHistBins; i += 64)
         s_hist[i] = 0;
-    for (int i = lane; i < CAPE_MAX_PLANES; i += 64)
+    for (int i = lane; i < 64; i += 64)
     {
         s_adj[i] = 0ull;
         s_mlab[i] = (unsigned char)i;
@@ -197,6 +232,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     CAPE_WAVE_SYNC();
 
     uint32_t status = 0;
+    CAPE_TICK_INIT();
+    MaskT U = 0, EL = 0, ER = 0, EU = 0, ED = 0; // bit rows, lane r <- grid row r (filled below)
 
     // =========================================================================================
     // init_histogram (primitive_detection.cpp:239-265, histogram.hpp:35-62)
@@ -205,8 +242,6 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     for (int i = lane; i < C; i += 64)
     {
         const uint32_t fl = p.cell_flags[cellBase + i];
-        const double* pl = p.cell_plane + (cellBase + i) * kPlaneStride;
-        s_mse[i] = pl[7];
         s_lab[i] = 0;
         s_cyl[i] = 0;
         const int bin = p.cell_bins[cellBase + i]; // computed by stage A2 (acos / atan2 of the cell normal)
@@ -223,6 +258,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     }
     const int nPlanar = wave_sum_i32(nPlanarLocal);
     CAPE_WAVE_SYNC();
+    CAPE_B_STOP(1);
+    CAPE_TICK(0);
 
     // =========================================================================================
     // bit rows: unassigned mask and the four directed edge masks (region_growing's predicate,
@@ -230,7 +267,6 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     //   EL bit c : parent (r,c-1) -> child (r,c)      ER bit c : parent (r,c+1) -> child (r,c)
     //   EU bit c : parent (r-1,c) -> child (r,c)      ED bit c : parent (r+1,c) -> child (r,c)
     // =========================================================================================
-    MaskT U = 0, EL = 0, ER = 0, EU = 0, ED = 0;
     {
         double unx = 0, uny = 0, unz = 0, ud = 0, ucx = 0, ucy = 0, ucz = 0, utol = 0; // row above, same column
         for (int r = 0; r < VC; ++r)
@@ -268,6 +304,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         }
     }
 
+    CAPE_B_STOP(2);
+    CAPE_TICK(1);
     // =========================================================================================
     // grow_planes_and_cylinders (primitive_detection.cpp:267-310)
     // =========================================================================================
@@ -304,7 +342,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             if (s_bins[i] == (short)bin)
             {
                 ++candLocal;
-                const unsigned long long mb = (unsigned long long)__double_as_longlong(s_mse[i]);
+                const unsigned long long mb =
+                        (unsigned long long)__double_as_longlong(p.cell_plane[(cellBase + i) * kPlaneStride + 7]);
                 if (mb < bestLocal)
                 {
                     bestLocal = mb;
@@ -312,6 +351,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
                 }
             }
         }
+        CAPE_TICK(2); // histogram arg-max + candidate scan
         const int cand = wave_sum_i32(candLocal);
         if (cand < p.planeSeedCount || cand == 0)
             break;
@@ -335,6 +375,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         const bool seedUnassigned = (seedRowU >> sx) & (MaskT)1;
         const bool seedOK = seedUnassigned && can_be_merged(pnx, pny, pnz, sd, snx, sny, snz, scx, scy, scz, stol, p.cosMerge);
 
+        CAPE_TICK(3); // seed pick + self test
         // ---- region_growing (:778-818) as label propagation on bit rows
         MaskT act = 0;
         if (seedOK)
@@ -361,6 +402,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             }
         }
 
+        CAPE_TICK(4); // label propagation
         // ---- activated cell list in ascending cell index (row-major)
         const int rowCnt = popc<MaskT>(act);
         const int incl = wave_scan_i32(rowCnt, lane);
@@ -379,26 +421,26 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
 
         // ---- expand_segment over activated cells in ascending order (:341-360): lanes 0..8 own one sum each, lane 9
         //      the point count.  The seed's own sums are counted twice (copy :325 + expand of the seed itself).
+        CAPE_TICK(5); // list build
         const int ql = lane < 10 ? lane : 0;
         double acc = sumsBase[(size_t)seed * kSumStride + ql];
+        for (int c0 = 0; c0 < total; c0 += kChunk)
         {
-            int i = 0;
-            for (; i + 4 <= total; i += 4)
+            // all lanes stage kChunk cells x 10 f64 (coalesced 16-B pieces), then lanes 0..9 add them in order from LDS
+            const int cn = (total - c0 < kChunk) ? (total - c0) : kChunk;
+            for (int e = lane; e < cn * 5; e += 64)
             {
-                const int c0 = s_list[i], c1 = s_list[i + 1], c2 = s_list[i + 2], c3 = s_list[i + 3];
-                const double v0 = sumsBase[(size_t)c0 * kSumStride + ql];
-                const double v1 = sumsBase[(size_t)c1 * kSumStride + ql];
-                const double v2 = sumsBase[(size_t)c2 * kSumStride + ql];
-                const double v3 = sumsBase[(size_t)c3 * kSumStride + ql];
-                acc += v0;
-                acc += v1;
-                acc += v2;
-                acc += v3;
+                const int ci = e / 5, piece = e - ci * 5;
+                const double2 v = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[c0 + ci] * kSumStride + 2 * piece);
+                *reinterpret_cast<double2*>(s_chunk + ci * kSumStride + 2 * piece) = v;
             }
-            for (; i < total; ++i)
-                acc += sumsBase[(size_t)s_list[i] * kSumStride + ql];
+            CAPE_WAVE_SYNC();
+            for (int ci = 0; ci < cn; ++ci)
+                acc += s_chunk[ci * kSumStride + ql];
+            CAPE_WAVE_SYNC();
         }
 
+        CAPE_TICK(6); // ordered accumulation
         // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
         for (int i = lane; i < total; i += 64)
         {
@@ -426,6 +468,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         }
         CAPE_WAVE_SYNC();
 
+        CAPE_TICK(7); // histogram removal
         SegRec ns;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -436,6 +479,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         if (!f.planar)
             continue; // "Plane segment is not planar after merge"
 
+        CAPE_TICK(8); // region plane fit
         if (f.score > 100)
         {
             // add_plane_segment_to_features (:391-411): push_back copies the segment (one more normalisation)
@@ -465,7 +509,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             cc.C = C;
             cc.s_list = s_list;
             cc.total = total;
-            cc.s_dist = s_mse; // borrowed; restored below
+            cc.s_dist = s_dist;
             cc.s_ids = s_ids;
             cc.s_idmask = s_idmask;
             cc.s_cur = s_cur;
@@ -479,9 +523,6 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
             ++nCylFits;
             CAPE_WAVE_SYNC();
-            for (int i = lane; i < C; i += 64)
-                s_mse[i] = p.cell_plane[(cellBase + i) * kPlaneStride + 7];
-            CAPE_WAVE_SYNC();
             if (planeOverflow)
             {
                 status |= CAPE_FRAME_PLANE_OVERFLOW;
@@ -490,6 +531,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         }
     }
 
+    CAPE_B_STOP(3);
+    CAPE_TICK(9);
     // =========================================================================================
     // merge_planes (:503-560) with get_connected_components_matrix (:736-776)
     // =========================================================================================
@@ -562,6 +605,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         CAPE_WAVE_SYNC();
     }
 
+    CAPE_B_STOP(4);
+    CAPE_TICK(10);
     // =========================================================================================
     // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
     // =========================================================================================
@@ -690,6 +735,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         }
     }
 
+    CAPE_B_STOP(5);
+    CAPE_TICK(11);
     // =========================================================================================
     // add_cylinders_to_primitives (:705-734): open (dilate, erode) + erode with the 3x3 cross, default borders
     // =========================================================================================
@@ -763,16 +810,16 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
 size_t grow_lds_bytes(int cells, bool cylinders)
 {
     size_t b = 0;
-    b += (size_t)cells * 8;                        // s_mse
     b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
-    b += (size_t)CAPE_MAX_PLANES * 8;               // s_adj
+    b += (size_t)kChunk * kSumStride * 8;           // s_chunk
+    b += (size_t)64 * 8;                            // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins
     b += (size_t)cells * 2;                         // s_list
     b += (size_t)cells * 2;                         // s_lab + s_cyl
     b += 64;                                        // s_mlab
     if (cylinders)
-        b += (size_t)cells * 2 + (size_t)cells * 3; // s_ids + s_idmask / s_cur / s_best
+        b += (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8; // s_ids, s_idmask / s_cur / s_best, s_dist
     return (b + 15) & ~(size_t)15;
 }
 

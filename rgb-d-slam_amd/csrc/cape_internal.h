@@ -79,6 +79,7 @@ struct StageBParams
     int rngCount;
     int ransacMaxIterations; // 43
     double* cylScratch;      // [frames][cells][6] projected normals / centroids (only with CAPE_FLAG_CYLINDERS)
+    unsigned long long* debugCycles; // [frames][16] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
 };
 
 } // namespace cape

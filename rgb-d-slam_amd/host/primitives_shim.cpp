@@ -112,6 +112,7 @@ Primitive_Detection::Primitive_Detection(const uint width, const uint height) : 
     cfg.device = 0;
     cfg.max_batch = _maxBatch = 64;
     cfg.boundary_capacity = 0;
+    cfg.sub_batches = 0;
     if (cape_create(&cfg, &_handle) != CAPE_OK)
     {
         log(2, std::string("Primitive_Detection: ") + cape_last_error());

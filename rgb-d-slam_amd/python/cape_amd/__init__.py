@@ -11,10 +11,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # rgb-d-slam_amd/
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libcape_hip.so")
+LIB_PATH = os.environ.get("CAPE_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcape_hip.so")  # env: kernel experiments
 
-CAPE_MAX_PLANES = 64
-CAPE_MAX_CYLINDERS = 32
+CAPE_MAX_PLANES = 32
+CAPE_MAX_CYLINDERS = 16
 CAPE_FLAG_CYLINDERS = 1
 
 FRAME_PLANE_OVERFLOW = 1 << 0
@@ -32,7 +32,7 @@ class CapeError(RuntimeError):
 class cape_config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_double), ("fy", C.c_double),
                 ("cx", C.c_double), ("cy", C.c_double), ("flags", C.c_uint32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("boundary_capacity", C.c_int32)]
+                ("max_batch", C.c_int32), ("boundary_capacity", C.c_int32), ("sub_batches", C.c_int32)]
 
 
 class cape_layout(C.Structure):
@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_host", "cape_device_results",
     "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings",
-    "cape_last_error", "cape_version", "cape_debug_eval",
+    "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -111,6 +111,7 @@ def load_library():
     L.cape_reset_timings.argtypes = [vp]
     L.cape_device_summaries.argtypes = [vp, C.POINTER(vp)]
     L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
+    L.cape_debug_cycles.argtypes = [vp, C.c_int32, vp]
     L.cape_last_error.restype = C.c_char_p
     L.cape_version.restype = C.c_char_p
     _lib = L
@@ -148,10 +149,10 @@ class Extractor:
     """Thin owner of a cape_handle (mirrors the ctor pair of reference src/rgbd_slam.cpp:48-57)."""
 
     def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=False, device=0,
-                 max_batch=64, boundary_capacity=0):
+                 max_batch=64, boundary_capacity=0, sub_batches=0):
         self.L = load_library()
         cfg = cape_config(width, height, fx, fy, cx, cy, CAPE_FLAG_CYLINDERS if cylinders else 0, device, max_batch,
-                          boundary_capacity)
+                          boundary_capacity, sub_batches)
         self.h = C.c_void_p()
         _check(self.L, self.L.cape_create(C.byref(cfg), C.byref(self.h)), "cape_create")
         lay = cape_layout()
@@ -208,6 +209,11 @@ class Extractor:
     def cell_stats(self, frame):
         out = np.zeros(self.cells, CELL_STATS_DTYPE)
         _check(self.L, self.L.cape_copy_cell_stats(self.h, frame, out.ctypes.data_as(C.c_void_p)), "cape_copy_cell_stats")
+        return out
+
+    def debug_cycles(self, n_frames):
+        out = np.zeros((n_frames, 16), np.uint64)
+        _check(self.L, self.L.cape_debug_cycles(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_debug_cycles")
         return out
 
     # ---- timing --------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert cape_amd.PLANE_SEGMENT_DTYPE.itemsize == 30 * 8 + 6 * 4
     assert cape_amd.CYLINDER_DTYPE.itemsize == 40
     assert cape_amd.HEADER_DTYPE.itemsize == 32
-    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 32 * 40
+    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 32 * 264 + 16 * 40
     assert cape_amd.SUMMARY_DTYPE.itemsize == 1296
     assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4
 
@@ -45,11 +45,11 @@ def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     lib = cape_amd.load_library()
-    cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0)
+    cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0, 0)
     h = C.c_void_p()
     assert lib.cape_create(C.byref(cfg), C.byref(h)) == -2
     assert b"no CPU fallback" in lib.cape_last_error()
-    bad = cape_amd.cape_config(641, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0)
+    bad = cape_amd.cape_config(641, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, 1, 0, 0)
     assert lib.cape_create(C.byref(bad), C.byref(h)) == -1
 
 
