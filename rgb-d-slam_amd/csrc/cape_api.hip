@@ -61,6 +61,7 @@ struct cape_handle_s
     uint32_t* cellFlags = nullptr;
     int32_t* cellBins = nullptr;
     cape::CellAux* cellAux = nullptr;
+    double* cellMse = nullptr;
     // results
     cape_frame_record* records = nullptr;
     cape_primitive_summary* summaries = nullptr;
@@ -130,6 +131,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cellFlags);
     (void)hipFree(h->cellBins);
     (void)hipFree(h->cellAux);
+    (void)hipFree(h->cellMse);
     (void)hipFree(h->records);
     (void)hipFree(h->summaries);
     (void)hipFree(h->planeLabels);
@@ -173,6 +175,9 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     a.cell_flags += F * C;
     a.cell_bins += F * C;
     a.cell_aux += F * C;
+    a.cell_mse += F * C;
+    b.cell_aux = a.cell_aux;
+    b.cell_mse = a.cell_mse;
     b.cell_sums = a.cell_sums;
     b.cell_plane = a.cell_plane;
     b.cell_score = a.cell_score;
@@ -323,6 +328,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellFlags, B * C));
     CAPE_ALLOC(dalloc(h->cellBins, B * C));
     CAPE_ALLOC(dalloc(h->cellAux, B * C));
+    CAPE_ALLOC(dalloc(h->cellMse, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * 6));
     CAPE_ALLOC(dalloc(h->debugCycles, B * 16));
@@ -399,6 +405,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     a.cell_flags = h->cellFlags;
     a.cell_bins = h->cellBins;
     a.cell_aux = h->cellAux;
+    a.cell_mse = h->cellMse;
     // primitive_detection.cpp:189-190 ; parameters.hpp:75 maximumPlaneAngleForMerge_d = 18.0f
     a.sinMerge = sinf(static_cast<float>(18.0f * M_PI / 180.0));
     // plane_segment.hpp:33-34 ; parameters.hpp:72 minimumZeroDepthProportion = 0.7f
@@ -418,6 +425,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cell_tol = h->cellTol;
     b.cell_flags = h->cellFlags;
     b.cell_bins = h->cellBins;
+    b.cell_aux = h->cellAux;
+    b.cell_mse = h->cellMse;
     b.records = h->records;
     b.summaries = h->summaries;
     b.plane_labels = h->planeLabels;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAP
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
-    __shared__ float s_corner[64 * 2];   // first and last pixel of every cell
+    __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
 
     const int t = threadIdx.x;
     const int frame = blockIdx.x / p.pairsPerFrame;
@@ -148,9 +148,11 @@ __global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAP
                 if (j == 2)
                     s_col[lcell * kCell + r] = buf[i].z; // pixel column 10 of the cell
                 if (r == 0 && j == 0)
-                    s_corner[lcell * 2] = buf[i].x;
+                    s_corner[lcell * 3] = buf[i].x;
                 if (r == kCell - 1 && j == 4)
-                    s_corner[lcell * 2 + 1] = buf[i].w;
+                    s_corner[lcell * 3 + 1] = buf[i].w;
+                if (r == kCell / 2 && j == 2)
+                    s_corner[lcell * 3 + 2] = buf[i].z;
             }
         };
         load_group(bufA, 0);
@@ -251,10 +253,10 @@ __global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAP
 
     const size_t gcell = (size_t)frame * p.cells + fRow * p.hCells + fCol;
     CellAux aux;
-    aux.z0 = s_corner[t * 2];
-    aux.z399 = s_corner[t * 2 + 1];
+    aux.z0 = s_corner[t * 3];
+    aux.z399 = s_corner[t * 3 + 1];
     aux.flags = (n & kCountMask) | (continuous ? kAuxContinuous : 0u) | (exact_ok ? kAuxExact : 0u);
-    aux.pad = 0;
+    aux.zc = s_corner[t * 3 + 2];
     p.cell_aux[gcell] = aux;
 }
 
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, in
     double* op = p.cell_plane + gcell * kPlaneStride;
     op[0] = f.nx; op[1] = f.ny; op[2] = f.nz; op[3] = f.d;
     op[4] = f.cx; op[5] = f.cy; op[6] = f.cz; op[7] = f.mse;
+    p.cell_mse[gcell] = f.mse;
     p.cell_score[gcell] = f.score;
     p.cell_tol[gcell] = tol;
     p.cell_bins[gcell] = bin;

@@ -63,6 +63,10 @@ constexpr int kChunk = 32;      // cells staged per step of the ordered moment a
 
 // wave-synchronous ordering point for LDS traffic between lanes of the single wave of this workgroup
 #define CAPE_WAVE_SYNC() __syncthreads()
+// LDS-only ordering point.  The workgroup is ONE wave and LDS instructions of a wave execute in issue order, so a
+// compiler-level fence is enough; unlike __syncthreads() it does not drain outstanding global loads (vmcnt), which
+// is what lets the cell-sum prefetch below stay in flight across it.
+#define CAPE_LDS_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
@@ -205,10 +209,11 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
 
     // ---- LDS carve (all offsets multiples of 16)
     double* s_seg = reinterpret_cast<double*>(smem);                              // CAPE_MAX_PLANES x 20 f64
-    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
-    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunk * kSumStride); // 64 u64
+    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // 2 x kChunk x 10 f64 staging of cell sums
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + 2 * kChunk * kSumStride); // 64 u64
     int* s_hist = reinterpret_cast<int*>(s_adj + 64);                             // 400 i32
-    short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
+    float* s_zc = reinterpret_cast<float*>(s_hist + kHistBins);                   // C f32 centre-pixel depth of every cell
+    short* s_bins = reinterpret_cast<short*>(s_zc + C);                           // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
     unsigned char* s_cyl = s_lab + C;                                             // C u8  cylinder labels
@@ -251,6 +256,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             ++nPlanarLocal;
         }
         s_bins[i] = (short)bin;
+        s_zc[i] = p.cell_aux[cellBase + i].zc;
         if (fl & kFlagNearEdge)
             status |= CAPE_FRAME_BIN_NEAR_EDGE;
         if (fl & kFlagInorder)
@@ -269,14 +275,26 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     // =========================================================================================
     {
         double unx = 0, uny = 0, unz = 0, ud = 0, ucx = 0, ucy = 0, ucz = 0, utol = 0; // row above, same column
-        for (int r = 0; r < VC; ++r)
-        {
-            const bool in = lane < HC;
+        const bool in = lane < HC;
+        // row r+1 is fetched while row r is evaluated (the records sit in L2 / HBM: ~2k cycles per dependent load)
+        double qnx, qny, qnz, qd, qcx, qcy, qcz;
+        float qtol;
+        uint32_t qfl;
+        auto fetch_row = [&](int r) {
             const int ci = r * HC + (in ? lane : 0);
             const double* pl = p.cell_plane + (cellBase + ci) * kPlaneStride;
-            const double nx = pl[0], ny = pl[1], nz = pl[2], d = pl[3], cx = pl[4], cy = pl[5], cz = pl[6];
-            const double tol = (double)p.cell_tol[cellBase + ci];
-            const bool planar = in && (p.cell_flags[cellBase + ci] & kFlagPlanar);
+            qnx = pl[0]; qny = pl[1]; qnz = pl[2]; qd = pl[3]; qcx = pl[4]; qcy = pl[5]; qcz = pl[6];
+            qtol = p.cell_tol[cellBase + ci];
+            qfl = p.cell_flags[cellBase + ci];
+        };
+        fetch_row(0);
+        for (int r = 0; r < VC; ++r)
+        {
+            const double nx = qnx, ny = qny, nz = qnz, d = qd, cx = qcx, cy = qcy, cz = qcz;
+            const double tol = (double)qtol;
+            const bool planar = in && (qfl & kFlagPlanar);
+            if (r + 1 < VC)
+                fetch_row(r + 1);
             // left neighbour (lane - 1)
             const double lnx = __shfl_up(nx, 1), lny = __shfl_up(ny, 1), lnz = __shfl_up(nz, 1), ld = __shfl_up(d, 1);
             const double lcx = __shfl_up(cx, 1), lcy = __shfl_up(cy, 1), lcz = __shfl_up(cz, 1), ltol = __shfl_up(tol, 1);
@@ -337,17 +355,32 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         int candLocal = 0;
         unsigned long long bestLocal = ~0ull; // (mse bits) ; mse >= 0 so the bit pattern orders like the value
         int bestIdxLocal = 0x7FFFFFFF;
-        for (int i = lane; i < C; i += 64)
         {
-            if (s_bins[i] == (short)bin)
+            const double* mseBase = p.cell_mse + cellBase;
+            constexpr int kBatch = 12; // 12 independent coalesced loads in flight per lane
+            for (int i0 = lane; i0 < C; i0 += 64 * kBatch)
             {
-                ++candLocal;
-                const unsigned long long mb =
-                        (unsigned long long)__double_as_longlong(p.cell_plane[(cellBase + i) * kPlaneStride + 7]);
-                if (mb < bestLocal)
+                double mv[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k)
                 {
-                    bestLocal = mb;
-                    bestIdxLocal = i;
+                    const int i = i0 + 64 * k;
+                    mv[k] = mseBase[i < C ? i : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k)
+                {
+                    const int i = i0 + 64 * k;
+                    if (i < C && s_bins[i] == (short)bin)
+                    {
+                        ++candLocal;
+                        const unsigned long long mb = (unsigned long long)__double_as_longlong(mv[k]);
+                        if (mb < bestLocal)
+                        {
+                            bestLocal = mb;
+                            bestIdxLocal = i;
+                        }
+                    }
                 }
             }
         }
@@ -424,20 +457,57 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
         CAPE_TICK(5); // list build
         const int ql = lane < 10 ? lane : 0;
         double acc = sumsBase[(size_t)seed * kSumStride + ql];
-        for (int c0 = 0; c0 < total; c0 += kChunk)
         {
-            // all lanes stage kChunk cells x 10 f64 (coalesced 16-B pieces), then lanes 0..9 add them in order from LDS
-            const int cn = (total - c0 < kChunk) ? (total - c0) : kChunk;
-            for (int e = lane; e < cn * 5; e += 64)
+            // all lanes stage kChunk cells x 10 f64 per step (coalesced 16-B pieces: 160 pieces = 2.5 per lane) through
+            // registers into one of two LDS buffers; the next chunk's loads are in flight while lanes 0..9 add the
+            // current chunk in order
+            // lane l owns pieces e = l, l+64, l+128 of a chunk (piece = 16 B = 2 of the 10 f64 of a cell)
+            const int e0 = lane, e1 = lane + 64, e2 = lane + 128;
+            const int ci0 = e0 / 5, pc0 = e0 - ci0 * 5;
+            const int ci1 = e1 / 5, pc1 = e1 - ci1 * 5;
+            const int ci2 = e2 / 5, pc2 = e2 - ci2 * 5;
+            double2 pre0 = make_double2(0, 0), pre1 = pre0, pre2 = pre0;
+#define CAPE_ISSUE_CHUNK(c0_)                                                                                          \
+    do                                                                                                               \
+    {                                                                                                                \
+        const int cn_ = (total - (c0_) < kChunk) ? (total - (c0_)) : kChunk;                                         \
+        if (e0 < cn_ * 5)                                                                                            \
+            pre0 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci0] * kSumStride + 2 * pc0); \
+        if (e1 < cn_ * 5)                                                                                            \
+            pre1 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci1] * kSumStride + 2 * pc1); \
+        if (e2 < cn_ * 5)                                                                                            \
+            pre2 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci2] * kSumStride + 2 * pc2); \
+    } while (0)
+            if (total > 0)
+                CAPE_ISSUE_CHUNK(0);
+            int buf = 0;
+            for (int c0 = 0; c0 < total; c0 += kChunk, buf ^= 1)
             {
-                const int ci = e / 5, piece = e - ci * 5;
-                const double2 v = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[c0 + ci] * kSumStride + 2 * piece);
-                *reinterpret_cast<double2*>(s_chunk + ci * kSumStride + 2 * piece) = v;
+                const int cn = (total - c0 < kChunk) ? (total - c0) : kChunk;
+                double* dst = s_chunk + buf * (kChunk * kSumStride);
+                if (e0 < cn * 5)
+                    *reinterpret_cast<double2*>(dst + ci0 * kSumStride + 2 * pc0) = pre0;
+                if (e1 < cn * 5)
+                    *reinterpret_cast<double2*>(dst + ci1 * kSumStride + 2 * pc1) = pre1;
+                if (e2 < cn * 5)
+                    *reinterpret_cast<double2*>(dst + ci2 * kSumStride + 2 * pc2) = pre2;
+                if (c0 + kChunk < total)
+                    CAPE_ISSUE_CHUNK(c0 + kChunk);
+                CAPE_LDS_SYNC();
+                if (cn == kChunk)
+                {
+#pragma unroll
+                    for (int ci = 0; ci < kChunk; ++ci)
+                        acc += dst[ci * kSumStride + ql];
+                }
+                else
+                {
+                    for (int ci = 0; ci < cn; ++ci)
+                        acc += dst[ci * kSumStride + ql];
+                }
+                CAPE_LDS_SYNC();
             }
-            CAPE_WAVE_SYNC();
-            for (int ci = 0; ci < cn; ++ci)
-                acc += s_chunk[ci * kSumStride + ql];
-            CAPE_WAVE_SYNC();
+#undef CAPE_ISSUE_CHUNK
         }
 
         CAPE_TICK(6); // ordered accumulation
@@ -613,7 +683,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     cape_frame_record* rec = p.records + frame;
     cape_primitive_summary* sum = p.summaries + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
-    const float* depthF = p.depth + (size_t)frame * p.W * p.H;
+    const double acolCenter = p.acol[(lane < HC ? lane : 0) * kCell + kCell / 2];
     int nBoundary = 0;
     int nPlanesOut = 0;
     for (int pi = 0; pi < nSeg; ++pi)
@@ -658,12 +728,11 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
                 double px = 0, py = 0, pz = 0;
                 if (lane < HC && ((ringRow >> lane) & (MaskT)1))
                 {
-                    const int centerX = lane * kCell + kCell / 2;
                     const int centerY = r * kCell + kCell / 2;
-                    const double dpt = (double)depthF[(size_t)centerY * p.W + centerX];
+                    const double dpt = (double)s_zc[r * HC + lane]; // depthImage(centerY, centerX), staged by stage A
                     if (dpt > 0)
                     {
-                        px = dpt * p.acol[centerX];
+                        px = dpt * acolCenter;
                         py = dpt * p.brow[centerY];
                         pz = dpt;
                         const double dist = dot3(A.nx, A.ny, A.nz, px, py, pz) + A.d;
@@ -811,7 +880,8 @@ size_t grow_lds_bytes(int cells, bool cylinders)
 {
     size_t b = 0;
     b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
-    b += (size_t)kChunk * kSumStride * 8;           // s_chunk
+    b += (size_t)2 * kChunk * kSumStride * 8;       // s_chunk (double buffered)
+    b += (size_t)cells * 4;                         // s_zc
     b += (size_t)64 * 8;                            // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins

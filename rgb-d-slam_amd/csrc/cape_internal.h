@@ -14,7 +14,8 @@ namespace cape {
 //   cell_tol   [cells]     f32 : _cellDistanceTols
 //   cell_flags [cells]     u32 : point count | near-edge << 29 | inorder << 30 | planar << 31
 //   cell_bins  [cells]     i32 : histogram bin (-1 if not planar)
-//   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts)
+//   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts) + centre depth
+//   cell_mse   [cells]     f64 : copy of the cell MSE, compact so the seed selection reads it coalesced
 constexpr int kSumStride = 10;
 constexpr int kPlaneStride = 8;
 constexpr uint32_t kFlagPlanar = 1u << 31;
@@ -28,7 +29,7 @@ struct CellAux
 {
     float z0, z399;  // depth of the cell's first / last pixel (cloud rows offset and offset+399)
     uint32_t flags;  // valid pixel count | kAuxExact | kAuxContinuous
-    uint32_t pad;
+    float zc;        // depth of the cell's centre pixel (col*20+10, row*20+10): boundary candidate test
 };
 
 struct StageAParams
@@ -49,6 +50,7 @@ struct StageAParams
     uint32_t* cell_flags;
     int32_t* cell_bins;
     CellAux* cell_aux;
+    double* cell_mse;
     float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
 };
@@ -65,6 +67,8 @@ struct StageBParams
     const float* cell_tol;
     const uint32_t* cell_flags;
     const int32_t* cell_bins; // Histogram::_bins right after init_histogram (written by stage A2)
+    const CellAux* cell_aux;
+    const double* cell_mse;
     cape_frame_record* records;
     cape_primitive_summary* summaries;
     int32_t* plane_labels;
