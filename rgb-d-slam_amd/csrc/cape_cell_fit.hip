@@ -24,6 +24,18 @@
 
 namespace cape {
 
+// tuning knobs (overridable for A/B builds, see profiles/sweep.py)
+#ifndef CAPE_A_GROUP
+#define CAPE_A_GROUP 2   // image rows per prefetch group
+#endif
+#ifndef CAPE_A_WAVES
+#define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
+#endif
+#ifndef CAPE_A_PACKED
+#define CAPE_A_PACKED 0  // 1: pixel pairs with v_pk_mul_f32 -- measured SLOWER (1.66-1.94 ms): gfx950 SIMDs are 32 wide,
+                         // a packed f32 op costs two issue slots, so packing buys nothing here
+#endif
+
 constexpr int kThreadsA = 320;
 constexpr int kBandThreads = 160;
 constexpr int kPartStride = 11; // 10 f64 per thread, padded against LDS bank conflicts
@@ -58,8 +70,54 @@ __device__ __forceinline__ void acc_px(float zr, double a, double b, PxAcc& A)
     A.S[8] += (double)(x * z);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two horizontally adjacent pixels at once: the six f32 products of both pixels are three v_pk_mul_f32 pairs each
+// (same IEEE results as scalar v_mul_f32), everything else is the per-pixel sequence of acc_px.
+__device__ __forceinline__ void acc_px2(float zr0, float zr1, double a0, double a1, double b, PxAcc& A)
+{
+    const float z0 = fmaxf(zr0, 0.0f), z1 = fmaxf(zr1, 0.0f); // invalid (<= 0, NaN) -> +0: adds nothing to any sum
+    const bool v0 = z0 > 0.0f, v1 = z1 > 0.0f;                // == `if (z > 0)` on the raw value
+    A.n += (v0 ? 1u : 0u) + (v1 ? 1u : 0u);
+    // z range of the valid pixels (exactness guard)
+    const float i0 = v0 ? z0 : __builtin_huge_valf(), i1 = v1 ? z1 : __builtin_huge_valf();
+    A.zmin = fminf(A.zmin, fminf(i0, i1));
+    A.zmax = fmaxf(A.zmax, fmaxf(z0, z1));
+    const double zd0 = (double)z0, zd1 = (double)z1;
+    f32x2 z, x, y;
+    z.x = z0;
+    z.y = z1;
+    x.x = (float)(zd0 * a0);
+    x.y = (float)(zd1 * a1);
+    y.x = (float)(zd0 * b);
+    y.y = (float)(zd1 * b);
+    const f32x2 xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    A.S[0] += (double)x.x;
+    A.S[1] += (double)y.x;
+    A.S[2] += zd0;
+    A.S[3] += (double)xx.x;
+    A.S[4] += (double)yy.x;
+    A.S[5] += (double)zz.x;
+    A.S[6] += (double)xy.x;
+    A.S[7] += (double)yz.x;
+    A.S[8] += (double)xz.x;
+    A.S[0] += (double)x.y;
+    A.S[1] += (double)y.y;
+    A.S[2] += zd1;
+    A.S[3] += (double)xx.y;
+    A.S[4] += (double)yy.y;
+    A.S[5] += (double)zz.y;
+    A.S[6] += (double)xy.y;
+    A.S[7] += (double)yz.y;
+    A.S[8] += (double)xz.y;
+}
+
 __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, double a2, double a3, double b, PxAcc& A)
 {
+#if CAPE_A_PACKED
+    acc_px2(v.x, v.y, a0, a1, b, A);
+    acc_px2(v.z, v.w, a2, a3, b, A);
+#else
     acc_px(v.x, a0, b, A);
     acc_px(v.y, a1, b, A);
     acc_px(v.z, a2, b, A);
@@ -72,6 +130,7 @@ __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, do
     A.zmin = fminf(fminf(A.zmin, ix), fminf(iy, fminf(iz, iw)));
     const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); // fmaxf ignores NaN
     A.zmax = fmaxf(A.zmax, mx);
+#endif
 }
 
 // plane_segment.cpp:44-60
@@ -89,7 +148,7 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
     return true;
 }
 
-__global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAParams p)
+__global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
 {
     // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
@@ -129,7 +188,8 @@ __global__ __launch_bounds__(kThreadsA, 5) void cape_cell_moments_kernel(StageAP
         const size_t W = (size_t)p.W;
 
         // rows in groups of kGroup, ping-pong buffered: the loads of group g+1 are in flight while group g is summed
-        constexpr int kGroup = 2, kGroups = kCell / kGroup;
+        constexpr int kGroup = CAPE_A_GROUP, kGroups = kCell / kGroup;
+        static_assert(kCell % kGroup == 0 && kGroups % 2 == 0, "the ping-pong loop consumes two groups per trip");
         float4 bufA[kGroup], bufB[kGroup];
         auto load_group = [&](float4 (&buf)[kGroup], int g) {
 #pragma unroll
