@@ -201,6 +201,12 @@ int cape_get_layout(cape_handle h, cape_layout* out);
  */
 int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* stream);
 
+/* Same path fed with the raw 16-bit sensor image (what the depth PNGs of the TUM / CAPE datasets hold): the device
+ * converts exactly like the reference's host-side cv::Mat::convertTo(CV_32F, scale) (examples/main_TUM.cpp:221,242
+ * with scale = 1/5 ; examples/main_CAPE.cpp:58-59 with scale = 1): z = float(raw) * scale, 0 = invalid.  Halves the
+ * bytes read per frame ("next" row N4 of SURVEY.md 8f). */
+int cape_extract_u16(cape_handle h, const uint16_t* depth_dev, float scale, int32_t n_frames, void* stream);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -166,8 +166,10 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     b = h->pb;
     const size_t C = (size_t)h->cells, F = (size_t)f0;
     const size_t px = F * (size_t)h->cfg.width * h->cfg.height;
-    a.depth += px;
-    b.depth += px;
+    if (a.depth)
+        a.depth += px;
+    if (a.depth_u16)
+        a.depth_u16 += px;
     a.cell_sums += F * C * cape::kSumStride;
     a.cell_plane += F * C * cape::kPlaneStride;
     a.cell_score += F * C;
@@ -483,9 +485,25 @@ int cape_get_layout(cape_handle h, cape_layout* out)
     return CAPE_OK;
 }
 
+static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* depth_u16, float scale, int32_t n_frames,
+                        void* stream_);
+
 int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* stream_)
 {
-    if (!h || !depth_dev || n_frames < 0)
+    return extract_impl(h, depth_dev, nullptr, 0.0f, n_frames, stream_);
+}
+
+int cape_extract_u16(cape_handle h, const uint16_t* depth_dev, float scale, int32_t n_frames, void* stream_)
+{
+    if (!(scale > 0.0f))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "scale must be positive");
+    return extract_impl(h, nullptr, depth_dev, scale, n_frames, stream_);
+}
+
+static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* depth_u16, float scale, int32_t n_frames,
+                        void* stream_)
+{
+    if (!h || (!depth_dev && !depth_u16) || n_frames < 0)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
     if (n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
@@ -494,7 +512,8 @@ int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* 
         return CAPE_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     h->pa.depth = depth_dev;
-    h->pb.depth = depth_dev;
+    h->pa.depth_u16 = depth_u16;
+    h->pa.u16_scale = scale;
     if (h->cfg.sub_batches > 1 && n_frames >= 2 * h->cfg.sub_batches)
     {
         // fork: both internal streams wait for everything already enqueued on the caller's stream

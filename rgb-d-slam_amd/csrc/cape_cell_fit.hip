@@ -148,7 +148,7 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
     return true;
 }
 
-__global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
+template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
 {
     // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
@@ -183,7 +183,10 @@ __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_ker
     if (active)
     {
         const double a0 = p.acol[col0], a1 = p.acol[col0 + 1], a2 = p.acol[col0 + 2], a3 = p.acol[col0 + 3];
-        const float* base = p.depth + frameOff + (size_t)(cellRow * kCell) * p.W + col0;
+        const size_t pixOff = frameOff + (size_t)(cellRow * kCell) * p.W + col0;
+        const float* base = p.depth + pixOff;                 // float32 millimetres
+        const uint16_t* base16 = p.depth_u16 + pixOff;        // raw sensor units (U16 variant)
+        const float scale16 = p.u16_scale;
         const double* brow = p.brow + cellRow * kCell;
         const size_t W = (size_t)p.W;
 
@@ -194,7 +197,20 @@ __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_ker
         auto load_group = [&](float4 (&buf)[kGroup], int g) {
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
-                buf[i] = *reinterpret_cast<const float4*>(base + (size_t)(kGroup * g + i) * W);
+            {
+                if (U16)
+                {
+                    // N4: the PNG payload of the TUM / CAPE datasets, converted exactly like
+                    // cv::Mat::convertTo(CV_32F, scale) does (examples/main_TUM.cpp:242): float(raw) * float(scale)
+                    const ushort4 rw = *reinterpret_cast<const ushort4*>(base16 + (size_t)(kGroup * g + i) * W);
+                    buf[i] = make_float4((float)rw.x * scale16, (float)rw.y * scale16, (float)rw.z * scale16,
+                                         (float)rw.w * scale16);
+                }
+                else
+                {
+                    buf[i] = *reinterpret_cast<const float4*>(base + (size_t)(kGroup * g + i) * W);
+                }
+            }
         };
         auto sum_group = [&](const float4 (&buf)[kGroup], int g) {
 #pragma unroll
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, in
         // in-order path: the reference's pixel order (plane_segment.cpp:131-152)
         inorder = 1;
         rewrite = true;
-        const float* cellBase = p.depth + (size_t)frame * p.W * p.H + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
+        const size_t cellOff = (size_t)frame * p.W * p.H + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
         PxAcc A;
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -363,7 +379,11 @@ __global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, in
         {
             const double b = p.brow[cellRow * kCell + r];
             for (int c = 0; c < kCell; ++c)
-                acc_px(cellBase[(size_t)r * p.W + c], p.acol[cellCol * kCell + c], b, A);
+            {
+                const size_t o = cellOff + (size_t)r * p.W + c;
+                const float zr = p.depth ? p.depth[o] : (float)p.depth_u16[o] * p.u16_scale;
+                acc_px(zr, p.acol[cellCol * kCell + c], b, A);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -459,7 +479,10 @@ __global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, in
 void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
 {
     const int grid = nFrames * p.pairsPerFrame;
-    hipLaunchKernelGGL(cape_cell_moments_kernel, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    if (p.depth)
+        hipLaunchKernelGGL(cape_cell_moments_kernel<false>, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    else
+        hipLaunchKernelGGL(cape_cell_moments_kernel<true>, dim3(grid), dim3(kThreadsA), 0, stream, p);
 }
 
 void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream)

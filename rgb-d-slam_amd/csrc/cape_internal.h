@@ -34,7 +34,9 @@ struct CellAux
 
 struct StageAParams
 {
-    const float* depth; // frames x H x W
+    const float* depth; // frames x H x W float32 millimetres ...
+    const uint16_t* depth_u16; // ... or raw uint16 sensor units (then depth == nullptr): z = (float)raw * u16_scale
+    float u16_scale;
     int W, H, hCells, vCells, cells;
     int segsPerRow;     // ceil(hCells / 32): 640-pixel wide band segments per cell row
     int bandsPerFrame;  // vCells * segsPerRow
@@ -57,7 +59,6 @@ struct StageAParams
 
 struct StageBParams
 {
-    const float* depth;
     int W, H, hCells, vCells, cells;
     const double* acol;
     const double* brow;

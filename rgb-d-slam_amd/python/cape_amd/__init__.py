@@ -70,7 +70,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_host", "cape_device_results",
+    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_device_results",
     "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",
@@ -103,6 +103,7 @@ def load_library():
     L.cape_get_layout.argtypes = [vp, C.POINTER(cape_layout)]
     L.cape_extract.argtypes = [vp, vp, C.c_int32, vp]
     L.cape_extract_host.argtypes = [vp, vp, C.c_int32, vp]
+    L.cape_extract_u16.argtypes = [vp, vp, C.c_float, C.c_int32, vp]
     L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     L.cape_copy_cell_stats.argtypes = [vp, C.c_int32, vp]
@@ -178,6 +179,11 @@ class Extractor:
     def extract_device(self, depth_ptr, n_frames, stream=0):
         """depth_ptr: integer device address of n_frames x H x W float32 (e.g. torch_tensor.data_ptr())."""
         _check(self.L, self.L.cape_extract(self.h, C.c_void_p(depth_ptr), n_frames, C.c_void_p(stream)), "cape_extract")
+
+    def extract_device_u16(self, depth_ptr, scale, n_frames, stream=0):
+        """depth_ptr: device address of n_frames x H x W uint16 raw sensor units; z = float(raw) * scale."""
+        _check(self.L, self.L.cape_extract_u16(self.h, C.c_void_p(depth_ptr), C.c_float(scale), n_frames, C.c_void_p(stream)),
+               "cape_extract_u16")
 
     def extract_host(self, depth, stream=0):
         d = np.ascontiguousarray(depth, dtype=np.float32)

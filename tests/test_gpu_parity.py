@@ -318,3 +318,31 @@ def test_summaries_visible_to_torch_without_copy():
         assert np.array_equal(s["planes"]["normal"][f, :k], pl["out_normal"][:k])
         assert np.array_equal(s["planes"]["d"][f, :k], pl["d"][:k])
     ex.close()
+
+
+def test_raw_uint16_input_path(oracle_mod):
+    """N4: cape_extract_u16 (device-side convertTo(CV_32F, 1/5)) equals the float path and the oracle, bit for bit."""
+    import os
+
+    import torch
+    from cape_amd import Extractor, synth
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    raw0 = np.load(os.path.join(here, "golden", "tumlike_s1_raw_u16.npz"))["raw"]
+    raws = [raw0]
+    for f in (3, 8):
+        d = synth.tumlike(seed=4, frame=f)
+        r = np.rint(d.astype(np.float64) * 5.0).astype(np.uint16)
+        assert np.array_equal(r.astype(np.float32) * np.float32(0.2), d)
+        raws.append(r)
+    raw = np.stack(raws)
+    depth = raw.astype(np.float32) * np.float32(0.2)
+    intr = synth.TUM_FR1_INTRINSICS
+    ex = Extractor(640, 480, cylinders=True, max_batch=4, **intr)
+    t = torch.from_numpy(raw.view(np.int16)).cuda()
+    ex.extract_device_u16(t.data_ptr(), 0.2, len(raw), torch.cuda.current_stream().cuda_stream)
+    res = ex.results(len(raw))
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    for f in range(len(raw)):
+        compare_frame(orc.run(depth[f]), ex, res, f)
+    ex.close()
