@@ -17,6 +17,7 @@ void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
 void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders);
+int grow_waves_per_group();
 } // namespace cape
 
 namespace {

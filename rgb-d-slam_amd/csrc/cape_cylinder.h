@@ -18,6 +18,16 @@
 
 namespace cape {
 
+// wave-local ordering point (see CAPE_WAVE_SYNC in cape_grow.hip): the waves of a workgroup are independent frames,
+// so there is no s_barrier; drain all counters so that LDS / global scratch written by one lane is visible to the others
+#define CAPE_CYL_SYNC()                                                                                       \
+    do                                                                                                       \
+    {                                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+    } while (0)
+
 struct CylCtx
 {
     const StageBParams* p;
@@ -102,7 +112,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         c.s_ids[j] = (unsigned short)j;
         c.s_idmask[j] = 1;
     }
-    __syncthreads();
+    CAPE_CYL_SYNC();
 
     int planeSegmentsLeft = N;
     int idsLeftCount = N;
@@ -171,7 +181,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     curLocal += inl ? 1 : 0;
                 }
                 const int curCount = cyl_wave_sum(curLocal);
-                __syncthreads();
+                CAPE_CYL_SYNC();
                 double dist = 0.0;
                 {
                     int jj = 0;
@@ -200,7 +210,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     // early-stop quirk (:308-312): tests the swapped-out vector
                     stop = (unsigned)prevBestCount > inliersAccepted;
                 }
-                __syncthreads();
+                CAPE_CYL_SYNC();
                 if (stop)
                     break;
             }
@@ -244,7 +254,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 const bool inl = i < N && c.s_best[i];
                 const bool keep = i < N && !inl && c.s_idmask[i];
                 const unsigned long long kb = __ballot(keep);
-                __syncthreads(); // all reads of s_ids[...] of the previous pass are done before it is rewritten
+                CAPE_CYL_SYNC(); // all reads of s_ids[...] of the previous pass are done before it is rewritten
                 if (inl)
                     c.s_idmask[i] = 0;
                 if (keep)
@@ -254,7 +264,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             idsLeftCount = newCount;
             planeSegmentsLeft -= maxInliers;
         }
-        __syncthreads();
+        CAPE_CYL_SYNC();
 
         const double kk = (double)((unsigned long long)maxInliers * (unsigned long long)maxInliers);
         const double oneOverSq = 1.0 / kk;
@@ -348,7 +358,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 if (c.s_best[i])
                     c.s_cyl[c.s_list[i]] = (unsigned char)nCylLabels;
         }
-        __syncthreads();
+        CAPE_CYL_SYNC();
     }
 }
 

@@ -27,6 +27,15 @@ namespace cape {
 constexpr int kHistBins = 400;
 constexpr int kSegDoubles = 20; // LDS plane-segment record: sums[9], n, normal[3], d, centroid[3], mse, score, planar
 constexpr int kChunk = 32;      // cells staged per step of the ordered moment accumulation
+#ifndef CAPE_B_WAVES_PER_GROUP
+#define CAPE_B_WAVES_PER_GROUP 4
+#endif
+constexpr int kWavesPerGroup = CAPE_B_WAVES_PER_GROUP; // independent frames (waves) per workgroup
+// the staging buffer doubles as the centre-depth array of the boundary phase: max(kChunk*10 f64, cells f32)
+__host__ __device__ constexpr int kChunkDoubles(int cells)
+{
+    return (kChunk * kSumStride > (cells + 1) / 2) ? kChunk * kSumStride : (cells + 1) / 2;
+}
 
 // kernel-phase ablation for profiling experiments: -DCAPE_B_STOP_AT=k makes the wave leave after phase k
 #ifdef CAPE_B_STOP_AT
@@ -62,7 +71,17 @@ constexpr int kChunk = 32;      // cells staged per step of the ordered moment a
 #endif
 
 // wave-synchronous ordering point for LDS traffic between lanes of the single wave of this workgroup
-#define CAPE_WAVE_SYNC() __syncthreads()
+// A workgroup carries several INDEPENDENT waves (one frame each, own LDS slice): the hardware admits only ~8
+// workgroups per CU, so single-wave workgroups would cap the CU at 8 frames in flight.  Nothing is ever exchanged
+// between waves, hence no s_barrier anywhere: this macro is "all my earlier LDS and global accesses are complete and
+// visible to the other lanes of MY wave" = drain every counter + compiler fence.
+#define CAPE_WAVE_SYNC()                                                                                      \
+    do                                                                                                       \
+    {                                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+    } while (0)
 // LDS-only ordering point.  The workgroup is ONE wave and LDS instructions of a wave execute in issue order, so a
 // compiler-level fence is enough; unlike __syncthreads() it does not drain outstanding global loads (vmcnt), which
 // is what lets the cell-sum prefetch below stay in flight across it.
@@ -199,37 +218,44 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
     r[8] = cof(2, 2) * invdet;
 }
 
-template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_grow_kernel(StageBParams p)
+template <typename MaskT, bool CYL>
+__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int frame = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    if (frame >= nFrames)
+        return; // whole wave leaves; there is no workgroup barrier in this kernel
+    unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     const int C = p.cells, HC = p.hCells, VC = p.vCells;
     const size_t cellBase = (size_t)frame * C;
 
     // ---- LDS carve (all offsets multiples of 16)
+    // ---- LDS carve (every offset a multiple of 8; 13.4 KB for 640x480 plane-only -> 12 waves per CU)
     double* s_seg = reinterpret_cast<double*>(smem);                              // CAPE_MAX_PLANES x 20 f64
-    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // 2 x kChunk x 10 f64 staging of cell sums
-    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + 2 * kChunk * kSumStride); // 64 u64
-    int* s_hist = reinterpret_cast<int*>(s_adj + 64);                             // 400 i32
-    float* s_zc = reinterpret_cast<float*>(s_hist + kHistBins);                   // C f32 centre-pixel depth of every cell
-    short* s_bins = reinterpret_cast<short*>(s_zc + C);                           // C i16
+    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums ;
+                                                                                  // after the seed loop: centre depths
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // 32 u64
+    int* s_hist = reinterpret_cast<int*>(s_adj + CAPE_MAX_PLANES);                // 400 i32
+    short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
-    unsigned char* s_cyl = s_lab + C;                                             // C u8  cylinder labels
-    unsigned char* s_mlab = s_cyl + C;                                            // 64 u8 merge labels
-    // cylinder RANSAC scratch (carved only when CAPE_FLAG_CYLINDERS is set, see grow_lds_bytes)
-    unsigned short* s_ids = reinterpret_cast<unsigned short*>(s_mlab + 64);       // C u16 idsLeft
+    unsigned char* s_mlab = s_lab + C;                                            // 32 u8 merge labels
+    // cylinder variant only (see grow_lds_bytes)
+    unsigned char* s_cyl = s_mlab + CAPE_MAX_PLANES;                              // C u8  cylinder labels
+    unsigned short* s_ids = reinterpret_cast<unsigned short*>(s_cyl + C + (C & 1)); // C u16 idsLeft
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
-    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64 (MSAC costs)
+    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64
+    float* s_zc = reinterpret_cast<float*>(s_chunk);                              // C f32, aliases s_chunk (boundary phase)
 
     const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
 
     for (int i = lane; i < kHistBins; i += 64)
         s_hist[i] = 0;
-    for (int i = lane; i < 64; i += 64)
+    for (int i = lane; i < CAPE_MAX_PLANES; i += 64)
     {
         s_adj[i] = 0ull;
         s_mlab[i] = (unsigned char)i;
@@ -248,7 +274,8 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     {
         const uint32_t fl = p.cell_flags[cellBase + i];
         s_lab[i] = 0;
-        s_cyl[i] = 0;
+        if (CYL)
+            s_cyl[i] = 0;
         const int bin = p.cell_bins[cellBase + i]; // computed by stage A2 (acos / atan2 of the cell normal)
         if (fl & kFlagPlanar)
         {
@@ -256,7 +283,6 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
             ++nPlanarLocal;
         }
         s_bins[i] = (short)bin;
-        s_zc[i] = p.cell_aux[cellBase + i].zc;
         if (fl & kFlagNearEdge)
             status |= CAPE_FRAME_BIN_NEAR_EDGE;
         if (fl & kFlagInorder)
@@ -480,11 +506,10 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     } while (0)
             if (total > 0)
                 CAPE_ISSUE_CHUNK(0);
-            int buf = 0;
-            for (int c0 = 0; c0 < total; c0 += kChunk, buf ^= 1)
+            for (int c0 = 0; c0 < total; c0 += kChunk)
             {
                 const int cn = (total - c0 < kChunk) ? (total - c0) : kChunk;
-                double* dst = s_chunk + buf * (kChunk * kSumStride);
+                double* dst = s_chunk; // one buffer is enough: the prefetch lives in registers
                 if (e0 < cn * 5)
                     *reinterpret_cast<double2*>(dst + ci0 * kSumStride + 2 * pc0) = pre0;
                 if (e1 < cn * 5)
@@ -680,6 +705,13 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     // =========================================================================================
     // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
     // =========================================================================================
+    // centre-pixel depth of every cell (depthImage(centerY, centerX) of compute_plane_segment_boundary) into LDS
+    if (nSeg > 0)
+    {
+        for (int i = lane; i < C; i += 64)
+            s_zc[i] = p.cell_aux[cellBase + i].zc;
+    }
+    CAPE_WAVE_SYNC();
     cape_frame_record* rec = p.records + frame;
     cape_primitive_summary* sum = p.summaries + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
@@ -855,7 +887,7 @@ template <typename MaskT, bool CYL> __global__ __launch_bounds__(64) void cape_g
     for (int i = lane; i < C; i += 64)
     {
         p.plane_labels[cellBase + i] = (int32_t)s_lab[i];
-        p.cyl_labels[cellBase + i] = (int32_t)s_cyl[i];
+        p.cyl_labels[cellBase + i] = CYL ? (int32_t)s_cyl[i] : 0;
     }
     // fold the per-lane status bits
     status = wave_or_u32(status);
@@ -880,36 +912,42 @@ size_t grow_lds_bytes(int cells, bool cylinders)
 {
     size_t b = 0;
     b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
-    b += (size_t)2 * kChunk * kSumStride * 8;       // s_chunk (double buffered)
-    b += (size_t)cells * 4;                         // s_zc
-    b += (size_t)64 * 8;                            // s_adj
+    b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk / s_zc
+    b += (size_t)CAPE_MAX_PLANES * 8;               // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins
     b += (size_t)cells * 2;                         // s_list
-    b += (size_t)cells * 2;                         // s_lab + s_cyl
-    b += 64;                                        // s_mlab
+    b += (size_t)cells;                             // s_lab
+    b += CAPE_MAX_PLANES;                           // s_mlab
     if (cylinders)
-        b += (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8; // s_ids, s_idmask / s_cur / s_best, s_dist
+        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8; // s_cyl, s_ids, masks, s_dist
     return (b + 15) & ~(size_t)15;
 }
 
+int grow_waves_per_group() { return kWavesPerGroup; }
+
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
 {
-    const size_t lds = grow_lds_bytes(p.cells, (p.flags & CAPE_FLAG_CYLINDERS) != 0);
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl);
+    int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the 160 KB of LDS admit (<= kWavesPerGroup)
+    while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
+        --wpg;
+    const size_t lds = (size_t)ldsPerWave * wpg;
+    const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
     {
         if (cyl)
-            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, true>), dim3(nFrames), dim3(64), lds, stream, p);
+            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, true>), grid, block, lds, stream, p, nFrames, ldsPerWave);
         else
-            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, false>), dim3(nFrames), dim3(64), lds, stream, p);
+            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, false>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     }
     else
     {
         if (cyl)
-            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, true>), dim3(nFrames), dim3(64), lds, stream, p);
+            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, true>), grid, block, lds, stream, p, nFrames, ldsPerWave);
         else
-            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, false>), dim3(nFrames), dim3(64), lds, stream, p);
+            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, false>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     }
 }
 
