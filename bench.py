@@ -31,7 +31,7 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(unique_frames, intr, budget_s=12.0):
+def cpu_baseline(unique_frames, intr, budget_s=12.0, cylinders=False):
     """Oracle (port of the reference CPU path) on this host: 1 thread (how the reference runs it), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import concurrent.futures as cf
@@ -41,7 +41,7 @@ def cpu_baseline(unique_frames, intr, budget_s=12.0):
     import cape_oracle_py as O
 
     H, W = unique_frames.shape[1:]
-    orc = O.Oracle(W, H, cylinders=False, **intr)
+    orc = O.Oracle(W, H, cylinders=cylinders, **intr)
     orc.run_many(unique_frames[:2])  # warm-up
     t0 = time.perf_counter()
     orc.run_many(unique_frames[:8])
@@ -54,7 +54,7 @@ def cpu_baseline(unique_frames, intr, budget_s=12.0):
     dt1 = time.perf_counter() - t0
     # frame-parallel over all host cores (BASELINE.md mode B), same sample
     cores = os.cpu_count() or 1
-    oracles = [O.Oracle(W, H, cylinders=False, **intr) for _ in range(cores)]
+    oracles = [O.Oracle(W, H, cylinders=cylinders, **intr) for _ in range(cores)]
     chunks = np.array_split(sample, cores)
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as pool:
@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--scene", default="room")
+    ap.add_argument("--cylinders", action="store_true", help="planes + cylinder RANSAC (BASELINE.json configs[2], [4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
     args = ap.parse_args()
@@ -118,7 +119,7 @@ def main():
     depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()
 
-    ex = Extractor(W, H, cylinders=False, device=local_rank, max_batch=B, sub_batches=args.sub_batches, **intr)
+    ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B, sub_batches=args.sub_batches, **intr)
     stream = torch.cuda.current_stream().cuda_stream
     summ_bytes = B * SUMMARY_DTYPE.itemsize
     summ_t = None
@@ -199,7 +200,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])",
+                "workload": (f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])"
+                             if (args.scene == "room" and not args.cylinders) else
+                             f"{W}x{H} synthetic {args.scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only")),
                 "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene, "sub_batches": args.sub_batches,
                 "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
             },
@@ -213,7 +216,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(unique, intr)
+            out["cpu_baseline"] = cpu_baseline(unique, intr, cylinders=args.cylinders)
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -185,7 +185,44 @@ def tunnel(seed=0, frame=0, width=640, height=480, intr=None):
     return _finish(t, _Rng(0x74756E6E, seed, frame + 1), "mm", 0.02)
 
 
-SCENES = {"room": room, "tumlike": tumlike, "tunnel": tunnel}
+def facets(seed=0, frame=0, width=640, height=480, intr=None, n_planes=9, max_tilt=1.1):
+    """Faceted surface (lower envelope of random planes) + a few foreground slabs: creases of every angle, depth jumps.
+
+    Stress input for region growing / plane merging: neighbouring facets under and over the 18 degree merge angle,
+    facets smaller than the 4-cell activation threshold, regions that touch after being grown from different seeds,
+    low-score regions that go to the cylinder branch."""
+    s = width / 640.0
+    intr = intr or {k: v * s for k, v in DEFAULT_INTRINSICS.items()}
+    rng = _Rng(0x6661636574, seed, frame + 1)
+    u = (np.arange(width, dtype=np.float64) - intr["cx"]) / intr["fx"]
+    v = (np.arange(height, dtype=np.float64) - intr["cy"]) / intr["fy"]
+    X, Y = np.meshgrid(u, v)
+    par = rng.uniform((n_planes, 3))
+    t = np.full((height, width), np.inf)
+    for k in range(n_planes):
+        nx, ny = max_tilt * (2 * par[k, 0] - 1), max_tilt * (2 * par[k, 1] - 1)
+        d = 1800.0 + 2200.0 * par[k, 2]
+        den = 1.0 + nx * X + ny * Y  # plane: z * (1 + nx x + ny y) = d
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = d / den
+        t = np.minimum(t, np.where(den > 0.05, z, np.inf))
+    # foreground slabs: tilted rectangles in front of the envelope (depth discontinuities, small regions)
+    slab = rng.uniform((4, 7))
+    for k in range(4):
+        x0, y0 = int(slab[k, 0] * width * 0.8), int(slab[k, 1] * height * 0.8)
+        w, h = int((0.08 + 0.25 * slab[k, 2]) * width), int((0.08 + 0.25 * slab[k, 3]) * height)
+        nx, ny = 0.6 * (2 * slab[k, 4] - 1), 0.6 * (2 * slab[k, 5] - 1)
+        d = 900.0 + 700.0 * slab[k, 6]
+        den = 1.0 + nx * X + ny * Y
+        z = d / np.maximum(den, 0.05)
+        region = np.zeros_like(t, dtype=bool)
+        region[y0:y0 + h, x0:x0 + w] = True
+        t = np.where(region & (z < t), z, t)
+    t = np.where(t > 9000.0, np.inf, t)
+    return _finish(t, rng, "mm", 0.03)
+
+
+SCENES = {"room": room, "tumlike": tumlike, "tunnel": tunnel, "facets": facets}
 
 
 def stream(scene, seed, n_frames, width=640, height=480, start=0):

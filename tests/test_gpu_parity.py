@@ -346,3 +346,61 @@ def test_raw_uint16_input_path(oracle_mod):
     for f in range(len(raw)):
         compare_frame(orc.run(depth[f]), ex, res, f)
     ex.close()
+
+
+FACET_CASES = [(11, 33, True), (22, 66, True), (0, 0, True), (13, 39, True), (4, 12, False), (9, 27, False),
+               (31, 93, False), (34, 102, True)]
+
+
+def test_faceted_scenes_batch(oracle_mod):
+    """Faceted surfaces + foreground slabs: 5-9 regions per frame, failed seeds, cylinder branch, and (seeds 11, 22)
+    plane segments that merge_planes() fuses -- the one path the room / tunnel scenes never reach."""
+    from cape_amd import Extractor, synth
+
+    intr = _intr("room")
+    merges = 0
+    for cyl in (True, False):
+        cases = [c for c in FACET_CASES if c[2] == cyl]
+        frames = np.stack([synth.facets(seed=s, frame=f) for s, f, _ in cases])
+        orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=len(cases), **intr)
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        for k in range(n):
+            r = orc.run(frames[k])
+            compare_frame(r, ex, res, k)
+            merges += int((r.merge_labels != np.arange(len(r.merge_labels))).sum())
+        ex.close()
+    assert merges >= 2, "the merge path was not exercised"
+
+
+def test_random_frames_property(oracle_mod):
+    """Randomised sweep: 24 frames across all generators and random corruptions, every observable bit-exact."""
+    from cape_amd import Extractor, synth
+
+    rng = np.random.default_rng(2024)
+    names = ["room", "tumlike", "tunnel", "facets"]
+    intr = _intr("room")
+    frames = []
+    for k in range(24):
+        d = synth.SCENES[names[k % 4]](seed=int(rng.integers(0, 1000)), frame=int(rng.integers(0, 500)))
+        mode = k % 6
+        if mode == 1:
+            d[rng.random(d.shape) < 0.2] = 0
+        elif mode == 2:
+            d += (rng.standard_normal(d.shape) * 5).astype(np.float32) * (d > 0)
+        elif mode == 3:
+            y, x = int(rng.integers(0, 400)), int(rng.integers(0, 560))
+            d[y:y + 80, x:x + 80] *= np.float32(0.5)
+        elif mode == 4:
+            d = np.ascontiguousarray(d[:, ::-1])
+        frames.append(d)
+    frames = np.stack(frames)
+    for cyl in (False, True):
+        orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=len(frames), **intr)
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        for k in range(n):
+            compare_frame(orc.run(frames[k]), ex, res, k, check_cells=(not cyl))
+        ex.close()
