@@ -95,7 +95,6 @@ def main():
     import torch.distributed as dist
 
     from cape_amd import SUMMARY_DTYPE, Extractor, synth
-    from cape_amd.dist import gather_summaries
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -123,16 +122,35 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     summ_bytes = B * SUMMARY_DTYPE.itemsize
     summ_t = None
+    stage, gathered, works = None, None, [None, None]
     if use_dist:
+        # one RCCL all-gather of the 1296-B primitive lists per batch.  The lists are copied out of the library's
+        # buffer (5 MB, D2D) and gathered asynchronously, so the collective of batch k runs under the kernels of batch
+        # k+1; a staging slot is reused only after its gather has completed.
         summ_t = torch.as_tensor(_DevMem(ex.summaries_pointer(), summ_bytes), device="cuda")
+        stage = [torch.empty(summ_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gathered = [torch.empty(world * summ_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    step_no = [0]
 
     def step():
         ex.extract_device(depth.data_ptr(), B, stream)
         if use_dist:
-            return gather_summaries(summ_t, world)  # one RCCL all-gather per batch
+            k = step_no[0] & 1
+            step_no[0] += 1
+            if works[k] is not None:
+                works[k].wait()
+            stage[k].copy_(summ_t, non_blocking=True)
+            works[k] = dist.all_gather_into_tensor(gathered[k], stage[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -142,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # every gather has landed before the clock stops
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -10,13 +10,14 @@ import torch
 from cape_amd import Extractor, synth
 
 NAMES = ["hist prologue", "edge masks", "argmax+cands", "seed pick", "propagation", "list build", "ordered accum",
-         "hist removal", "region fit", "seed-loop tail", "merge", "boundary+records", "", "", "", ""]
+         "hist removal", "region fit", "seed-loop tail", "merge", "boundary+records", "cyl: cov+eigen", "cyl: projection", "cyl: RANSAC", "cyl: LLS/MSE/plane"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 scene = sys.argv[2] if len(sys.argv) > 2 else "room"
 u = synth.stream(scene, seed=100, n_frames=16)
 d = torch.from_numpy(u).cuda().repeat(B // 16, 1, 1).contiguous()
 intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
-ex = Extractor(640, 480, max_batch=B, **intr)
+cyl = len(sys.argv) > 3 and sys.argv[3] == "cyl"
+ex = Extractor(640, 480, max_batch=B, cylinders=cyl, **intr)
 ex.extract_device(d.data_ptr(), B, torch.cuda.current_stream().cuda_stream)
 cyc = ex.debug_cycles(B).astype(np.float64)
 tot = cyc.sum(1)

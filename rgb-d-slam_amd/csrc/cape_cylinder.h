@@ -15,6 +15,7 @@
 
 #include "cape_device.h"
 #include "cape_internal.h"
+#include "cape_staged.h"
 
 namespace cape {
 
@@ -27,6 +28,21 @@ namespace cape {
         __builtin_amdgcn_s_waitcnt(0);                                                                       \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
     } while (0)
+
+#ifdef CAPE_B_PROFILE
+#define CAPE_CYL_TICK(k)                                                                                     \
+    do                                                                                                       \
+    {                                                                                                        \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                                          \
+        if (lane == 0)                                                                                       \
+            c.dbg[(k)] += _n - _ct;                                                                          \
+        _ct = _n;                                                                                            \
+    } while (0)
+#define CAPE_CYL_TICK_INIT() unsigned long long _ct = __builtin_amdgcn_s_memtime()
+#else
+#define CAPE_CYL_TICK(k)
+#define CAPE_CYL_TICK_INIT()
+#endif
 
 struct CylCtx
 {
@@ -42,10 +58,12 @@ struct CylCtx
     unsigned char* s_cur;         // inliers of the current hypothesis
     unsigned char* s_best;        // finalInlierIndexes as flags
     double* scratch;              // [N][6] projected normals / projected centroids of this frame
+    double* s_stage;              // kStageChunk x 10 f64 staging buffer (cape_staged.h)
     double* s_seg;
     unsigned char* s_lab;
     unsigned char* s_cyl;
     cape_frame_record* rec;
+    unsigned long long* dbg;      // per-frame phase ticks (profiling builds)
 };
 
 __device__ __forceinline__ int cyl_wave_sum(int v)
@@ -66,6 +84,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
     const double* planeBase = p.cell_plane + c.cellBase * kPlaneStride;
     const double* sumsBase = p.cell_sums + c.cellBase * kSumStride;
 
+    CAPE_CYL_TICK_INIT();
     // ---- cov = (M * M^T) / (cols - 1), M = [normals, -normals] (cylinder_segment.cpp:47-89): ascending column order
     double cov6;
     {
@@ -76,11 +95,10 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         double acc = 0.0;
         for (int half = 0; half < 2; ++half)
         {
-            for (int k = 0; k < N; ++k)
-            {
-                const double* pl = planeBase + (size_t)c.s_list[k] * kPlaneStride;
-                acc += pl[r] * pl[cc]; // (-a)*(-b) == a*b bit for bit in the second half
-            }
+            // records: (nx, ny, nz, d) of every activated cell, staged through LDS (2 pieces of cell_plane)
+            staged_for_each<2>(
+                    N, planeBase, kPlaneStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
+                    [&](int, const double* rec) { acc += rec[r] * rec[cc]; }); // (-a)*(-b) == a*b in the second half
         }
         cov6 = acc / (double)(2 * N - 1);
     }
@@ -89,6 +107,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
     Eig3 eg;
     self_adjoint_eigen3(m00, m10, m11, m20, m21, m22, eg);
     const double score = eg.val[2] / eg.val[0];
+    CAPE_CYL_TICK(12); // covariance + eigen
     if (score < (double)75.0f) // cylinderRansacMinimumScore, checkpoint 1 (:95-102)
         return;
     const double ax = eg.q[0][0], ay = eg.q[1][0], az = eg.q[2][0];
@@ -114,6 +133,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
     }
     CAPE_CYL_SYNC();
 
+    CAPE_CYL_TICK(13); // projection
     int planeSegmentsLeft = N;
     int idsLeftCount = N;
     const float maxSqrtDistF = 0.04f; // cylinderRansacSqrtMaxDistance
@@ -215,6 +235,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     break;
             }
         }
+        CAPE_CYL_TICK(14); // RANSAC iterations
         // checkpoint 2
         if (bestCount < 6)
             break;
@@ -222,26 +243,25 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
 
         // ===== LLS over all inliers, ascending i (:157-186): lanes 0-2 sumN, 3-5 sumC, 6 b
         double chain = 0.0;
-        for (int i = 0; i < N; ++i)
-        {
-            if (c.s_best[i])
-            {
-                const double* t = c.scratch + (size_t)i * 6;
-                const double v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3], v4 = t[4], v5 = t[5];
-                double v;
-                switch (lane)
-                {
-                case 0: v = v0; break;
-                case 1: v = v1; break;
-                case 2: v = v2; break;
-                case 3: v = v3; break;
-                case 4: v = v4; break;
-                case 5: v = v5; break;
-                default: v = (v0 * v3 + v1 * v4) + v2 * v5; break;
-                }
-                chain += v;
-            }
-        }
+        staged_for_each<3>(
+                N, c.scratch, 6, 0, [&](int e) { return e; }, c.s_stage, lane, [&](int i, const double* t) {
+                    if (c.s_best[i])
+                    {
+                        const double v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3], v4 = t[4], v5 = t[5];
+                        double v;
+                        switch (lane)
+                        {
+                        case 0: v = v0; break;
+                        case 1: v = v1; break;
+                        case 2: v = v2; break;
+                        case 3: v = v3; break;
+                        case 4: v = v4; break;
+                        case 5: v = v5; break;
+                        default: v = (v0 * v3 + v1 * v4) + v2 * v5; break;
+                        }
+                        chain += v;
+                    }
+                });
         const double sNx = __shfl(chain, 0), sNy = __shfl(chain, 1), sNz = __shfl(chain, 2);
         const double sCx = __shfl(chain, 3), sCy = __shfl(chain, 4), sCz = __shfl(chain, 5);
         double b = __shfl(chain, 6);
@@ -283,27 +303,31 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double dx = P2x - ctx, dy = P2y - cty, dz = P2z - ctz;
         const double P1P2d = sqrt((dx * dx + dy * dy) + dz * dz);
         double mse = 0.0;
-        for (int i = 0; i < N; ++i)
-        {
-            if (c.s_best[i])
-            {
-                const double* pl = planeBase + (size_t)c.s_list[i] * kPlaneStride;
-                const double wx = pl[4] - P2x, wy = pl[5] - P2y, wz = pl[6] - P2z;
-                const double crx = dy * wz - dz * wy;
-                const double cry = dz * wx - dx * wz;
-                const double crz = dx * wy - dy * wx;
-                const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
-                mse += t * t;
-            }
-        }
+        // records: (cx, cy, cz, mse) = pieces 2..3 of cell_plane
+        staged_for_each<2>(
+                N, planeBase, kPlaneStride, 2, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
+                [&](int i, const double* pl) {
+                    if (c.s_best[i])
+                    {
+                        const double wx = pl[0] - P2x, wy = pl[1] - P2y, wz = pl[2] - P2z;
+                        const double crx = dy * wz - dz * wy;
+                        const double cry = dz * wx - dx * wz;
+                        const double crz = dx * wy - dy * wx;
+                        const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
+                        mse += t * t;
+                    }
+                });
         mse /= (double)maxInliers;
 
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
         const int ql = lane < 10 ? lane : 0;
         double acc = 0.0; // Plane_Segment newMergedPlane: cleared sums
-        for (int i = 0; i < N; ++i)
-            if (c.s_best[i])
-                acc += sumsBase[(size_t)c.s_list[i] * kSumStride + ql];
+        staged_for_each<5>(
+                N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
+                [&](int i, const double* rec) {
+                    if (c.s_best[i])
+                        acc += rec[ql];
+                });
         double S[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -359,6 +383,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     c.s_cyl[c.s_list[i]] = (unsigned char)nCylLabels;
         }
         CAPE_CYL_SYNC();
+        CAPE_CYL_TICK(15); // LLS + MSE + merged plane + labels
     }
 }
 

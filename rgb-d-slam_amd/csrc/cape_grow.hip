@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cape_cylinder.h"
+#include "cape_staged.h"
 #include "cape_device.h"
 #include "cape_internal.h"
 
@@ -26,7 +27,7 @@ namespace cape {
 
 constexpr int kHistBins = 400;
 constexpr int kSegDoubles = 20; // LDS plane-segment record: sums[9], n, normal[3], d, centroid[3], mse, score, planar
-constexpr int kChunk = 32;      // cells staged per step of the ordered moment accumulation
+constexpr int kChunk = kStageChunk; // cells staged per step of the ordered moment accumulation (cape_staged.h)
 #ifndef CAPE_B_WAVES_PER_GROUP
 #define CAPE_B_WAVES_PER_GROUP 4
 #endif
@@ -483,57 +484,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
         CAPE_TICK(5); // list build
         const int ql = lane < 10 ? lane : 0;
         double acc = sumsBase[(size_t)seed * kSumStride + ql];
-        {
-            // all lanes stage kChunk cells x 10 f64 per step (coalesced 16-B pieces: 160 pieces = 2.5 per lane) through
-            // registers into one of two LDS buffers; the next chunk's loads are in flight while lanes 0..9 add the
-            // current chunk in order
-            // lane l owns pieces e = l, l+64, l+128 of a chunk (piece = 16 B = 2 of the 10 f64 of a cell)
-            const int e0 = lane, e1 = lane + 64, e2 = lane + 128;
-            const int ci0 = e0 / 5, pc0 = e0 - ci0 * 5;
-            const int ci1 = e1 / 5, pc1 = e1 - ci1 * 5;
-            const int ci2 = e2 / 5, pc2 = e2 - ci2 * 5;
-            double2 pre0 = make_double2(0, 0), pre1 = pre0, pre2 = pre0;
-#define CAPE_ISSUE_CHUNK(c0_)                                                                                          \
-    do                                                                                                               \
-    {                                                                                                                \
-        const int cn_ = (total - (c0_) < kChunk) ? (total - (c0_)) : kChunk;                                         \
-        if (e0 < cn_ * 5)                                                                                            \
-            pre0 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci0] * kSumStride + 2 * pc0); \
-        if (e1 < cn_ * 5)                                                                                            \
-            pre1 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci1] * kSumStride + 2 * pc1); \
-        if (e2 < cn_ * 5)                                                                                            \
-            pre2 = *reinterpret_cast<const double2*>(sumsBase + (size_t)s_list[(c0_) + ci2] * kSumStride + 2 * pc2); \
-    } while (0)
-            if (total > 0)
-                CAPE_ISSUE_CHUNK(0);
-            for (int c0 = 0; c0 < total; c0 += kChunk)
-            {
-                const int cn = (total - c0 < kChunk) ? (total - c0) : kChunk;
-                double* dst = s_chunk; // one buffer is enough: the prefetch lives in registers
-                if (e0 < cn * 5)
-                    *reinterpret_cast<double2*>(dst + ci0 * kSumStride + 2 * pc0) = pre0;
-                if (e1 < cn * 5)
-                    *reinterpret_cast<double2*>(dst + ci1 * kSumStride + 2 * pc1) = pre1;
-                if (e2 < cn * 5)
-                    *reinterpret_cast<double2*>(dst + ci2 * kSumStride + 2 * pc2) = pre2;
-                if (c0 + kChunk < total)
-                    CAPE_ISSUE_CHUNK(c0 + kChunk);
-                CAPE_LDS_SYNC();
-                if (cn == kChunk)
-                {
-#pragma unroll
-                    for (int ci = 0; ci < kChunk; ++ci)
-                        acc += dst[ci * kSumStride + ql];
-                }
-                else
-                {
-                    for (int ci = 0; ci < cn; ++ci)
-                        acc += dst[ci * kSumStride + ql];
-                }
-                CAPE_LDS_SYNC();
-            }
-#undef CAPE_ISSUE_CHUNK
-        }
+        staged_for_each<5>(
+                total, sumsBase, kSumStride, 0, [&](int e) { return (int)s_list[e]; }, s_chunk, lane,
+                [&](int, const double* rec) { acc += rec[ql]; });
 
         CAPE_TICK(6); // ordered accumulation
         // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
@@ -610,14 +563,17 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
             cc.s_cur = s_cur;
             cc.s_best = s_best;
             cc.scratch = p.cylScratch + cellBase * 6;
+            cc.s_stage = s_chunk;
             cc.s_seg = s_seg;
             cc.s_lab = s_lab;
             cc.s_cyl = s_cyl;
             cc.rec = p.records + frame;
+            cc.dbg = p.debugCycles + (size_t)frame * 16;
             bool planeOverflow = false;
             cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
             ++nCylFits;
             CAPE_WAVE_SYNC();
+            CAPE_TICK(8); // (cylinder phases are booked in slots 12..15)
             if (planeOverflow)
             {
                 status |= CAPE_FRAME_PLANE_OVERFLOW;
