@@ -1,0 +1,371 @@
+#include "boundary_polygon.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+
+namespace rgbd_slam::utils {
+
+namespace {
+
+inline double dot(const vector3& a, const vector3& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline vector3 cross(const vector3& a, const vector3& b)
+{
+    return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+}
+inline double norm(const vector3& a) { return std::sqrt(dot(a, a)); }
+inline vector3 normalized(const vector3& a)
+{
+    const double n = norm(a);
+    return n > 0 ? vector3 {a[0] / n, a[1] / n, a[2] / n} : a;
+}
+inline bool double_equal(double a, double b, double eps = std::numeric_limits<double>::epsilon()) { return std::abs(a - b) <= eps; }
+
+// select_correct_transform, polygon.cpp:50-68
+vector3 select_correct_transform(const vector3& normal)
+{
+    const double distX = std::abs(normal[0]), distY = std::abs(normal[1]), distZ = std::abs(normal[2]);
+    const double res = std::min(distX, std::min(distY, distZ));
+    if (double_equal(res, distX, 0.1))
+        return {1, 0, 0};
+    if (double_equal(res, distY, 0.1))
+        return {0, 1, 0};
+    if (double_equal(res, distZ, 0.1))
+        return {0, 0, 1};
+    return normalized({normal[2], normal[0], normal[1]});
+}
+
+inline double cross2(const vector2& o, const vector2& a, const vector2& b)
+{
+    return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);
+}
+
+// proper or touching intersection of the open segments (a1,a2) and (b1,b2); shared endpoints do not count
+bool segments_intersect(const vector2& a1, const vector2& a2, const vector2& b1, const vector2& b2)
+{
+    auto same = [](const vector2& p, const vector2& q) { return p[0] == q[0] && p[1] == q[1]; };
+    if (same(a1, b1) || same(a1, b2) || same(a2, b1) || same(a2, b2))
+        return false;
+    const double d1 = cross2(b1, b2, a1), d2 = cross2(b1, b2, a2), d3 = cross2(a1, a2, b1), d4 = cross2(a1, a2, b2);
+    if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0)))
+        return true;
+    auto on = [](const vector2& p, const vector2& q, const vector2& r) {
+        return std::min(p[0], q[0]) <= r[0] && r[0] <= std::max(p[0], q[0]) && std::min(p[1], q[1]) <= r[1] &&
+               r[1] <= std::max(p[1], q[1]);
+    };
+    if (d1 == 0 && on(b1, b2, a1)) return true;
+    if (d2 == 0 && on(b1, b2, a2)) return true;
+    if (d3 == 0 && on(a1, a2, b1)) return true;
+    if (d4 == 0 && on(a1, a2, b2)) return true;
+    return false;
+}
+
+// crossing-number test; points on the boundary count as inside when `closed`
+bool point_in_ring(const vector2& p, const std::vector<vector2>& ring, bool closed)
+{
+    const size_t n = ring.size();
+    bool inside = false;
+    for (size_t i = 0, j = n - 1; i < n; j = i++)
+    {
+        const vector2 &a = ring[i], &b = ring[j];
+        if (cross2(a, b, p) == 0 && std::min(a[0], b[0]) <= p[0] && p[0] <= std::max(a[0], b[0]) &&
+            std::min(a[1], b[1]) <= p[1] && p[1] <= std::max(a[1], b[1]))
+            return closed;
+        if (((a[1] > p[1]) != (b[1] > p[1])) && (p[0] < (b[0] - a[0]) * (p[1] - a[1]) / (b[1] - a[1]) + a[0]))
+            inside = !inside;
+    }
+    return inside;
+}
+
+double ring_area_signed(const std::vector<vector2>& r)
+{
+    double s = 0;
+    for (size_t i = 0, j = r.size() - 1; i < r.size(); j = i++)
+        s += (r[j][0] * r[i][1] - r[i][0] * r[j][1]);
+    return 0.5 * s;
+}
+
+// One run of the Moreira-Santos k-nearest-neighbours concave hull; false if no simple hull exists for this k.
+bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vector2>& hull)
+{
+    const size_t n = pts.size();
+    hull.clear();
+    if (n < 3)
+        return false;
+    if (n == 3)
+    {
+        hull = pts;
+        return true;
+    }
+    k = std::min(std::max<size_t>(k, 3), n - 1);
+    std::vector<char> used(n, 0);
+    size_t first = 0;
+    for (size_t i = 1; i < n; ++i)
+        if (pts[i][1] < pts[first][1] || (pts[i][1] == pts[first][1] && pts[i][0] < pts[first][0]))
+            first = i;
+    std::vector<size_t> h {first};
+    used[first] = 1;
+    size_t current = first;
+    double prevAngle = M_PI; // walking direction so far: pointing west, the first turn is taken clockwise from it
+    size_t step = 1;
+    size_t remaining = n - 1;
+    while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
+    {
+        if (step == 4)
+            used[first] = 0; // the start point becomes reachable again once the hull has three edges
+        // k nearest unused neighbours of the current point
+        std::vector<std::pair<double, size_t>> cand;
+        for (size_t i = 0; i < n; ++i)
+            if (!used[i] && i != current)
+            {
+                const double dx = pts[i][0] - pts[current][0], dy = pts[i][1] - pts[current][1];
+                cand.emplace_back(dx * dx + dy * dy, i);
+            }
+        if (cand.empty())
+            break;
+        const size_t kk = std::min(k, cand.size());
+        std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
+        cand.resize(kk);
+        // order by the largest right-hand turn relative to the previous edge
+        std::vector<std::pair<double, size_t>> byTurn;
+        for (const auto& c : cand)
+        {
+            const double ang = std::atan2(pts[c.second][1] - pts[current][1], pts[c.second][0] - pts[current][0]);
+            double turn = prevAngle - ang; // clockwise turn from the direction we came from
+            while (turn < 0) turn += 2 * M_PI;
+            while (turn >= 2 * M_PI) turn -= 2 * M_PI;
+            byTurn.emplace_back(turn, c.second);
+        }
+        std::sort(byTurn.begin(), byTurn.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        bool found = false;
+        size_t next = 0;
+        for (const auto& c : byTurn)
+        {
+            const size_t cnd = c.second;
+            bool its = false;
+            const size_t last = (cnd == first) ? 1 : 0;
+            for (size_t j = last; j + 2 < h.size() + 1 && !its; ++j)
+            {
+                if (j + 1 >= h.size())
+                    break;
+                if (j + 1 == h.size() - 1)
+                    continue; // the edge that ends at the current point shares it with the candidate edge
+                its = segments_intersect(pts[current], pts[cnd], pts[h[j]], pts[h[j + 1]]);
+            }
+            if (!its)
+            {
+                found = true;
+                next = cnd;
+                break;
+            }
+        }
+        if (!found)
+            return false;
+        if (next == first)
+        {
+            current = first;
+            break;
+        }
+        prevAngle = std::atan2(pts[current][1] - pts[next][1], pts[current][0] - pts[next][0]); // looking back
+        current = next;
+        h.push_back(current);
+        used[current] = 1;
+        --remaining;
+        ++step;
+    }
+    if (current != first || h.size() < 3)
+        return false;
+    hull.reserve(h.size());
+    for (size_t i : h)
+        hull.push_back(pts[i]);
+    // every input point must lie inside or on the hull
+    for (size_t i = 0; i < n; ++i)
+        if (!used[i] && !point_in_ring(pts[i], hull, true))
+            return false;
+    return true;
+}
+
+void douglas_peucker(const std::vector<vector2>& in, size_t a, size_t b, double eps, std::vector<char>& keep)
+{
+    if (b <= a + 1)
+        return;
+    double dmax = -1;
+    size_t idx = a;
+    const double dx = in[b][0] - in[a][0], dy = in[b][1] - in[a][1];
+    const double len = std::sqrt(dx * dx + dy * dy);
+    for (size_t i = a + 1; i < b; ++i)
+    {
+        double d;
+        if (len == 0)
+            d = std::hypot(in[i][0] - in[a][0], in[i][1] - in[a][1]);
+        else
+            d = std::abs(dx * (in[a][1] - in[i][1]) - (in[a][0] - in[i][0]) * dy) / len;
+        if (d > dmax)
+        {
+            dmax = d;
+            idx = i;
+        }
+    }
+    if (dmax > eps)
+    {
+        keep[idx] = 1;
+        douglas_peucker(in, a, idx, eps, keep);
+        douglas_peucker(in, idx, b, eps, keep);
+    }
+}
+
+bool ring_is_simple(const std::vector<vector2>& r)
+{
+    const size_t n = r.size();
+    if (n < 3)
+        return false;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+        {
+            if (j == i + 1 || (i == 0 && j == n - 1))
+                continue; // adjacent edges share a vertex
+            if (segments_intersect(r[i], r[(i + 1) % n], r[j], r[(j + 1) % n]))
+                return false;
+        }
+    return std::abs(ring_area_signed(r)) > 0;
+}
+
+} // namespace
+
+std::pair<vector3, vector3> get_plane_coordinate_system(const vector3& normal)
+{
+    if (!double_equal(norm(normal), 1.0, 1e-9))
+        throw std::invalid_argument("get_plane_coordinate_system: The normal should have a norm of 1");
+    const vector3 r = select_correct_transform(normal);
+    const vector3 xAxis = normalized(cross(normal, r));
+    const vector3 yAxis = normalized(cross(normal, xAxis));
+    return {xAxis, yAxis};
+}
+
+vector2 get_projected_plan_coordinates(const vector3& p, const vector3& c, const vector3& xAxis, const vector3& yAxis)
+{
+    const vector3 d {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    return {dot(xAxis, d), dot(yAxis, d)};
+}
+
+vector3 get_point_from_plane_coordinates(const vector2& p, const vector3& c, const vector3& xAxis, const vector3& yAxis)
+{
+    return {c[0] + p[0] * xAxis[0] + p[1] * yAxis[0], c[1] + p[0] * xAxis[1] + p[1] * yAxis[1],
+            c[2] + p[0] * xAxis[2] + p[1] * yAxis[2]};
+}
+
+std::vector<vector2> Polygon::compute_convex_hull(const std::vector<vector2>& in) noexcept
+{
+    std::vector<vector2> p = in;
+    std::sort(p.begin(), p.end());
+    p.erase(std::unique(p.begin(), p.end()), p.end());
+    if (p.size() < 3)
+        return p;
+    std::vector<vector2> h(2 * p.size());
+    size_t k = 0;
+    for (size_t i = 0; i < p.size(); ++i)
+    {
+        while (k >= 2 && cross2(h[k - 2], h[k - 1], p[i]) <= 0) k--;
+        h[k++] = p[i];
+    }
+    for (size_t i = p.size() - 1, t = k + 1; i > 0; --i)
+    {
+        while (k >= t && cross2(h[k - 2], h[k - 1], p[i - 1]) <= 0) k--;
+        h[k++] = p[i - 1];
+    }
+    h.resize(k - 1);
+    std::reverse(h.begin(), h.end()); // clockwise like boost's default polygon
+    return h;
+}
+
+std::vector<vector2> Polygon::compute_concave_hull(const std::vector<vector2>& in) noexcept
+{
+    std::vector<vector2> pts = in;
+    std::sort(pts.begin(), pts.end());
+    pts.erase(std::unique(pts.begin(), pts.end()), pts.end()); // RemoveDuplicates
+    std::vector<vector2> hull;
+    if (pts.size() < 3)
+        return hull;
+    // third_party/concave_fitting.cpp: k = 3, then the prime ladder, at most 8 attempts
+    static const size_t ladder[] = {3, 3, 5, 7, 11, 13, 17, 21};
+    for (size_t k : ladder)
+    {
+        if (concave_hull_k(pts, k, hull) && ring_is_simple(hull))
+        {
+            if (ring_area_signed(hull) > 0)
+                std::reverse(hull.begin(), hull.end());
+            return hull;
+        }
+        if (k > pts.size())
+            break;
+    }
+    hull.clear();
+    return hull;
+}
+
+Polygon::Polygon(const std::vector<vector3>& points, const vector3& normal, const vector3& center) : _center(center)
+{
+    if (!double_equal(norm(normal), 1.0, 1e-9))
+        throw std::invalid_argument("Polygon: normal norm should be 1");
+    if (points.size() < 3)
+        throw std::invalid_argument("Polygon: need at least 3 points to fit a polygon");
+    const auto axes = get_plane_coordinate_system(normal);
+    _xAxis = axes.first;
+    _yAxis = axes.second;
+    std::vector<vector2> projected;
+    projected.reserve(points.size());
+    for (auto it = points.rbegin(); it != points.rend(); ++it) // the reference projects in reverse order
+        projected.push_back(get_projected_plan_coordinates(*it, _center, _xAxis, _yAxis));
+    _ring = compute_concave_hull(projected);
+    if (!is_valid())
+        _ring = compute_convex_hull(projected); // the reference first tries boost's `correct`, then this fallback
+    _area = area();
+    simplify();
+}
+
+bool Polygon::is_valid() const noexcept { return ring_is_simple(_ring); }
+
+double Polygon::area() const noexcept { return _ring.size() < 3 ? 0.0 : std::abs(ring_area_signed(_ring)); }
+
+bool Polygon::contains(const vector2& point) const noexcept { return _ring.size() >= 3 && point_in_ring(point, _ring, false); }
+
+vector3 Polygon::get_normal() const noexcept { return cross(_xAxis, _yAxis); }
+
+std::vector<vector3> Polygon::get_unprojected_boundary() const
+{
+    std::vector<vector3> out;
+    out.reserve(_ring.size());
+    for (const vector2& p : _ring)
+        out.push_back(get_point_from_plane_coordinates(p, _center, _xAxis, _yAxis));
+    return out;
+}
+
+void Polygon::simplify(const double distanceThreshold) noexcept
+{
+    _area = area();
+    if (_ring.size() < 4)
+        return;
+    const double eps = std::max(_area / 1e5, distanceThreshold);
+    // closed ring: run Douglas-Peucker on the ring opened at vertex 0 and closed back onto it
+    std::vector<vector2> closed = _ring;
+    closed.push_back(_ring.front());
+    std::vector<char> keep(closed.size(), 0);
+    keep.front() = keep.back() = 1;
+    douglas_peucker(closed, 0, closed.size() - 1, eps, keep);
+    std::vector<vector2> out;
+    for (size_t i = 0; i + 1 < closed.size(); ++i)
+        if (keep[i])
+            out.push_back(closed[i]);
+    if (ring_is_simple(out))
+    {
+        const double newArea = std::abs(ring_area_signed(out));
+        if (newArea > _area * 0.75) // "check that the area is not too reduced" (polygon.cpp:592-598)
+        {
+            _area = newArea;
+            _ring = out;
+        }
+    }
+}
+
+} // namespace rgbd_slam::utils

@@ -1,0 +1,59 @@
+// Host-side boundary polygon of a plane ("next" row N1 of SURVEY.md 8f): the step that follows the boundary candidate
+// points of compute_plane_segment_boundary in the reference (primitive_detection.cpp:622):
+//   utils::Polygon(points, normal, center)   reference src/utils/polygon.cpp:168-229
+//     get_plane_coordinate_system            :74-115   (select_correct_transform :50-68)
+//     get_projected_plan_coordinates         :125-144
+//     compute_concave_hull                   :283-318  -> third_party/concave_fitting.cpp (Moreira-Santos k-nearest
+//                                             neighbours hull, k = 3,3,5,7,11,13,17,21)
+//     compute_convex_hull fallback           :268-281
+//     area / contains / simplify             :453-461, :320-323, :578-601
+// Dependency-free (the reference uses Boost.Geometry + FLANN).  The polygon's VERTICES are not a parity target -- the
+// reference feeds the hull a nondeterministically ordered point list through randomized kd-trees -- its validity,
+// area and containment are (reference tests/test_polygons.cpp:6-89), and tests/host/test_polygon.cpp checks those.
+#pragma once
+#include <array>
+#include <cstddef>
+#include <utility>
+#include <vector>
+
+namespace rgbd_slam::utils {
+
+using vector2 = std::array<double, 2>;
+using vector3 = std::array<double, 3>;
+
+// get_plane_coordinate_system (polygon.cpp:74-115): two unit vectors spanning the plane of `normal`
+std::pair<vector3, vector3> get_plane_coordinate_system(const vector3& normal);
+vector2 get_projected_plan_coordinates(const vector3& point, const vector3& center, const vector3& xAxis, const vector3& yAxis);
+vector3 get_point_from_plane_coordinates(const vector2& point, const vector3& center, const vector3& xAxis, const vector3& yAxis);
+
+class Polygon
+{
+  public:
+    Polygon() = default;
+    // throws std::invalid_argument like the reference (normal not unit / fewer than 3 points)
+    Polygon(const std::vector<vector3>& points, const vector3& normal, const vector3& center);
+
+    [[nodiscard]] bool is_valid() const noexcept;               // simple (non self-intersecting) ring of >= 3 vertices
+    [[nodiscard]] size_t boundary_length() const noexcept { return _ring.size(); }
+    [[nodiscard]] double area() const noexcept;                 // shoelace, >= 0
+    [[nodiscard]] double get_area() const noexcept { return _area; }
+    [[nodiscard]] bool contains(const vector2& point) const noexcept; // strictly inside (boost::geometry::within)
+    [[nodiscard]] vector3 get_center() const noexcept { return _center; }
+    [[nodiscard]] vector3 get_x_axis() const noexcept { return _xAxis; }
+    [[nodiscard]] vector3 get_y_axis() const noexcept { return _yAxis; }
+    [[nodiscard]] vector3 get_normal() const noexcept;          // xAxis x yAxis
+    [[nodiscard]] const std::vector<vector2>& boundary() const noexcept { return _ring; }
+    [[nodiscard]] std::vector<vector3> get_unprojected_boundary() const;
+
+    void simplify(double distanceThreshold = 10) noexcept;      // Douglas-Peucker, threshold max(area/1e5, distanceThreshold)
+
+    static std::vector<vector2> compute_concave_hull(const std::vector<vector2>& points) noexcept;
+    static std::vector<vector2> compute_convex_hull(const std::vector<vector2>& points) noexcept;
+
+  private:
+    std::vector<vector2> _ring; // open ring (first vertex not repeated), clockwise like the reference
+    vector3 _center {0, 0, 0}, _xAxis {1, 0, 0}, _yAxis {0, 1, 0};
+    double _area = 0.0;
+};
+
+} // namespace rgbd_slam::utils

@@ -3,6 +3,7 @@
 #include "primitives_shim.hpp"
 
 #include <chrono>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <mutex>
@@ -56,6 +57,18 @@ Plane::Plane(const cape_plane_segment& seg, const double* pts) noexcept :
     _boundaryPoints.reserve(seg.boundary_count);
     for (uint32_t i = 0; i < seg.boundary_count; ++i)
         _boundaryPoints.push_back({pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]});
+    // const CameraPolygon polygon(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center()),
+    // primitive_detection.cpp:622 -- note the SEGMENT's normal / centre, not the re-normalised Plane normal
+    try
+    {
+        const utils::vector3 n {seg.normal[0], seg.normal[1], seg.normal[2]};
+        const utils::vector3 c {seg.normal[0] * (-seg.d), seg.normal[1] * (-seg.d), seg.normal[2] * (-seg.d)};
+        _boundaryPolygon = utils::Polygon(_boundaryPoints, n, c);
+    }
+    catch (const std::exception&)
+    {
+        _boundaryPolygon = utils::Polygon();
+    }
 }
 
 bool Plane::is_normal_similar(const Plane& p) const noexcept
@@ -141,8 +154,14 @@ void Primitive_Detection::collect(int f, plane_container& planes, cylinder_conta
     for (int i = 0; i < r.header.n_plane_segments; ++i)
     {
         const cape_plane_segment& s = r.segments[i];
-        if (s.is_output)
-            planes.emplace_back(s, bnd + static_cast<size_t>(s.boundary_offset) * 3);
+        if (!s.is_output)
+            continue;
+        Plane plane(s, bnd + static_cast<size_t>(s.boundary_offset) * 3);
+        // primitive_detection.cpp:624-632: keep the plane only if its polygon is valid and has >= 3 edges
+        if (plane.get_boundary_polygon().is_valid() && plane.get_boundary_polygon().boundary_length() >= 3)
+            planes.push_back(std::move(plane));
+        else
+            log(2, "Polyfit error: invalid boundary polygon, rejecting plane segment");
     }
     cylinders.reserve(r.header.n_cylinders);
     for (int i = 0; i < r.header.n_cylinder_labels; ++i)

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/cape_hip.h"
+#include "boundary_polygon.hpp"
 
 #if defined(__has_include)
 #if __has_include(<Eigen/Dense>) && __has_include(<opencv2/core.hpp>)
@@ -56,8 +57,9 @@ struct DepthImageView
     size_t step = 0; // elements per row (>= cols)
 };
 
-// Plane, shape_primitives.hpp:73-126.  The boundary polygon of the reference (CameraPolygon, Boost.Geometry) is the
-// "next" row N1 of SURVEY.md 8(f); the plane carries the boundary candidate points the polygon is fitted to.
+// Plane, shape_primitives.hpp:73-126.  The boundary polygon (reference: CameraPolygon over Boost.Geometry + FLANN,
+// primitive_detection.cpp:622) is built on the host by boundary_polygon.{hpp,cpp} ("next" row N1 of SURVEY.md 8f)
+// from the boundary candidate points the device emits.
 class Plane
 {
   public:
@@ -72,6 +74,7 @@ class Plane
     [[nodiscard]] vector3 get_center() const noexcept { return {_normal[0] * (-_d), _normal[1] * (-_d), _normal[2] * (-_d)}; }
     [[nodiscard]] matrix33 get_point_cloud_covariance() const noexcept { return _pointCloudCovariance; }
     [[nodiscard]] const std::vector<vector3>& get_boundary_points() const noexcept { return _boundaryPoints; }
+    [[nodiscard]] const utils::Polygon& get_boundary_polygon() const noexcept { return _boundaryPolygon; }
     // shape_primitives.cpp:66-86 (20 degrees, 100 mm; parameters.hpp:92-95)
     [[nodiscard]] bool is_normal_similar(const Plane& prim) const noexcept;
     [[nodiscard]] bool is_distance_similar(const Plane& prim) const noexcept;
@@ -81,6 +84,7 @@ class Plane
     double _d;
     matrix33 _pointCloudCovariance;
     std::vector<vector3> _boundaryPoints;
+    utils::Polygon _boundaryPolygon;
 };
 
 // Cylinder, shape_primitives.hpp:31-68 (public data members as in the reference)

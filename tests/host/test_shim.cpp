@@ -35,7 +35,8 @@ int main(int argc, char** argv)
     for (const Plane& p : planes)
     {
         const auto n = p.get_normal();
-        std::printf("P %a %a %a %a %zu\n", n[0], n[1], n[2], p.get_d(), p.get_boundary_points().size());
+        std::printf("P %a %a %a %a %zu %zu %.3f\n", n[0], n[1], n[2], p.get_d(), p.get_boundary_points().size(),
+                    p.get_boundary_polygon().boundary_length(), p.get_boundary_polygon().get_area());
     }
     for (const Cylinder& c : cylinders)
         std::printf("C %a %a %a\n", c._normal[0], c._normal[1], c._normal[2]);

@@ -31,6 +31,8 @@ def test_shim_matches_oracle(oracle_mod, tmp_path, scene, seed, frame):
         vals = np.array([float.fromhex(v) for v in p[:4]])
         assert np.array_equal(vals.view(np.uint64), np.ascontiguousarray(r.planes[k, 0:4]).view(np.uint64))
         assert int(p[4]) == len(r.boundary[k])
+        # N1: the host-side boundary polygon is a valid ring spanning the candidate points (area in mm^2)
+        assert 3 <= int(p[5]) <= len(r.boundary[k]) and float(p[6]) > 1e4
     Cc = [ln.split()[1:] for ln in lines if ln.startswith("C ")]
     for k, c in enumerate(Cc):
         vals = np.array([float.fromhex(v) for v in c])
