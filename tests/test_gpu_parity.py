@@ -404,3 +404,35 @@ def test_random_frames_property(oracle_mod):
         for k in range(n):
             compare_frame(orc.run(frames[k]), ex, res, k, check_cells=(not cyl))
         ex.close()
+
+
+def test_pathological_values_terminate_and_match_labels(oracle_mod):
+    """+inf / NaN / denormal / 1e30 depths: both paths terminate; integer observables still agree (float payloads of
+    NaN sums are not compared)."""
+    from cape_amd import Extractor, synth
+
+    d = synth.room(seed=6, frame=2)
+    a = d.copy()
+    a[40:60, 100:140] = np.inf
+    a[200:220, 300:340] = np.nan
+    a[300:320, 20:60] = 1e-42      # denormal
+    a[400:420, 500:540] = 1e30
+    a[100:120, 400:440] = -np.inf
+    b = np.full_like(d, np.inf)
+    c = np.full_like(d, np.nan)
+    frames = np.stack([a, b, c])
+    intr = _intr("room")
+    for cyl in (False, True):
+        orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=3, **intr)
+        ex.extract_host(frames)
+        res = ex.results(3)
+        for f in range(3):
+            r = orc.run(frames[f])
+            cs = ex.cell_stats(f)
+            assert np.array_equal(cs["planar"], r.planar)
+            assert np.array_equal(cs["point_count"], r.n)
+            assert np.array_equal(res.plane_labels[f], r.plane_labels)
+            assert np.array_equal(res.cyl_labels[f], r.cyl_labels)
+            assert res.records["header"]["n_plane_segments"][f] == len(r.segments)
+        ex.close()
