@@ -207,6 +207,15 @@ int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* 
  * bytes read per frame ("next" row N4 of SURVEY.md 8f). */
 int cape_extract_u16(cape_handle h, const uint16_t* depth_dev, float scale, int32_t n_frames, void* stream);
 
+/* "Next" row N3: Depth_Map_Transformation::rectify_depth (depth_map_transformation.hpp:29, .cpp:23-87) for a batch --
+ * registers the depth camera's image to the colour camera.  `cam2_to_cam1` is the row-major 4x4 matrix
+ * Parameters::get_camera_2_to_camera_1_transformation() (host pointer, 16 doubles; the last row is ignored).  Both
+ * images are device pointers, n_frames x H x W float32, not in place.  Collisions keep the last source pixel in
+ * row-major order, which is what the reference's MAKE_DETERMINISTIC loop does.  The intrinsics are the handle's
+ * (the reference also uses camera 1's for both directions, depth_map_transformation.cpp:156 / point_coordinates.cpp:90). */
+int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_dev, int32_t n_frames,
+                       const double* cam2_to_cam1, void* stream);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

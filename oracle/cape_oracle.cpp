@@ -988,6 +988,41 @@ static void init_plane_segment(PlaneSeg& s, const float* xM, const float* yM, co
     s.planar = s.mse <= q * q;
 }
 
+void Oracle::rectify_depth(const float* depth, const double T[16], std::vector<float>& rectified) const
+{
+    const int W = cfg_.width, H = cfg_.height;
+    rectified.assign(static_cast<size_t>(W) * H, 0.0f);
+    for (int row = 0; row < H; ++row)
+    {
+        for (int column = 0; column < W; ++column)
+        {
+            const float originalZ = depth[static_cast<size_t>(row) * W + column];
+            if (!(originalZ > 0)) // `<= 0 -> continue`; NaN would reach exit(-1) in the reference, dropped here
+                continue;
+            // _Xpre / _Ypre = static_cast<float>(ScreenCoordinate2D(col,row).to_camera_coordinates()), :156-161
+            const float preX = static_cast<float>((k00_ * column + 0.0 * row) + k02_);
+            const float preY = static_cast<float>((0.0 * column + k11_ * row) + k12_);
+            const double o[3] = {static_cast<double>(preX * originalZ), static_cast<double>(preY * originalZ),
+                                 static_cast<double>(originalZ)};
+            // (T * original.homogeneous()).head<3>(): T[:, :3] * original + T[:, 3]
+            double pr[3];
+            for (int i = 0; i < 3; ++i)
+                pr[i] = ((T[4 * i] * o[0] + T[4 * i + 1] * o[1]) + T[4 * i + 2] * o[2]) + T[4 * i + 3];
+            // CameraCoordinate::to_screen_coordinates (point_coordinates.cpp:201-210): 1.0 / z * (K1 * p).head<2>()
+            const double u = (cfg_.fx * pr[0] + 0.0 * pr[1]) + cfg_.cx * pr[2];
+            const double v = (0.0 * pr[0] + cfg_.fy * pr[1]) + cfg_.cy * pr[2];
+            const double s = 1.0 / pr[2];
+            const double sx = s * u, sy = s * v;
+            if (std::isnan(sx) || std::isnan(sy))
+                continue;
+            const double fx_ = std::floor(sx), fy_ = std::floor(sy);
+            if (!(fx_ > 0.0 && fy_ > 0.0 && fx_ < W && fy_ < H))
+                continue;
+            rectified[static_cast<size_t>(fy_) * W + static_cast<size_t>(fx_)] = static_cast<float>(pr[2]);
+        }
+    }
+}
+
 void Oracle::run(const float* depth, FrameResult& out)
 {
     organized_cloud(depth, lastCloud);
@@ -1452,6 +1487,14 @@ int cape_oracle_run_many(void* h, const float* depth, int n_frames, long long* t
     if (total_planes)
         *total_planes = acc;
     return 0;
+}
+
+void cape_oracle_rectify(void* h, const float* depth, const double* T16, float* out)
+{
+    Handle* H = static_cast<Handle*>(h);
+    std::vector<float> r;
+    H->oracle.rectify_depth(depth, T16, r);
+    std::memcpy(out, r.data(), r.size() * sizeof(float));
 }
 
 void cape_oracle_get_cloud(void* h, float* cloud)

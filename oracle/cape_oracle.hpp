@@ -105,6 +105,10 @@ class Oracle
     // convenience: both steps
     void run(const float* depth, FrameResult& out);
 
+    // Depth_Map_Transformation::rectify_depth, depth_map_transformation.cpp:23-87 (MAKE_DETERMINISTIC loop order);
+    // T = row-major 4x4 camera2 -> camera1 matrix
+    void rectify_depth(const float* depth, const double T[16], std::vector<float>& rectified) const;
+
     // state exposed for per-stage parity
     std::vector<PlaneSeg> planeGrid;   // _planeGrid
     std::vector<float> cellTols;       // _cellDistanceTols

@@ -39,6 +39,7 @@ def lib():
         L.cape_oracle_run.argtypes = [C.c_void_p, C.c_void_p]
         L.cape_oracle_run_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.cape_oracle_get_cloud.argtypes = [C.c_void_p, C.c_void_p]
+        L.cape_oracle_rectify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cape_oracle_get_cell_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 10
         L.cape_oracle_get_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cape_oracle_num_seeds.argtypes = [C.c_void_p]
@@ -143,6 +144,13 @@ class Oracle:
         if K:
             self.L.cape_oracle_get_cylinders(self.h, _p(r.cylinders))
         return r
+
+    def rectify(self, depth, T):
+        d = np.ascontiguousarray(depth, np.float32)
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        out = np.zeros_like(d)
+        self.L.cape_oracle_rectify(self.h, _p(d), _p(T), _p(out))
+        return out
 
     def cloud(self):
         c = np.zeros((3, self.width * self.height), np.float32)

@@ -17,6 +17,7 @@ void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
 void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders);
+void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 int grow_waves_per_group();
 } // namespace cape
 
@@ -54,6 +55,11 @@ struct cape_handle_s
     double* rng = nullptr;
     double* cylScratch = nullptr;
     unsigned long long* debugCycles = nullptr;
+    // rectify_depth (N3): float copies of the back-projection factors + collision keys (allocated on first use)
+    float* xpre = nullptr;
+    float* ypre = nullptr;
+    unsigned long long* rectKeys = nullptr;
+    size_t rectKeyFrames = 0;
     // per-frame scratch (stage A -> stage B)
     double* cellSums = nullptr;
     double* cellPlane = nullptr;
@@ -125,6 +131,9 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->rng);
     (void)hipFree(h->cylScratch);
     (void)hipFree(h->debugCycles);
+    (void)hipFree(h->xpre);
+    (void)hipFree(h->ypre);
+    (void)hipFree(h->rectKeys);
     (void)hipFree(h->cellSums);
     (void)hipFree(h->cellPlane);
     (void)hipFree(h->cellScore);
@@ -378,6 +387,14 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         std::uniform_real_distribution<double> dist(0.0, 1.0);
         for (auto& v : rng)
             v = dist(engine);
+    }
+    {
+        // _Xpre / _Ypre of Depth_Map_Transformation::init_matrices (depth_map_transformation.cpp:156-161)
+        std::vector<float> xp(acol.begin(), acol.end()), yp(brow.begin(), brow.end());
+        CAPE_ALLOC(dalloc(h->xpre, xp.size()));
+        CAPE_ALLOC(dalloc(h->ypre, yp.size()));
+        CAPE_ALLOC(hipMemcpy(h->xpre, xp.data(), xp.size() * sizeof(float), hipMemcpyHostToDevice));
+        CAPE_ALLOC(hipMemcpy(h->ypre, yp.data(), yp.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     CAPE_ALLOC(hipMemcpy(h->acol, acol.data(), acol.size() * sizeof(double), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->brow, brow.data(), brow.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -657,6 +674,46 @@ int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* out)
         o.inorder = (flags[i] & cape::kFlagInorder) ? 1u : 0u;
         o.pad = 0;
     }
+    return CAPE_OK;
+}
+
+int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_dev, int32_t n_frames,
+                       const double* cam2_to_cam1, void* stream_)
+{
+    if (!h || !depth_dev || !rectified_dev || !cam2_to_cam1 || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or negative frame count");
+    if (n_frames == 0)
+        return CAPE_OK;
+    if (depth_dev == rectified_dev)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "rectify_depth is not in-place");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t frameSize = (size_t)h->cfg.width * h->cfg.height;
+    if (h->rectKeyFrames < (size_t)n_frames)
+    {
+        CAPE_HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(h->rectKeys);
+        h->rectKeys = nullptr;
+        h->rectKeyFrames = 0;
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rectKeys), (size_t)n_frames * frameSize * 8));
+        CAPE_HIP_TRY(hipMemset(h->rectKeys, 0, (size_t)n_frames * frameSize * 8));
+        h->rectKeyFrames = (size_t)n_frames;
+    }
+    cape::RectifyParams p;
+    p.in = depth_dev;
+    p.out = rectified_dev;
+    p.keys = h->rectKeys;
+    p.W = h->cfg.width;
+    p.H = h->cfg.height;
+    p.xpre = h->xpre;
+    p.ypre = h->ypre;
+    for (int i = 0; i < 12; ++i)
+        p.T[i] = cam2_to_cam1[i];
+    p.fx = h->cfg.fx;
+    p.fy = h->cfg.fy;
+    p.cx = h->cfg.cx;
+    p.cy = h->cfg.cy;
+    cape::launch_rectify(p, n_frames, stream);
+    CAPE_HIP_TRY(hipGetLastError());
     return CAPE_OK;
 }
 

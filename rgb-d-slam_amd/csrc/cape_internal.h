@@ -87,4 +87,17 @@ struct StageBParams
     unsigned long long* debugCycles; // [frames][16] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
 };
 
+// N3: Depth_Map_Transformation::rectify_depth
+struct RectifyParams
+{
+    const float* in;  // frames x H x W depth of camera 2
+    float* out;       // frames x H x W depth registered to camera 1
+    unsigned long long* keys; // frames x H x W collision keys, all zero between calls
+    int W, H;
+    const float* xpre; // [W] static_cast<float>(acol), ypre [H]
+    const float* ypre;
+    double T[12];      // first three rows of the 4x4 camera2 -> camera1 matrix, row-major
+    double fx, fy, cx, cy; // camera 1 intrinsics
+};
+
 } // namespace cape

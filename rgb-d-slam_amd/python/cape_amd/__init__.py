@@ -70,7 +70,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_device_results",
+    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_device_results",
     "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",
@@ -104,6 +104,7 @@ def load_library():
     L.cape_extract.argtypes = [vp, vp, C.c_int32, vp]
     L.cape_extract_host.argtypes = [vp, vp, C.c_int32, vp]
     L.cape_extract_u16.argtypes = [vp, vp, C.c_float, C.c_int32, vp]
+    L.cape_rectify_depth.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     L.cape_copy_cell_stats.argtypes = [vp, C.c_int32, vp]
@@ -184,6 +185,12 @@ class Extractor:
         """depth_ptr: device address of n_frames x H x W uint16 raw sensor units; z = float(raw) * scale."""
         _check(self.L, self.L.cape_extract_u16(self.h, C.c_void_p(depth_ptr), C.c_float(scale), n_frames, C.c_void_p(stream)),
                "cape_extract_u16")
+
+    def rectify_device(self, in_ptr, out_ptr, n_frames, cam2_to_cam1, stream=0):
+        """Depth_Map_Transformation::rectify_depth on device buffers; cam2_to_cam1: 4x4 row-major."""
+        T = np.ascontiguousarray(cam2_to_cam1, np.float64).reshape(16)
+        _check(self.L, self.L.cape_rectify_depth(self.h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), n_frames,
+                                                 T.ctypes.data_as(C.c_void_p), C.c_void_p(stream)), "cape_rectify_depth")
 
     def extract_host(self, depth, stream=0):
         d = np.ascontiguousarray(depth, dtype=np.float32)

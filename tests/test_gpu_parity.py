@@ -436,3 +436,36 @@ def test_pathological_values_terminate_and_match_labels(oracle_mod):
             assert np.array_equal(res.cyl_labels[f], r.cyl_labels)
             assert res.records["header"]["n_plane_segments"][f] == len(r.segments)
         ex.close()
+
+
+def test_rectify_depth_parity(oracle_mod):
+    """N3: device rectify_depth == oracle (deterministic last-writer-wins), then the rectified image through the path."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    intr = synth.DEFAULT_INTRINSICS
+    frames = np.stack([synth.room(seed=3, frame=1), synth.tunnel(seed=2, frame=5), synth.facets(seed=7, frame=0)])
+    # a realistic Kinect-style extrinsic: 25 mm baseline, ~1 degree rotation about y, small z offset
+    a = np.deg2rad(1.0)
+    T = np.array([[np.cos(a), 0, np.sin(a), -25.0], [0, 1, 0, 1.5], [-np.sin(a), 0, np.cos(a), 4.0], [0, 0, 0, 1]])
+    ex = Extractor(640, 480, cylinders=False, max_batch=3, **intr)
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    din = torch.from_numpy(frames).cuda()
+    dout = torch.empty_like(din)
+    s = torch.cuda.current_stream().cuda_stream
+    for TT in (np.eye(4), T):
+        ex.rectify_device(din.data_ptr(), dout.data_ptr(), 3, TT, s)
+        got = dout.cpu().numpy()
+        for f in range(3):
+            ref = orc.rectify(frames[f], TT)
+            assert np.array_equal(got[f].view(np.uint32), ref.view(np.uint32)), "rectified depth differs"
+        # second call reuses the (cleared) key buffer
+        ex.rectify_device(din.data_ptr(), dout.data_ptr(), 3, TT, s)
+        assert np.array_equal(dout.cpu().numpy().view(np.uint32), got.view(np.uint32))
+    # rectified frames feed the extractor like in examples/main_CAPE.cpp:186
+    ex.extract_device(dout.data_ptr(), 3, s)
+    res = ex.results(3)
+    rect = dout.cpu().numpy()
+    for f in range(3):
+        compare_frame(orc.run(rect[f]), ex, res, f)
+    ex.close()

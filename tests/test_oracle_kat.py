@@ -175,3 +175,23 @@ def test_plane_only_mode_is_a_subset(oracle_mod):
     assert len(a.cylinders) >= 1 and np.isnan(a.cylinders[:, 3]).all()  # radius NaN quirk
     assert abs(np.linalg.norm(a.cylinders[0, :3]) - 1) < 1e-12
     assert abs(a.cylinders[0, 2]) > 0.99  # tunnel axis ~ optical axis
+
+
+def test_rectify_depth_identity_and_shift(oracle_mod):
+    """Depth_Map_Transformation::rectify_depth (N3).  With the identity transform a pixel re-projects to u +- 1e-5 (the
+    pre-factors are float32), so floor() sends it to its own or to the previous column/row; row/col 0 are dropped by the
+    `> 0` test (depth_map_transformation.cpp:62-63).  A pure +x translation moves columns by fx*tx/z."""
+    orc = oracle_mod.Oracle(640, 480)
+    flat = np.full((480, 640), 2000.0, np.float32)
+    r = orc.rectify(flat, np.eye(4))
+    assert (r[0, :] == 0).all() and (r[:, 0] == 0).all()
+    assert (r[1:-1, 1:-1] == 2000.0).all()  # every interior target is hit by its own or its right/lower neighbour
+    ramp = np.tile(np.arange(640, dtype=np.float32) + 1000.0, (480, 1))
+    rr = orc.rectify(ramp, np.eye(4))
+    d = rr[5:-5, 5:-5] - ramp[5:-5, 5:-5]
+    assert set(np.unique(d)) <= {0.0, 1.0}  # value of column u or u+1
+    T = np.eye(4)
+    T[0, 3] = 100.0  # 100 mm to the right: du = 550 * 100 / z
+    r2 = orc.rectify(flat, T)
+    shift = int(np.floor(550.0 * 100.0 / 2000.0))
+    assert (r2[100, :shift] == 0).all() and (r2[100, shift + 2:] == 2000.0).all()
