@@ -197,4 +197,5 @@ def test_rectify_depth_identity_and_shift(oracle_mod):
     T[0, 3] = 100.0  # 100 mm to the right: du = 550 * 100 / z
     r2 = orc.rectify(flat, T)
     shift = int(np.floor(550.0 * 100.0 / 2000.0))
-    assert (r2[100, :shift] == 0).all() and (r2[100, shift + 2:] == 2000.0).all()
+    cols = np.flatnonzero((r2 > 0).any(axis=0))
+    assert abs(int(cols.min()) - shift) <= 1 and set(np.unique(r2)) == {0.0, 2000.0}
