@@ -216,6 +216,10 @@ int cape_extract_u16(cape_handle h, const uint16_t* depth_dev, float scale, int3
 int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_dev, int32_t n_frames,
                        const double* cam2_to_cam1, void* stream);
 
+/* Same with host images (H2D copy, rectify, D2H copy, synchronous): the host boundary of the reference signature. */
+int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* rectified_host, int32_t n_frames,
+                            const double* cam2_to_cam1);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -717,6 +717,31 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
     return CAPE_OK;
 }
 
+int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* rectified_host, int32_t n_frames,
+                            const double* cam2_to_cam1)
+{
+    if (!h || !depth_host || !rectified_host || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or negative frame count");
+    const size_t bytes = (size_t)n_frames * h->cfg.width * h->cfg.height * sizeof(float);
+    float *din = nullptr, *dout = nullptr;
+    CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&din), bytes));
+    if (hipMalloc(reinterpret_cast<void**>(&dout), bytes) != hipSuccess)
+    {
+        (void)hipFree(din);
+        return fail(CAPE_ERR_HIP, "hipMalloc failed");
+    }
+    int rc = CAPE_OK;
+    if (hipMemcpy(din, depth_host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(CAPE_ERR_HIP, "H2D copy failed");
+    if (rc == CAPE_OK)
+        rc = cape_rectify_depth(h, din, dout, n_frames, cam2_to_cam1, nullptr);
+    if (rc == CAPE_OK && hipMemcpy(rectified_host, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(CAPE_ERR_HIP, "D2H copy failed");
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
+
 int cape_device_summaries(cape_handle h, void** summaries)
 {
     if (!h || !summaries)

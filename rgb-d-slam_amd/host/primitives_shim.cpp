@@ -95,6 +95,42 @@ Depth_Map_Transformation::Depth_Map_Transformation(const uint width, const uint 
         log(2, "Depth_Map_Transformation: only the reference's 20 px cell size is supported");
 }
 
+Depth_Map_Transformation::~Depth_Map_Transformation() { cape_destroy(_handle); }
+
+bool Depth_Map_Transformation::rectify_depth(const DepthImageView& depthImage, float* rectified) noexcept
+{
+    if (!rectified || depthImage.rows != static_cast<int>(_height) || depthImage.cols != static_cast<int>(_width) ||
+        depthImage.step != static_cast<size_t>(depthImage.cols))
+    {
+        log(2, "rectify_depth: depth image must be a contiguous width x height float image");
+        return false;
+    }
+    if (!_handle)
+    {
+        if (!Parameters::is_valid())
+            Parameters::load_defaut();
+        uint w, h;
+        cape_config cfg {};
+        Parameters::get_camera_1(w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy);
+        cfg.width = static_cast<int32_t>(_width);
+        cfg.height = static_cast<int32_t>(_height);
+        cfg.max_batch = 1;
+        if (cape_create(&cfg, &_handle) != CAPE_OK)
+        {
+            log(2, std::string("rectify_depth: ") + cape_last_error());
+            _handle = nullptr;
+            return false;
+        }
+    }
+    // host boundary of the reference signature: stage through device memory (cape_debug-style helper of the C ABI)
+    if (cape_rectify_depth_host(_handle, depthImage.data, rectified, 1, _cam2to1.data()) != CAPE_OK)
+    {
+        log(2, std::string("rectify_depth: ") + cape_last_error());
+        return false;
+    }
+    return true;
+}
+
 bool Depth_Map_Transformation::get_organized_cloud_array(const DepthImageView& depthImage) noexcept
 {
     // the reference always returns true (depth_map_transformation.cpp:141)

@@ -101,18 +101,28 @@ using cylinder_container = std::vector<Cylinder>;
 using plane_container = std::vector<Plane>;
 
 // depth_map_transformation.hpp:15-57.  The organised cloud exists in the reference only to feed find_primitives
-// (src/rgbd_slam.cpp:109-121); the native path back-projects inside the cell-fit kernel, so this class only
-// validates sizes.  rectify_depth (dataset-specific pre-step) is not part of the path.
+// (src/rgbd_slam.cpp:109-121); the native path back-projects inside the cell-fit kernel, so get_organized_cloud_array
+// only validates sizes.  rectify_depth runs on the device through cape_rectify_depth.
 class Depth_Map_Transformation
 {
   public:
     Depth_Map_Transformation(const uint width, const uint height, const uint cellSize);
+    ~Depth_Map_Transformation();
+    Depth_Map_Transformation(const Depth_Map_Transformation&) = delete;
+    Depth_Map_Transformation& operator=(const Depth_Map_Transformation&) = delete;
     [[nodiscard]] bool get_organized_cloud_array(const DepthImageView& depthImage) noexcept;
+    // rectify_depth(depthImage, rectifiedDepth): `rectified` must hold rows*cols floats.  The camera2 -> camera1
+    // matrix is Parameters::get_camera_2_to_camera_1_transformation() in the reference; here it is set explicitly
+    // (identity by default = Parameters::load_defaut).
+    [[nodiscard]] bool rectify_depth(const DepthImageView& depthImage, float* rectified) noexcept;
+    void set_camera_2_to_camera_1_transformation(const std::array<double, 16>& rowMajor4x4) noexcept { _cam2to1 = rowMajor4x4; }
 #ifdef CAPE_HAVE_EIGEN_OPENCV
     [[nodiscard]] bool get_organized_cloud_array(const cv::Mat_<float>& depthImage, Eigen::MatrixXf& organizedCloudArray) noexcept;
 #endif
   private:
     uint _width, _height, _cellSize;
+    cape_handle _handle = nullptr; // created on the first rectify_depth call
+    std::array<double, 16> _cam2to1 {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 };
 
 // primitive_detection.hpp:27-241

@@ -70,7 +70,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_device_results",
+    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",

@@ -40,6 +40,17 @@ int main(int argc, char** argv)
     }
     for (const Cylinder& c : cylinders)
         std::printf("C %a %a %a\n", c._normal[0], c._normal[1], c._normal[2]);
+    // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
+    std::vector<float> rect(depth.size());
+    if (!depthOps.rectify_depth(img, rect.data()))
+        return 6;
+    size_t hits = 0;
+    for (float v : rect)
+        hits += v > 0;
+    plane_container planes2;
+    cylinder_container cylinders2;
+    detector.find_primitives(DepthImageView {rect.data(), static_cast<int>(H), static_cast<int>(W), W}, planes2, cylinders2);
+    std::printf("R %zu %zu\n", hits, planes2.size());
     detector.show_statistics(0.01, 1, true);
     return 0;
 }

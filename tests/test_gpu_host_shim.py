@@ -37,4 +37,9 @@ def test_shim_matches_oracle(oracle_mod, tmp_path, scene, seed, frame):
     for k, c in enumerate(Cc):
         vals = np.array([float.fromhex(v) for v in c])
         assert np.array_equal(vals.view(np.uint64), np.ascontiguousarray(r.cylinders[k, 0:3]).view(np.uint64))
+    # rectify_depth through the mirror class == oracle rectify (identity transform), and its frame still yields planes
+    R = [ln.split()[1:] for ln in lines if ln.startswith("R ")][0]
+    ref_rect = oracle_mod.Oracle(640, 480, cylinders=True, **intr).rectify(depth, np.eye(4))
+    assert int(R[0]) == int((ref_rect > 0).sum())
+    assert int(R[1]) == len(oracle_mod.Oracle(640, 480, cylinders=True, **intr).run(ref_rect).planes)
     assert "Mean primitive extraction time" in out.stderr
