@@ -469,3 +469,27 @@ def test_rectify_depth_parity(oracle_mod):
     for f in range(3):
         compare_frame(orc.run(rect[f]), ex, res, f)
     ex.close()
+
+
+def test_large_mixed_batch_labels(oracle_mod):
+    """256 different frames in one launch (several independent frame-waves per workgroup): every label grid, plane count
+    and primitive summary equals the frame's own oracle run."""
+    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+
+    names = ["room", "facets", "tunnel", "facets"]
+    frames = np.stack([synth.SCENES[names[i % 4]](seed=1000 + i, frame=3 * i) for i in range(64)])
+    frames = np.concatenate([frames, frames[::-1], frames[:, :, ::-1], frames[::-1, :, ::-1]])  # 256 frames
+    frames = np.ascontiguousarray(frames)
+    intr = _intr("room")
+    for cyl in (False, True):
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=len(frames), **intr)
+        ex.extract_host(frames)
+        res = ex.results(len(frames), with_boundary=False)
+        orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+        for f in range(len(frames)):
+            r = orc.run(frames[f])
+            assert np.array_equal(res.plane_labels[f], r.plane_labels), f
+            assert np.array_equal(res.cyl_labels[f], r.cyl_labels), f
+            assert res.records["header"]["n_planes"][f] == len(r.planes)
+            assert res.records["header"]["n_cylinders"][f] == len(r.cylinders)
+        ex.close()
