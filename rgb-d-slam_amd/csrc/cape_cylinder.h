@@ -52,7 +52,7 @@ struct CylCtx
     int C;
     const unsigned short* s_list; // activated cells, ascending (= _local2globalMap)
     int total;                    // _cellActivatedCount
-    double* s_dist;               // N f64 (aliases s_mse; the caller restores it)
+    double* s_dist;               // N f64: MSAC cost of every remaining cell for the current hypothesis
     unsigned short* s_ids;        // idsLeft
     unsigned char* s_idmask;      // idsLeftMask
     unsigned char* s_cur;         // inliers of the current hypothesis
