@@ -339,7 +339,10 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
 // ---------------------------------------------------------------------------------------------------------------
 // A2: one lane per cell
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cape_cell_plane_kernel(StageAParams p, int nFrames)
+#ifndef CAPE_A2_WAVES
+#define CAPE_A2_WAVES 4
+#endif
+__global__ __launch_bounds__(256, CAPE_A2_WAVES) void cape_cell_plane_kernel(StageAParams p, int nFrames)
 {
     const size_t gcell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gcell >= (size_t)nFrames * p.cells)
