@@ -31,6 +31,13 @@ namespace cape {
 #ifndef CAPE_A_WAVES
 #define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
 #endif
+#ifndef CAPE_A_LDS_ATOMIC
+#define CAPE_A_LDS_ATOMIC 0 // 0: per-thread partial sums meet through a [thread][11] f64 staging array (38.9 KB LDS per
+                            //    workgroup) -- default, 1.48 ms per 4 096 frames;
+                            // 1: through ds_add_f64 into [cell][10] (16.6 KB).  The sums are exact, so the atomics'
+                            //    arbitrary order cannot change a bit (parity tests pass), but it measures 3 % slower
+                            //    (1.53 ms) and the LDS it frees did not let the grow kernel of another sub-batch overlap.
+#endif
 #ifndef CAPE_A_PACKED
 #define CAPE_A_PACKED 0  // 1: pixel pairs with v_pk_mul_f32 -- measured SLOWER (1.66-1.94 ms): gfx950 SIMDs are 32 wide,
                          // a packed f32 op costs two issue slots, so packing buys nothing here
@@ -38,7 +45,7 @@ namespace cape {
 
 constexpr int kThreadsA = 320;
 constexpr int kBandThreads = 160;
-constexpr int kPartStride = 11; // 10 f64 per thread, padded against LDS bank conflicts
+[[maybe_unused]] constexpr int kPartStride = 11; // 10 f64 per thread, padded against LDS bank conflicts
 
 struct PxAcc
 {
@@ -151,7 +158,12 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
 template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
 {
     // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
+#if CAPE_A_LDS_ATOMIC
+    __shared__ double s_cellsum[64 * 10];   // [cell][9 sums, count]
+    __shared__ unsigned s_zminmax[64 * 2];  // float bits of (zmin, zmax): non-negative floats order like unsigned ints
+#else
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
+#endif
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
     __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
@@ -172,6 +184,16 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     const int j = q - cseg * 5;      // float4 within the cell row
     const int lcell = bsel * 32 + cseg;
 
+#if CAPE_A_LDS_ATOMIC
+    for (int e = t; e < 640; e += kThreadsA)
+        s_cellsum[e] = 0.0;
+    if (t < 64)
+    {
+        s_zminmax[2 * t] = 0x7F800000u; // +inf
+        s_zminmax[2 * t + 1] = 0u;
+    }
+    __syncthreads();
+#endif
     // ------------------------------------------------------------------ streaming accumulation
     PxAcc A;
 #pragma unroll
@@ -242,6 +264,18 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             sum_group(bufB, g + 1);
         }
     }
+#if CAPE_A_LDS_ATOMIC
+    if (active)
+    {
+        double* dst = s_cellsum + lcell * 10;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            atomicAdd(dst + k, A.S[k]); // ds_add_f64; exact sums => order-free
+        atomicAdd(dst + 9, (double)A.n);
+        atomicMin(&s_zminmax[2 * lcell], __float_as_uint(A.zmin));
+        atomicMax(&s_zminmax[2 * lcell + 1], __float_as_uint(A.zmax));
+    }
+#else
     {
         double* dst = s_part + t * kPartStride;
 #pragma unroll
@@ -250,6 +284,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         dst[9] = (double)A.n;
         reinterpret_cast<float2*>(dst + 10)[0] = make_float2(A.zmin, A.zmax);
     }
+#endif
     __syncthreads();
 
     // ------------------------------------------------------------------ 5 partials -> one cell (exact, any order)
@@ -266,12 +301,16 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         const int cc = sg * 32 + cs;
         if (bnd < p.bandsPerFrame && cc < p.hCells)
         {
+#if CAPE_A_LDS_ATOMIC
+            const double acc = s_cellsum[e];
+#else
             const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
             double acc = src[0];
             acc += src[kPartStride];
             acc += src[2 * kPartStride];
             acc += src[3 * kPartStride];
             acc += src[4 * kPartStride];
+#endif
             p.cell_sums[((size_t)frame * p.cells + cr * p.hCells + cc) * kSumStride + m] = acc;
         }
     }
@@ -311,6 +350,10 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             continuous = continuous && is_continuous(zc[i], last);
     }
     // exactness guard: all addends of every sum within 2^20 of each other (see header)
+#if CAPE_A_LDS_ATOMIC
+    const float zmin = __uint_as_float(s_zminmax[2 * t]), zmax = __uint_as_float(s_zminmax[2 * t + 1]);
+    const uint32_t n = (uint32_t)s_cellsum[t * 10 + 9];
+#else
     float zmin = __builtin_huge_valf(), zmax = 0.0f;
     uint32_t n = 0;
     {
@@ -324,6 +367,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             n += (uint32_t)s_part[(pbase + k) * kPartStride + 9];
         }
     }
+#endif
     const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);
     const bool exact_ok = (n == 0) || (zmax * rab <= 512.0f * zmin);
 
