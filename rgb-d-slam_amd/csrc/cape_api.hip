@@ -528,6 +528,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     h->lastFrames = n_frames;
     if (n_frames == 0)
         return CAPE_OK;
+    CAPE_HIP_TRY(hipSetDevice(h->cfg.device)); // the handle's device, whatever the calling thread had current
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     h->pa.depth = depth_dev;
     h->pa.depth_u16 = depth_u16;
@@ -627,6 +628,7 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
 {
     if (!h || n_frames < 0 || n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
+    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
     CAPE_HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)n_frames, C = (size_t)h->cells;
     if (records)
