@@ -493,3 +493,23 @@ def test_large_mixed_batch_labels(oracle_mod):
             assert res.records["header"]["n_planes"][f] == len(r.planes)
             assert res.records["header"]["n_cylinders"][f] == len(r.cylinders)
         ex.close()
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (800, 600), (1280, 720), (160, 120), (1000, 40)])
+def test_other_grid_shapes(oracle_mod, w, h):
+    """Grids that are not 32x24 / 64x48: partial band segments (40 = 32 + 8 cells), odd band counts, u64 rows with
+    fewer than 64 columns, a single cell row."""
+    from cape_amd import Extractor, synth
+
+    s = w / 640.0
+    intr = dict(fx=550.0 * s, fy=550.0 * s, cx=w / 2.0 + 0.25, cy=h / 2.0 - 0.5)
+    frames = np.stack([synth.facets(seed=21, frame=1, width=w, height=h, intr=intr),
+                       synth.tunnel(seed=5, frame=2, width=w, height=h, intr=intr)])
+    for cyl in (False, True):
+        orc = oracle_mod.Oracle(w, h, cylinders=cyl, **intr)
+        ex = Extractor(w, h, cylinders=cyl, max_batch=2, **intr)
+        ex.extract_host(frames)
+        res = ex.results(2)
+        for f in range(2):
+            compare_frame(orc.run(frames[f]), ex, res, f)
+        ex.close()
