@@ -247,19 +247,10 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 N, c.scratch, 6, 0, [&](int e) { return e; }, c.s_stage, lane, [&](int i, const double* t) {
                     if (c.s_best[i])
                     {
-                        const double v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3], v4 = t[4], v5 = t[5];
-                        double v;
-                        switch (lane)
-                        {
-                        case 0: v = v0; break;
-                        case 1: v = v1; break;
-                        case 2: v = v2; break;
-                        case 3: v = v3; break;
-                        case 4: v = v4; break;
-                        case 5: v = v5; break;
-                        default: v = (v0 * v3 + v1 * v4) + v2 * v5; break;
-                        }
-                        chain += v;
+                        // lanes 0..5 take component `lane`, lane 6 the n.c product -- branch-free
+                        const double dotv = (t[0] * t[3] + t[1] * t[4]) + t[2] * t[5];
+                        const double comp = t[lane < 6 ? lane : 0];
+                        chain += (lane < 6) ? comp : dotv;
                     }
                 });
         const double sNx = __shfl(chain, 0), sNy = __shfl(chain, 1), sNz = __shfl(chain, 2);
@@ -303,20 +294,30 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double dx = P2x - ctx, dy = P2y - cty, dz = P2z - ctz;
         const double P1P2d = sqrt((dx * dx + dy * dy) + dz * dz);
         double mse = 0.0;
-        // records: (cx, cy, cz, mse) = pieces 2..3 of cell_plane
-        staged_for_each<2>(
-                N, planeBase, kPlaneStride, 2, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
-                [&](int i, const double* pl) {
-                    if (c.s_best[i])
-                    {
-                        const double wx = pl[0] - P2x, wy = pl[1] - P2y, wz = pl[2] - P2z;
-                        const double crx = dy * wz - dz * wy;
-                        const double cry = dz * wx - dx * wz;
-                        const double crz = dx * wy - dy * wx;
-                        const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
-                        mse += t * t;
-                    }
-                });
+        {
+            // the per-cell squared distances are independent: all lanes compute them (cx, cy, cz straight from
+            // cell_plane) into LDS, then they are added in ascending order like the reference's loop
+            for (int i = lane; i < N; i += 64)
+            {
+                double t2 = 0.0;
+                if (c.s_best[i])
+                {
+                    const double* pl = planeBase + (size_t)c.s_list[i] * kPlaneStride;
+                    const double wx = pl[4] - P2x, wy = pl[5] - P2y, wz = pl[6] - P2z;
+                    const double crx = dy * wz - dz * wy;
+                    const double cry = dz * wx - dx * wz;
+                    const double crz = dx * wy - dy * wx;
+                    const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
+                    t2 = t * t;
+                }
+                c.s_dist[i] = t2;
+            }
+            CAPE_CYL_SYNC();
+            for (int i = 0; i < N; ++i)
+                if (c.s_best[i])
+                    mse += c.s_dist[i];
+            CAPE_CYL_SYNC();
+        }
         mse /= (double)maxInliers;
 
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
