@@ -231,6 +231,76 @@ bool ring_is_simple(const std::vector<vector2>& r)
     return std::abs(ring_area_signed(r)) > 0;
 }
 
+// Area of the intersection of two simple rings.  The plane is cut into vertical slabs at every vertex and every
+// edge-edge crossing; inside a slab no two edges cross, so each ring is a stack of trapezoids ordered by y and the
+// overlap of the two stacks is a sum of trapezoids.
+double rings_inter_area(const std::vector<vector2>& A, const std::vector<vector2>& B)
+{
+    if (A.size() < 3 || B.size() < 3)
+        return 0.0;
+    struct Edge { vector2 a, b; }; // a.x < b.x
+    auto edges_of = [](const std::vector<vector2>& r) {
+        std::vector<Edge> e;
+        for (size_t i = 0, j = r.size() - 1; i < r.size(); j = i++)
+        {
+            vector2 p = r[j], q = r[i];
+            if (p[0] == q[0])
+                continue; // vertical edges bound no area in x
+            if (p[0] > q[0])
+                std::swap(p, q);
+            e.push_back({p, q});
+        }
+        return e;
+    };
+    const std::vector<Edge> ea = edges_of(A), eb = edges_of(B);
+    std::vector<double> xs;
+    for (const auto& p : A) xs.push_back(p[0]);
+    for (const auto& p : B) xs.push_back(p[0]);
+    for (const Edge& e : ea)
+        for (const Edge& f : eb)
+        {
+            const double d1x = e.b[0] - e.a[0], d1y = e.b[1] - e.a[1], d2x = f.b[0] - f.a[0], d2y = f.b[1] - f.a[1];
+            const double den = d1x * d2y - d1y * d2x;
+            if (den == 0)
+                continue; // parallel / collinear: no isolated crossing
+            const double t = ((f.a[0] - e.a[0]) * d2y - (f.a[1] - e.a[1]) * d2x) / den;
+            const double u = ((f.a[0] - e.a[0]) * d1y - (f.a[1] - e.a[1]) * d1x) / den;
+            if (t > 0 && t < 1 && u > 0 && u < 1)
+                xs.push_back(e.a[0] + t * d1x);
+        }
+    std::sort(xs.begin(), xs.end());
+    xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+    auto y_at = [](const Edge& e, double x) { return e.a[1] + (e.b[1] - e.a[1]) * ((x - e.a[0]) / (e.b[0] - e.a[0])); };
+    double area = 0.0;
+    for (size_t s = 0; s + 1 < xs.size(); ++s)
+    {
+        const double x0 = xs[s], x1 = xs[s + 1], xm = 0.5 * (x0 + x1);
+        if (!(x1 > x0))
+            continue;
+        auto stack = [&](const std::vector<Edge>& es) {
+            std::vector<std::pair<double, const Edge*>> st;
+            for (const Edge& e : es)
+                if (e.a[0] <= x0 && e.b[0] >= x1)
+                    st.emplace_back(y_at(e, xm), &e);
+            std::sort(st.begin(), st.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+            return st;
+        };
+        const auto sa = stack(ea), sb = stack(eb);
+        for (size_t i = 0; i + 1 < sa.size(); i += 2)
+            for (size_t j = 0; j + 1 < sb.size(); j += 2)
+            {
+                const auto& lo = (sa[i].first > sb[j].first) ? sa[i] : sb[j];
+                const auto& hi = (sa[i + 1].first < sb[j + 1].first) ? sa[i + 1] : sb[j + 1];
+                if (hi.first <= lo.first)
+                    continue;
+                const double h0 = y_at(*hi.second, x0) - y_at(*lo.second, x0);
+                const double h1 = y_at(*hi.second, x1) - y_at(*lo.second, x1);
+                area += 0.5 * (h0 + h1) * (x1 - x0);
+            }
+    }
+    return area;
+}
+
 } // namespace
 
 std::pair<vector3, vector3> get_plane_coordinate_system(const vector3& normal)
@@ -322,6 +392,54 @@ Polygon::Polygon(const std::vector<vector3>& points, const vector3& normal, cons
         _ring = compute_convex_hull(projected); // the reference first tries boost's `correct`, then this fallback
     _area = area();
     simplify();
+}
+
+Polygon::Polygon(const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center) :
+    _ring(ring),
+    _center(center),
+    _xAxis(xAxis),
+    _yAxis(yAxis)
+{
+    if (_ring.size() > 1 && _ring.front() == _ring.back())
+        _ring.pop_back();
+    if (ring_area_signed(_ring) > 0) // boost::geometry::correct: clockwise outer ring
+        std::reverse(_ring.begin(), _ring.end());
+    _area = area();
+}
+
+Polygon Polygon::project(const vector3& nextNormal, const vector3& nextCenter) const
+{
+    const auto axes = get_plane_coordinate_system(nextNormal);
+    return project(axes.first, axes.second, nextCenter);
+}
+
+Polygon Polygon::project(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const
+{
+    std::vector<vector2> ring;
+    ring.reserve(_ring.size());
+    for (const vector2& p : _ring)
+        ring.push_back(get_projected_plan_coordinates(get_point_from_plane_coordinates(p, _center, _xAxis, _yAxis), nextCenter,
+                                                      nextXAxis, nextYAxis));
+    return Polygon(ring, nextXAxis, nextYAxis, nextCenter);
+}
+
+double Polygon::inter_area(const Polygon& other) const
+{
+    return rings_inter_area(_ring, other.project(_xAxis, _yAxis, _center)._ring);
+}
+
+double Polygon::union_area(const Polygon& other) const
+{
+    const Polygon o = other.project(_xAxis, _yAxis, _center);
+    return area() + o.area() - rings_inter_area(_ring, o._ring);
+}
+
+double Polygon::inter_over_union(const Polygon& other) const
+{
+    const Polygon o = other.project(_xAxis, _yAxis, _center);
+    const double inter = rings_inter_area(_ring, o._ring);
+    const double uni = area() + o.area() - inter;
+    return (uni <= 0 || inter <= 0) ? 0.0 : inter / uni;
 }
 
 bool Polygon::is_valid() const noexcept { return ring_is_simple(_ring); }

@@ -47,6 +47,18 @@ class Polygon
 
     void simplify(double distanceThreshold = 10) noexcept;      // Douglas-Peucker, threshold max(area/1e5, distanceThreshold)
 
+    // --- plane matching support ("next" row N2: MapPlane::find_matches, map_primitive.cpp:91-161) -----------------
+    // Polygon::project (polygon.cpp:338-382): the same boundary expressed in another plane frame (orthogonal projection)
+    [[nodiscard]] Polygon project(const vector3& nextNormal, const vector3& nextCenter) const;
+    [[nodiscard]] Polygon project(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const;
+    // inter_area / union_area / inter_over_union (polygon.cpp:525-576): `other` is first projected into this frame.
+    // Exact areas of the intersection of two simple polygons by vertical-slab decomposition (no Boost).
+    [[nodiscard]] double inter_area(const Polygon& other) const;
+    [[nodiscard]] double union_area(const Polygon& other) const;
+    [[nodiscard]] double inter_over_union(const Polygon& other) const;
+    // polygon from an explicit ring in a given frame (polygon.cpp:236-266)
+    Polygon(const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center);
+
     static std::vector<vector2> compute_concave_hull(const std::vector<vector2>& points) noexcept;
     static std::vector<vector2> compute_convex_hull(const std::vector<vector2>& points) noexcept;
 

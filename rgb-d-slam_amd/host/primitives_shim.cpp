@@ -79,6 +79,41 @@ bool Plane::is_normal_similar(const Plane& p) const noexcept
 }
 bool Plane::is_distance_similar(const Plane& p) const noexcept { return std::abs(_d - p._d) < 100.0; }
 
+int find_plane_match(const plane_container& detected, const std::vector<bool>& isMatched, const std::array<double, 4>& projectedPlane,
+                     const utils::Polygon& projectedPolygon, bool useAdvancedSearch) noexcept
+{
+    static const double minimumNormalDotDiff = std::abs(std::cos(20.0 * M_PI / 180.0));
+    const double projectedArea = projectedPolygon.get_area();
+    const double planeMinimalOverlap = static_cast<double>(0.4f); // minimumPlaneOverlapToConsiderMatch (float)
+    const double areaSimilarityThreshold = useAdvancedSearch ? planeMinimalOverlap / 2 : planeMinimalOverlap;
+    double greatestSimilarity = 0.0;
+    if (projectedArea <= 0.0)
+        return -1;
+    int selectedIndex = -1;
+    for (int i = 0; i < static_cast<int>(detected.size()); ++i)
+    {
+        if (i < static_cast<int>(isMatched.size()) && isMatched[i])
+            continue;
+        const Plane& p = detected[i];
+        const auto n = p.get_normal();
+        const bool distanceSimilar = std::abs(p.get_d() - projectedPlane[3]) < 100.0;
+        const double c = (n[0] * projectedPlane[0] + n[1] * projectedPlane[1]) + n[2] * projectedPlane[2];
+        if (!distanceSimilar || !(std::abs(c) > minimumNormalDotDiff))
+            continue;
+        const utils::Polygon& detectedPolygon = p.get_boundary_polygon();
+        const double newPlaneArea = detectedPolygon.get_area();
+        const double interArea = detectedPolygon.inter_area(projectedPolygon);
+        if (interArea > greatestSimilarity && interArea / newPlaneArea >= areaSimilarityThreshold)
+        {
+            selectedIndex = i;
+            greatestSimilarity = interArea;
+        }
+    }
+    if (selectedIndex <= 0) // quirk of the reference: index 0 can never be returned
+        return -1;
+    return selectedIndex;
+}
+
 bool Cylinder::is_similar(const Cylinder& c) const noexcept
 {
     static const double minimumNormalDotDiff = std::abs(std::cos(20.0 * M_PI / 180.0));

@@ -100,6 +100,16 @@ class Cylinder
 using cylinder_container = std::vector<Cylinder>;
 using plane_container = std::vector<Plane>;
 
+// "Next" row N2: the selection loop of MapPlane::find_matches (src/map_management/map_features/map_primitive.cpp:91-161)
+// for one map plane that the caller has already projected into camera space (parametrization nx,ny,nz,d and boundary
+// polygon).  A detected plane is a candidate if |d - d'| < 100 mm and |n.n'| > cos 20 deg (shape_primitives.cpp:66-86);
+// the candidate with the greatest polygon intersection area wins provided inter / area(detected) >= 0.4 (0.2 with
+// useAdvancedSearch; parameters.hpp:90-95).  Returns the index of the selected detected plane or -1; like the
+// reference it rejects index 0 (`if (selectedIndex <= 0)`, map_primitive.cpp:146).
+int find_plane_match(const plane_container& detectedPlanes, const std::vector<bool>& isDetectedFeatureMatched,
+                     const std::array<double, 4>& projectedPlane, const utils::Polygon& projectedPolygon,
+                     bool useAdvancedSearch = false) noexcept;
+
 // depth_map_transformation.hpp:15-57.  The organised cloud exists in the reference only to feed find_primitives
 // (src/rgbd_slam.cpp:109-121); the native path back-projects inside the cell-fit kernel, so get_organized_cloud_array
 // only validates sizes.  rectify_depth runs on the device through cape_rectify_depth.

@@ -106,6 +106,40 @@ int main()
             EXPECT(poly.get_area() > 0);
         }
     }
+    {
+        // SquareTests.SimpleFitting :36-47 and SquareTests.Unions (areas): union / intersection areas
+        const std::vector<vector3> sq {{-1000.0, 1000.0, 0.0}, {1000.0, 1000.0, 0.0}, {-1000.0, -1000.0, 0.0}, {1000.0, -1000.0, 0.0}};
+        const vector3 normal {0, 0, 1}, center {0, 0, 0};
+        Polygon polygon(sq, normal, center);
+        EXPECT(std::abs(polygon.get_area() - polygon.union_area(polygon)) < 0.1);
+        EXPECT(std::abs(polygon.get_area() - polygon.inter_area(polygon)) < 0.1);
+        Polygon inv(sq, {0, 0, -1}, center);
+        EXPECT(std::abs(polygon.get_area() - polygon.union_area(inv)) < 0.1);
+        EXPECT(std::abs(polygon.get_area() - polygon.inter_area(inv)) < 0.1);
+        const std::vector<vector3> di {{-1000.0, 0.0, 0.0}, {1000.0, 0.0, 0.0}, {0.0, -1000.0, 0.0}, {0.0, 1000.0, 0.0}};
+        Polygon diamond(di, normal, center);
+        EXPECT(std::abs(polygon.inter_area(diamond) - 2e6) < 0.1 && std::abs(polygon.union_area(diamond) - 4e6) < 0.1);
+        // the diamond shifted by half a length: half of it sticks out (Unions: area 4e6 + 1e6)
+        Polygon shifted = diamond.project(normal, {-1000.0, 0.0, 0.0}); // same boundary seen from a frame moved to -1000
+        std::vector<vector3> di2;
+        for (const auto& v : di)
+            di2.push_back({v[0] + 1000.0, v[1], v[2]});
+        Polygon diamondRight(di2, normal, center);
+        EXPECT(std::abs(polygon.union_area(diamondRight) - 5e6) < 0.1);
+        EXPECT(std::abs(polygon.inter_area(diamondRight) - 1e6) < 0.1);
+        EXPECT(std::abs(polygon.inter_over_union(diamondRight) - 0.2) < 1e-6);
+        EXPECT(std::abs(shifted.get_area() - 2e6) < 0.1);
+        // projection on a perpendicular plane has zero area; on a 45 degree plane it shrinks by cos(45)
+        EXPECT(polygon.project({1, 0, 0}, {1000, 0, 0}).get_area() < 1e-6);
+        const double c45 = std::sqrt(0.5);
+        const double a45 = polygon.project({c45, 0, c45}, {1000, 0, 0}).get_area();
+        EXPECT(a45 > 0 && a45 < polygon.get_area() && std::abs(a45 - 4e6 * c45) < 1.0);
+        // disjoint and concave cases
+        std::vector<vector3> far;
+        for (const auto& v : sq)
+            far.push_back({v[0] + 5000.0, v[1], v[2]});
+        EXPECT(polygon.inter_area(Polygon(far, normal, center)) == 0.0);
+    }
     std::printf(failures ? "%d FAILURES\n" : "all polygon tests passed\n", failures);
     return failures ? 1 : 0;
 }

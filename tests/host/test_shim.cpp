@@ -40,6 +40,14 @@ int main(int argc, char** argv)
     }
     for (const Cylinder& c : cylinders)
         std::printf("C %a %a %a\n", c._normal[0], c._normal[1], c._normal[2]);
+    // N2: MapPlane::find_matches selection with the frame's own planes standing in for projected map planes
+    for (size_t i = 0; i < planes.size(); ++i)
+    {
+        const auto n = planes[i].get_normal();
+        const int m = find_plane_match(planes, std::vector<bool>(planes.size(), false), {n[0], n[1], n[2], planes[i].get_d()},
+                                       planes[i].get_boundary_polygon());
+        std::printf("M %zu %d\n", i, m);
+    }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
     std::vector<float> rect(depth.size());
     if (!depthOps.rectify_depth(img, rect.data()))

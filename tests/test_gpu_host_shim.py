@@ -37,6 +37,9 @@ def test_shim_matches_oracle(oracle_mod, tmp_path, scene, seed, frame):
     for k, c in enumerate(Cc):
         vals = np.array([float.fromhex(v) for v in c])
         assert np.array_equal(vals.view(np.uint64), np.ascontiguousarray(r.cylinders[k, 0:3]).view(np.uint64))
+    # N2: every plane matches itself, except index 0 which the reference's `selectedIndex <= 0` test can never return
+    M = {int(ln.split()[1]): int(ln.split()[2]) for ln in lines if ln.startswith("M ")}
+    assert len(M) == len(P) and all(M[i] == (i if i > 0 else -1) for i in M)
     # rectify_depth through the mirror class == oracle rectify (identity transform), and its frame still yields planes
     R = [ln.split()[1:] for ln in lines if ln.startswith("R ")][0]
     ref_rect = oracle_mod.Oracle(640, 480, cylinders=True, **intr).rectify(depth, np.eye(4))
