@@ -249,6 +249,8 @@ def main():
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
                 "kernel_ms": {"cape_cell_moments_kernel": a1_ms, "cape_cell_plane_kernel": a2_ms, "cape_grow_kernel": b_ms},
+                "stage_b": {"us_per_frame": 1e3 * b_ms / fpl, "frames_in_flight": ex.grow_frames_per_cu * ex.compute_units,
+                            "note": "one wavefront per frame, latency bound; ~0 HBM bytes beyond the 168 B/cell it reads"},
                 "end_to_end_GBps": frames_total / world * e2e_bytes_per_frame / elapsed / 1e9,
                 "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
             },

@@ -186,6 +186,8 @@ typedef struct cape_layout
     int32_t h_cells, v_cells, cells;
     int32_t boundary_capacity;
     uint64_t frame_record_bytes;  /* sizeof(cape_frame_record) */
+    int32_t compute_units;        /* CUs of the handle's device */
+    int32_t grow_frames_per_cu;   /* frames (one wavefront each) the grow kernel keeps in flight per CU (occupancy API) */
 } cape_layout;
 
 /* Depth_Map_Transformation / Primitive_Detection constructors (src/rgbd_slam.cpp:48-57). */

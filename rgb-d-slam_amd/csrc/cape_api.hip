@@ -19,6 +19,7 @@ void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders);
 void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 int grow_waves_per_group();
+int grow_waves_per_cu(const StageBParams& p);
 } // namespace cape
 
 namespace {
@@ -495,6 +496,11 @@ int cape_get_layout(cape_handle h, cape_layout* out)
 {
     if (!h || !out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    {
+        hipDeviceProp_t prop;
+        out->compute_units = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess) ? prop.multiProcessorCount : 0;
+        out->grow_frames_per_cu = cape::grow_waves_per_cu(h->pb);
+    }
     out->h_cells = h->hCells;
     out->v_cells = h->vCells;
     out->cells = h->cells;

@@ -32,11 +32,7 @@ constexpr int kChunk = kStageChunk; // cells staged per step of the ordered mome
 #define CAPE_B_WAVES_PER_GROUP 4
 #endif
 constexpr int kWavesPerGroup = CAPE_B_WAVES_PER_GROUP; // independent frames (waves) per workgroup
-// the staging buffer doubles as the centre-depth array of the boundary phase: max(kChunk*10 f64, cells f32)
-__host__ __device__ constexpr int kChunkDoubles(int cells)
-{
-    return (kChunk * kSumStride > (cells + 1) / 2) ? kChunk * kSumStride : (cells + 1) / 2;
-}
+__host__ __device__ constexpr int kChunkDoubles(int) { return kChunk * kSumStride; }
 
 // kernel-phase ablation for profiling experiments: -DCAPE_B_STOP_AT=k makes the wave leave after phase k
 #ifdef CAPE_B_STOP_AT
@@ -235,8 +231,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
     // ---- LDS carve (all offsets multiples of 16)
     // ---- LDS carve (every offset a multiple of 8; 13.4 KB for 640x480 plane-only -> 12 waves per CU)
     double* s_seg = reinterpret_cast<double*>(smem);                              // CAPE_MAX_PLANES x 20 f64
-    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums ;
-                                                                                  // after the seed loop: centre depths
+    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
     unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // 32 u64
     int* s_hist = reinterpret_cast<int*>(s_adj + CAPE_MAX_PLANES);                // 400 i32
     short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
@@ -250,7 +245,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
     double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64
-    float* s_zc = reinterpret_cast<float*>(s_chunk);                              // C f32, aliases s_chunk (boundary phase)
+    // centre-pixel depths of the boundary phase: C f32 = exactly the bytes of s_bins + s_list, both dead after the seed loop
+    float* s_zc = reinterpret_cast<float*>(s_bins);
 
     const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
 
@@ -868,11 +864,11 @@ size_t grow_lds_bytes(int cells, bool cylinders)
 {
     size_t b = 0;
     b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
-    b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk / s_zc
+    b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk
     b += (size_t)CAPE_MAX_PLANES * 8;               // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
-    b += (size_t)cells * 2;                         // s_bins
-    b += (size_t)cells * 2;                         // s_list
+    b += (size_t)cells * 2;                         // s_bins  } after the seed loop these two hold s_zc
+    b += (size_t)cells * 2;                         // s_list  }
     b += (size_t)cells;                             // s_lab
     b += CAPE_MAX_PLANES;                           // s_mlab
     if (cylinders)
@@ -881,6 +877,25 @@ size_t grow_lds_bytes(int cells, bool cylinders)
 }
 
 int grow_waves_per_group() { return kWavesPerGroup; }
+
+// frame-waves of the grow kernel that one CU can hold at once (occupancy API; advisory, see MI355X_MICROARCH.md)
+int grow_waves_per_cu(const StageBParams& p)
+{
+    const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl);
+    int wpg = kWavesPerGroup;
+    while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
+        --wpg;
+    int blocks = 0;
+    hipError_t e;
+    if (p.hCells <= 32)
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
+    else
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, true>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
+    return e == hipSuccess ? blocks * wpg : 0;
+}
 
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
 {

@@ -37,7 +37,8 @@ class cape_config(C.Structure):
 
 class cape_layout(C.Structure):
     _fields_ = [("h_cells", C.c_int32), ("v_cells", C.c_int32), ("cells", C.c_int32),
-                ("boundary_capacity", C.c_int32), ("frame_record_bytes", C.c_uint64)]
+                ("boundary_capacity", C.c_int32), ("frame_record_bytes", C.c_uint64),
+                ("compute_units", C.c_int32), ("grow_frames_per_cu", C.c_int32)]
 
 
 class cape_timings(C.Structure):
@@ -164,6 +165,8 @@ class Extractor:
         self.cells, self.h_cells, self.v_cells = lay.cells, lay.h_cells, lay.v_cells
         self.boundary_capacity = lay.boundary_capacity
         self.record_bytes = int(lay.frame_record_bytes)
+        self.compute_units = int(lay.compute_units)
+        self.grow_frames_per_cu = int(lay.grow_frames_per_cu)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
