@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--scene", default="room")
     ap.add_argument("--cylinders", action="store_true", help="planes + cylinder RANSAC (BASELINE.json configs[2], [4])")
+    ap.add_argument("--match", action="store_true",
+                    help="also run the consecutive-frame plane matcher every step (the 'IoU matching' of BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
     args = ap.parse_args()
@@ -153,6 +155,8 @@ def main():
 
     def step():
         ex.extract_device(depth.data_ptr(), B, stream)
+        if args.match:
+            ex.match_consecutive(B, 0, stream)
         if use_dist:
             k = step_no[0] & 1
             step_no[0] += 1
@@ -240,7 +244,8 @@ def main():
             "config": {
                 "workload": (f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])"
                              if (args.scene == "room" and not args.cylinders) else
-                             f"{W}x{H} synthetic {args.scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only")),
+                             f"{W}x{H} synthetic {args.scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only")
+                             + (" + consecutive-frame plane matching" if args.match else "")),
                 "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene, "sub_batches": args.sub_batches,
                 "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
             },

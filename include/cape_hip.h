@@ -222,6 +222,36 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
 int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* rectified_host, int32_t n_frames,
                             const double* cam2_to_cam1);
 
+/* "Next" row N2, device part: a cell-mask pre-filter for MapPlane::find_matches
+ * (src/map_management/map_features/map_primitive.cpp:91-161) between CONSECUTIVE frames of the last cape_extract batch.
+ * For frame f >= 1 the planes of frame f-1 play the map planes ("projected" with the identity pose) and the planes of
+ * frame f the detected ones; plane i = i-th segment with is_output, its mask = the cells whose label belongs to its
+ * merge group (the mask add_planes_to_primitives builds, primitive_detection.cpp:586-594).  Areas are counted in
+ * cells instead of polygon mm^2; everything else follows the reference: |d_i - d_j| < 100 mm and |n_i . n_j| >
+ * |cos 20 deg| (shape_primitives.cpp:70-86), inter > best so far and inter / area(detected) >= 0.4f (0.2 with
+ * CAPE_MATCH_ADVANCED), previous planes visited in order with the is-matched flags updated between them
+ * (feature_map.hpp:651-669), and the `selectedIndex <= 0` quirk that never returns detected plane 0
+ * (map_primitive.cpp:146) unless CAPE_MATCH_ALLOW_INDEX0 is set.  Frame 0 of a batch has no predecessor (n_prev = 0). */
+enum
+{
+    CAPE_MATCH_ADVANCED = 1u << 0,
+    CAPE_MATCH_ALLOW_INDEX0 = 1u << 1
+};
+typedef struct cape_frame_match
+{
+    int32_t n_prev;                      /* planes of frame f-1 */
+    int32_t n_cur;                       /* planes of frame f */
+    int32_t match[CAPE_MAX_PLANES];      /* per previous plane j: matched plane of this frame, or -1 */
+    uint16_t area_prev[CAPE_MAX_PLANES]; /* cells */
+    uint16_t area_cur[CAPE_MAX_PLANES];
+    uint16_t inter[CAPE_MAX_PLANES][CAPE_MAX_PLANES]; /* inter[j][i]: cells shared by previous plane j and plane i */
+} cape_frame_match;
+/* Asynchronous on `stream`; reads the device results of the last cape_extract (n_frames <= that batch). */
+int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void* stream);
+/* Device pointer to / synchronous copy of the n_frames x cape_frame_match written by cape_match_consecutive. */
+int cape_device_matches(cape_handle h, void** matches);
+int cape_copy_matches(cape_handle h, int32_t n_frames, cape_frame_match* out);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -18,6 +18,7 @@ void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders);
 void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
+void launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 int grow_waves_per_group();
 int grow_waves_per_cu(const StageBParams& p);
 } // namespace cape
@@ -61,6 +62,8 @@ struct cape_handle_s
     float* ypre = nullptr;
     unsigned long long* rectKeys = nullptr;
     size_t rectKeyFrames = 0;
+    // plane matching between consecutive frames (N2): max_batch x cape_frame_match, allocated on first use
+    cape_frame_match* matches = nullptr;
     // per-frame scratch (stage A -> stage B)
     double* cellSums = nullptr;
     double* cellPlane = nullptr;
@@ -135,6 +138,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->xpre);
     (void)hipFree(h->ypre);
     (void)hipFree(h->rectKeys);
+    (void)hipFree(h->matches);
     (void)hipFree(h->cellSums);
     (void)hipFree(h->cellPlane);
     (void)hipFree(h->cellScore);
@@ -748,6 +752,57 @@ int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* recti
     (void)hipFree(din);
     (void)hipFree(dout);
     return rc;
+}
+
+int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void* stream_)
+{
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
+    if (n_frames > h->lastFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
+    if (flags & ~(uint32_t)(CAPE_MATCH_ADVANCED | CAPE_MATCH_ALLOW_INDEX0))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "unknown match flag");
+    if (n_frames == 0)
+        return CAPE_OK;
+    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->matches)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matches), (size_t)h->cfg.max_batch * sizeof(cape_frame_match)));
+    cape::MatchParams p;
+    p.records = h->records;
+    p.plane_labels = h->planeLabels;
+    p.matches = h->matches;
+    p.cells = h->cells;
+    p.flags = flags;
+    // parameters::matching (src/parameters.hpp:89-95), evaluated on the host like the reference's function-local statics
+    p.minCosAngle = std::abs(std::cos(20.0 * M_PI / 180.0));
+    p.maxDistance = 100.0;
+    const double planeMinimalOverlap = static_cast<double>(0.4f);
+    p.minOverlap = (flags & CAPE_MATCH_ADVANCED) ? planeMinimalOverlap / 2 : planeMinimalOverlap;
+    cape::launch_match(p, n_frames, static_cast<hipStream_t>(stream_));
+    CAPE_HIP_TRY(hipGetLastError());
+    return CAPE_OK;
+}
+
+int cape_device_matches(cape_handle h, void** matches)
+{
+    if (!h || !matches)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->matches)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_consecutive has not run");
+    *matches = h->matches;
+    return CAPE_OK;
+}
+
+int cape_copy_matches(cape_handle h, int32_t n_frames, cape_frame_match* out)
+{
+    if (!h || !out || n_frames < 0 || n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!h->matches)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_consecutive has not run");
+    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    CAPE_HIP_TRY(hipMemcpy(out, h->matches, (size_t)n_frames * sizeof(cape_frame_match), hipMemcpyDeviceToHost));
+    return CAPE_OK;
 }
 
 int cape_device_summaries(cape_handle h, void** summaries)

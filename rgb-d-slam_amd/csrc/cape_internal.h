@@ -100,4 +100,17 @@ struct RectifyParams
     double fx, fy, cx, cy; // camera 1 intrinsics
 };
 
+// N2 (device part): cell-mask plane matching between consecutive frames
+struct MatchParams
+{
+    const cape_frame_record* records;
+    const int32_t* plane_labels;
+    cape_frame_match* matches;
+    int cells;
+    uint32_t flags;
+    double minCosAngle;     // abs(cos(20 * pi / 180)), shape_primitives.cpp:72-73
+    double maxDistance;     // 100 mm, shape_primitives.cpp:84
+    double minOverlap;      // (double)0.4f, halved for the advanced search (map_primitive.cpp:106-107)
+};
+
 } // namespace cape

@@ -267,6 +267,24 @@ void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames
     _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame_match>& matches, bool useAdvancedSearch,
+                                            bool allowIndexZero) noexcept
+{
+    matches.clear();
+    if (!_handle || n_frames < 0)
+        return false;
+    const uint32_t flags = (useAdvancedSearch ? CAPE_MATCH_ADVANCED : 0u) | (allowIndexZero ? CAPE_MATCH_ALLOW_INDEX0 : 0u);
+    matches.resize(n_frames);
+    if (cape_match_consecutive(_handle, n_frames, flags, nullptr) != CAPE_OK ||
+        cape_copy_matches(_handle, n_frames, matches.data()) != CAPE_OK)
+    {
+        log(2, std::string("match_consecutive: ") + cape_last_error());
+        matches.clear();
+        return false;
+    }
+    return true;
+}
+
 void Primitive_Detection::find_primitives(const DepthImageView& depthImage, plane_container& planeContainer,
                                           cylinder_container& primitiveContainer) noexcept
 {

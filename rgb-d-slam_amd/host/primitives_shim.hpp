@@ -155,6 +155,13 @@ class Primitive_Detection
     void find_primitives_batch(const float* depth, int n_frames, std::vector<plane_container>& planes,
                                std::vector<cylinder_container>& cylinders) noexcept;
 
+    // "Next" row N2, device part: candidate matches between consecutive frames of the frames still resident on the
+    // device (the last chunk of <= 64 frames of find_primitives_batch), computed on cell masks by
+    // cape_match_consecutive.  Plane indices count the segments with is_output, i.e. the planes BEFORE the polygon
+    // validity test drops any; a host-side polygon check with find_plane_match confirms a candidate.
+    bool match_consecutive(int n_frames, std::vector<cape_frame_match>& matches, bool useAdvancedSearch = false,
+                           bool allowIndexZero = false) noexcept;
+
     void show_statistics(const double meanFrameTreatmentDuration, const uint frameCount,
                          const bool shouldDisplayDetails = false) const noexcept;
 

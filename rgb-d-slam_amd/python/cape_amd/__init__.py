@@ -65,6 +65,12 @@ SUMMARY_DTYPE = np.dtype([
     ("planes", np.dtype([("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8")]), 16),
     ("cylinders", np.dtype([("axis", "<f8", 3), ("radius", "<f8")]), 8)], align=True)
 assert SUMMARY_DTYPE.itemsize == 1296
+MATCH_DTYPE = np.dtype([
+    ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", 32), ("area_prev", "<u2", 32), ("area_cur", "<u2", 32),
+    ("inter", "<u2", (32, 32))], align=True)
+MATCH_ADVANCED = 1
+MATCH_ALLOW_INDEX0 = 2
+
 CELL_STATS_DTYPE = np.dtype([
     ("sums", "<f8", 9), ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"),
     ("score", "<f8"), ("tol", "<f4"), ("point_count", "<u4"), ("bin", "<i4"), ("planar", "<u4"),
@@ -73,7 +79,7 @@ CELL_STATS_DTYPE = np.dtype([
 EXPORTED_SYMBOLS = [
     "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
-    "cape_reset_timings",
+    "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
@@ -113,6 +119,9 @@ def load_library():
     L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
     L.cape_reset_timings.argtypes = [vp]
     L.cape_device_summaries.argtypes = [vp, C.POINTER(vp)]
+    L.cape_match_consecutive.argtypes = [vp, C.c_int32, C.c_uint32, vp]
+    L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
+    L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
     L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
     L.cape_debug_cycles.argtypes = [vp, C.c_int32, vp]
     L.cape_last_error.restype = C.c_char_p
@@ -221,6 +230,15 @@ class Extractor:
                                                 bd.ctypes.data_as(C.c_void_p) if with_boundary else None),
                "cape_copy_results")
         return FrameResults(rec, pl, cl, bd)
+
+    # ---- N2: cell-mask plane matching between consecutive frames of the last batch -----------------
+    def match_consecutive(self, n_frames, flags=0, stream=0):
+        _check(self.L, self.L.cape_match_consecutive(self.h, n_frames, flags, C.c_void_p(stream)), "cape_match_consecutive")
+
+    def matches(self, n_frames):
+        out = np.zeros(n_frames, MATCH_DTYPE)
+        _check(self.L, self.L.cape_copy_matches(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_copy_matches")
+        return out
 
     def cell_stats(self, frame):
         out = np.zeros(self.cells, CELL_STATS_DTYPE)

@@ -48,6 +48,21 @@ int main(int argc, char** argv)
                                        planes[i].get_boundary_polygon());
         std::printf("M %zu %d\n", i, m);
     }
+    // N2 device part: the same frame twice -> every plane of "frame 1" overlaps its own copy in "frame 0"
+    {
+        std::vector<float> two(depth);
+        two.insert(two.end(), depth.begin(), depth.end());
+        std::vector<plane_container> bp;
+        std::vector<cylinder_container> bc;
+        detector.find_primitives_batch(two.data(), 2, bp, bc);
+        std::vector<cape_frame_match> mm;
+        if (!detector.match_consecutive(2, mm) || mm.size() != 2)
+            return 7;
+        std::printf("D %d %d", mm[1].n_prev, mm[1].n_cur);
+        for (int j = 0; j < mm[1].n_prev; ++j)
+            std::printf(" %d", mm[1].match[j]);
+        std::printf("\n");
+    }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
     std::vector<float> rect(depth.size());
     if (!depthOps.rectify_depth(img, rect.data()))

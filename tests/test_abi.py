@@ -33,6 +33,7 @@ def test_struct_sizes_match_header():
     assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 32 * 264 + 16 * 40
     assert cape_amd.SUMMARY_DTYPE.itemsize == 1296
     assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4
+    assert cape_amd.MATCH_DTYPE.itemsize == 8 + 32 * 4 + 2 * 32 * 2 + 32 * 32 * 2
 
 
 def test_no_cpu_fallback():

@@ -40,6 +40,9 @@ def test_shim_matches_oracle(oracle_mod, tmp_path, scene, seed, frame):
     # N2: every plane matches itself, except index 0 which the reference's `selectedIndex <= 0` test can never return
     M = {int(ln.split()[1]): int(ln.split()[2]) for ln in lines if ln.startswith("M ")}
     assert len(M) == len(P) and all(M[i] == (i if i > 0 else -1) for i in M)
+    # N2 device part on a duplicated frame: same verdicts from the cell masks
+    D = [int(v) for v in [ln for ln in lines if ln.startswith("D ")][0].split()[1:]]
+    assert D[0] == D[1] == len(r.planes) and D[2:] == [(i if i > 0 else -1) for i in range(len(r.planes))]
     # rectify_depth through the mirror class == oracle rectify (identity transform), and its frame still yields planes
     R = [ln.split()[1:] for ln in lines if ln.startswith("R ")][0]
     ref_rect = oracle_mod.Oracle(640, 480, cylinders=True, **intr).rectify(depth, np.eye(4))
