@@ -288,7 +288,7 @@ enum
     CAPE_DEBUG_SQRTF = 5, CAPE_DEBUG_EIGEN3 = 6, CAPE_DEBUG_FIT_PLANE = 7
 };
 int cape_debug_eval(int op, const double* a, const double* b, double* out, int n);
-/* Debug: shader-clock ticks spent per phase of the grow kernel, n_frames x 16 (all zero unless the library was built
+/* Debug: shader-clock ticks spent per phase of the grow kernel, n_frames x 32 (all zero unless the library was built
  * with -DCAPE_B_PROFILE).  Synchronises. */
 int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out);
 

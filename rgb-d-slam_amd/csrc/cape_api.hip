@@ -207,8 +207,8 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     b.cyl_labels += F * C;
     b.boundary += F * (size_t)h->boundaryCap * 3;
     if (b.cylScratch)
-        b.cylScratch += F * C * 6;
-    b.debugCycles += F * 16;
+        b.cylScratch += F * C * cape::kCylStride;
+    b.debugCycles += F * cape::kProfileSlots;
 }
 
 int fold_timings(cape_handle_s* h);
@@ -347,9 +347,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellAux, B * C));
     CAPE_ALLOC(dalloc(h->cellMse, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
-        CAPE_ALLOC(dalloc(h->cylScratch, B * C * 6));
-    CAPE_ALLOC(dalloc(h->debugCycles, B * 16));
-    CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * 16 * 8));
+        CAPE_ALLOC(dalloc(h->cylScratch, B * C * cape::kCylStride));
+    CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
+    CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     CAPE_ALLOC(dalloc(h->records, B));
     CAPE_ALLOC(dalloc(h->summaries, B));
     CAPE_ALLOC(dalloc(h->planeLabels, B * C));
@@ -818,7 +818,7 @@ int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out)
     if (!h || !out || n_frames < 0 || n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
     CAPE_HIP_TRY(hipDeviceSynchronize());
-    CAPE_HIP_TRY(hipMemcpy(out, h->debugCycles, (size_t)n_frames * 16 * 8, hipMemcpyDeviceToHost));
+    CAPE_HIP_TRY(hipMemcpy(out, h->debugCycles, (size_t)n_frames * cape::kProfileSlots * 8, hipMemcpyDeviceToHost));
     return CAPE_OK;
 }
 

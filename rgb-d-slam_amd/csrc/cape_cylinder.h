@@ -35,13 +35,20 @@ namespace cape {
     {                                                                                                        \
         const unsigned long long _n = __builtin_amdgcn_s_memtime();                                          \
         if (lane == 0)                                                                                       \
-            c.dbg[(k)] += _n - _ct;                                                                          \
+            atomicAdd(&c.dbg[(k)], _n - _ct);                                                                \
         _ct = _n;                                                                                            \
     } while (0)
 #define CAPE_CYL_TICK_INIT() unsigned long long _ct = __builtin_amdgcn_s_memtime()
+#define CAPE_CYL_COUNT(k, v)                                                                                 \
+    do                                                                                                       \
+    {                                                                                                        \
+        if (lane == 0)                                                                                       \
+            atomicAdd(&c.dbg[(k)], (unsigned long long)(v));                                                 \
+    } while (0)
 #else
 #define CAPE_CYL_TICK(k)
 #define CAPE_CYL_TICK_INIT()
+#define CAPE_CYL_COUNT(k, v)
 #endif
 
 struct CylCtx
@@ -57,7 +64,7 @@ struct CylCtx
     unsigned char* s_idmask;      // idsLeftMask
     unsigned char* s_cur;         // inliers of the current hypothesis
     unsigned char* s_best;        // finalInlierIndexes as flags
-    double* scratch;              // [N][6] projected normals / projected centroids of this frame
+    double* scratch;              // [N][kCylStride] projected normals / projected centroids / their dot product
     double* s_stage;              // kStageChunk x 10 f64 staging buffer (cape_staged.h)
     double* s_seg;
     unsigned char* s_lab;
@@ -66,12 +73,80 @@ struct CylCtx
     unsigned long long* dbg;      // per-frame phase ticks (profiling builds)
 };
 
+// The RANSAC distance pass streams the remaining cells four rounds (256 cells) at a time: the twelve 16-byte loads of
+// a trip are all requested before the first distance is computed, so a trip costs one memory round trip instead of four
+#define CAPE_CYL_TRIP(F) F(0) F(1) F(2) F(3)
+#define CAPE_CYL_DECL(k) double2 cqa##k, cqb##k, cqc##k; int cqi##k;
+#define CAPE_CYL_FETCH(k)                                                                                    \
+    {                                                                                                        \
+        const int jj_ = j0 + lane + 64 * (k);                                                                \
+        cqi##k = c.s_ids[jj_ < m ? jj_ : 0];                                                                 \
+        const double2* t_ = reinterpret_cast<const double2*>(c.scratch + (size_t)cqi##k * kCylStride);       \
+        cqa##k = t_[0];                                                                                      \
+        cqb##k = t_[1];                                                                                      \
+        cqc##k = t_[2];                                                                                      \
+    }
+#define CAPE_CYL_SCORE(k)                                                                                    \
+    {                                                                                                        \
+        bool inl_;                                                                                           \
+        const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
+        if (j0 + lane + 64 * (k) < m)                                                                        \
+        {                                                                                                    \
+            psum += d_;                                                                                      \
+            curLocal += inl_ ? 1 : 0;                                                                        \
+        }                                                                                                    \
+    }
+#define CAPE_CYL_PARK(k)                                                                                     \
+    {                                                                                                        \
+        bool inl_;                                                                                           \
+        const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
+        if (j0 + lane + 64 * (k) < m)                                                                        \
+        {                                                                                                    \
+            c.s_dist[j0 + lane + 64 * (k)] = d_;                                                             \
+            c.s_cur[cqi##k] = inl_ ? 1 : 0;                                                                  \
+        }                                                                                                    \
+    }
+
 __device__ __forceinline__ int cyl_wave_sum(int v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         v += __shfl_xor(v, o);
     return v;
+}
+
+// init-less ordered sum s[0] + s[1] + ... + s[n-1] (ascending, one rounding per add, like the reference's loops) of
+// NON-NEGATIVE addends parked in LDS.  The running sum of non-negative terms never decreases, so the scan may stop as
+// soon as it reaches `limit`: the caller only needs to know that the total is >= limit then.  Eight elements per
+// trip with the next eight already requested, so the LDS latency hides behind the dependent adds.  `s` is 16-byte
+// aligned and readable up to s[n + 7].
+__device__ __forceinline__ double ordered_sum_lds(const double* s, int n, double limit)
+{
+    double sum = 0.0;
+    int j = 0;
+    if (n >= 8)
+    {
+        const double2* v = reinterpret_cast<const double2*>(s);
+        double2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        for (; j + 8 <= n; j += 8)
+        {
+            const double2 b0 = v[j / 2 + 4], b1 = v[j / 2 + 5], b2 = v[j / 2 + 6], b3 = v[j / 2 + 7];
+            sum += a0.x;
+            sum += a0.y;
+            sum += a1.x;
+            sum += a1.y;
+            sum += a2.x;
+            sum += a2.y;
+            sum += a3.x;
+            sum += a3.y;
+            if (sum >= limit)
+                return sum;
+            a0 = b0, a1 = b1, a2 = b2, a3 = b3;
+        }
+    }
+    for (; j < n; ++j)
+        sum += s[j];
+    return sum;
 }
 
 // returns with nSeg / nCylLabels / rngPos / status updated; nCylFits is incremented by the caller
@@ -121,13 +196,16 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double ndt = dot3(ax, ay, az, nx, ny, nz);
         const double px = nx - ndt * ax, py = ny - ndt * ay, pz = nz - ndt * az;
         const double nrm = sqrt((px * px + py * py) + pz * pz);
-        double* o = c.scratch + (size_t)j * 6;
-        o[0] = px / nrm;
-        o[1] = py / nrm;
-        o[2] = pz / nrm;
-        o[3] = cx - cdt * ax;
-        o[4] = cy - cdt * ay;
-        o[5] = cz - cdt * az;
+        double* o = c.scratch + (size_t)j * kCylStride;
+        const double o0 = px / nrm, o1 = py / nrm, o2 = pz / nrm;
+        const double o3 = cx - cdt * ax, o4 = cy - cdt * ay, o5 = cz - cdt * az;
+        o[0] = o0;
+        o[1] = o1;
+        o[2] = o2;
+        o[3] = o3;
+        o[4] = o4;
+        o[5] = o5;
+        o[6] = (o0 * o3 + o1 * o4) + o2 * o5; // the LLS term b += n.dot(c) (cylinder_segment.cpp:171), ready for the ordered pass
         c.s_ids[j] = (unsigned short)j;
         c.s_idmask[j] = 1;
     }
@@ -166,9 +244,9 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     ++rngPos;
                     id[q] = c.s_ids[(unsigned)floor(U * (double)(unsigned)m)];
                 }
-                const double* t1 = c.scratch + (size_t)id[0] * 6;
-                const double* t2 = c.scratch + (size_t)id[1] * 6;
-                const double* t3 = c.scratch + (size_t)id[2] * 6;
+                const double* t1 = c.scratch + (size_t)id[0] * kCylStride;
+                const double* t2 = c.scratch + (size_t)id[1] * kCylStride;
+                const double* t3 = c.scratch + (size_t)id[2] * kCylStride;
                 const double n1x = t1[0], n1y = t1[1], n1z = t1[2], c1x = t1[3], c1y = t1[4], c1z = t1[5];
                 const double n2x = t2[0], n2y = t2[1], n2z = t2[2], c2x = t2[3], c2y = t2[4], c2z = t2[5];
                 const double n3x = t3[0], n3y = t3[1], n3z = t3[2], c3x = t3[3], c3y = t3[4], c3z = t3[5];
@@ -185,36 +263,43 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 const double cty = (sCy - radius * sNy) / 3.0;
                 const double ctz = (sCz - radius * sNz) / 3.0;
 
-                // MSAC truncated distances of all remaining cells (parallel), cost summed in ascending order
-                int curLocal = 0;
-                for (int jj = lane; jj < m; jj += 64)
-                {
-                    const int i = c.s_ids[jj];
-                    const double* t = c.scratch + (size_t)i * 6;
-                    const double vx = (t[3] - radius * t[0]) - ctx;
-                    const double vy = (t[4] - radius * t[1]) - cty;
-                    const double vz = (t[5] - radius * t[2]) - ctz;
+                // MSAC truncated distances of all remaining cells, in parallel.  The cost the reference compares is their
+                // ORDERED sum, a serial chain over m cells, so a cheap decision comes first: psum is the same sum in
+                // tree order.  Both roundings of a sum of m <= 4096 non-negative terms stay within 2^-41 (relative)
+                // of the exact value, so psum * (1 - 2^-40) >= minHyp proves that the ordered sum cannot be < minHyp:
+                // the hypothesis loses and nothing else of it is observable.  Otherwise the distances are parked in
+                // LDS and summed in order (stopping early once the running sum reaches minHyp).
+                auto msac = [&](double t0, double t1, double t2, double t3, double t4, double t5, bool& inl) {
+                    const double vx = (t3 - radius * t0) - ctx;
+                    const double vy = (t4 - radius * t1) - cty;
+                    const double vz = (t5 - radius * t2) - ctz;
                     const double distance = ((vx * vx + vy * vy) + vz * vz) * invR2;
-                    const bool inl = distance < maxSqrtDist;
-                    c.s_cur[i] = inl ? 1 : 0;
-                    c.s_dist[jj] = inl ? distance : maxSqrtDist;
-                    curLocal += inl ? 1 : 0;
+                    inl = distance < maxSqrtDist;
+                    return inl ? distance : maxSqrtDist;
+                };
+                int curLocal = 0;
+                double psum = 0.0;
+                for (int j0 = 0; j0 < m; j0 += 256)
+                {
+                    CAPE_CYL_TRIP(CAPE_CYL_DECL)
+                    CAPE_CYL_TRIP(CAPE_CYL_FETCH)
+                    CAPE_CYL_TRIP(CAPE_CYL_SCORE)
                 }
                 const int curCount = cyl_wave_sum(curLocal);
-                CAPE_CYL_SYNC();
-                double dist = 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    psum += __shfl_xor(psum, o);
+                double dist = minHyp;
+                if (!(psum * (1.0 - 0x1p-40) >= minHyp))
                 {
-                    int jj = 0;
-                    for (; jj + 4 <= m; jj += 4)
+                    for (int j0 = 0; j0 < m; j0 += 256)
                     {
-                        const double d0 = c.s_dist[jj], d1 = c.s_dist[jj + 1], d2 = c.s_dist[jj + 2], d3 = c.s_dist[jj + 3];
-                        dist += d0;
-                        dist += d1;
-                        dist += d2;
-                        dist += d3;
+                        CAPE_CYL_TRIP(CAPE_CYL_DECL)
+                        CAPE_CYL_TRIP(CAPE_CYL_FETCH)
+                        CAPE_CYL_TRIP(CAPE_CYL_PARK)
                     }
-                    for (; jj < m; ++jj)
-                        dist += c.s_dist[jj];
+                    CAPE_CYL_SYNC();
+                    dist = ordered_sum_lds(c.s_dist, m, minHyp);
                 }
                 bool stop = false;
                 if (dist < minHyp)
@@ -231,6 +316,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     stop = (unsigned)prevBestCount > inliersAccepted;
                 }
                 CAPE_CYL_SYNC();
+                CAPE_CYL_COUNT(27, 1); // hypotheses evaluated
                 if (stop)
                     break;
             }
@@ -243,16 +329,22 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
 
         // ===== LLS over all inliers, ascending i (:157-186): lanes 0-2 sumN, 3-5 sumC, 6 b
         double chain = 0.0;
-        staged_for_each<3>(
-                N, c.scratch, 6, 0, [&](int e) { return e; }, c.s_stage, lane, [&](int i, const double* t) {
-                    if (c.s_best[i])
-                    {
-                        // lanes 0..5 take component `lane`, lane 6 the n.c product -- branch-free
-                        const double dotv = (t[0] * t[3] + t[1] * t[4]) + t[2] * t[5];
-                        const double comp = t[lane < 6 ? lane : 0];
-                        chain += (lane < 6) ? comp : dotv;
-                    }
+        unsigned inlMask = 0; // bit ci: element c0 + ci of the chunk being consumed is an inlier (uniform)
+        auto ballotInliers = [&](int c0, int cn) {
+            const int ci = lane & (kStageChunk - 1);
+            inlMask = (unsigned)__ballot(lane < kStageChunk && ci < cn && c.s_best[c0 + ci] != 0);
+        };
+        staged_for_each<4>(
+                N, c.scratch, kCylStride, 0, [&](int e) { return e; }, c.s_stage, lane, ballotInliers,
+                [&](int i, const double* t) {
+                    // lanes 0..5 take component `lane`, lane 6 the precomputed n.c product; a non-inlier adds +0.0, which
+                    // leaves the running sum unchanged bit for bit (the sum is never -0.0).  The operand is loaded
+                    // unconditionally: a load inside the selected arm would cost one LDS round trip per element.
+                    const double term = t[lane < 7 ? lane : 0];
+                    const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
+                    chain += inl ? term : 0.0;
                 });
+        CAPE_CYL_TICK(16); // LLS ordered pass
         const double sNx = __shfl(chain, 0), sNy = __shfl(chain, 1), sNz = __shfl(chain, 2);
         const double sCx = __shfl(chain, 3), sCy = __shfl(chain, 4), sCz = __shfl(chain, 5);
         double b = __shfl(chain, 6);
@@ -277,6 +369,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         }
         CAPE_CYL_SYNC();
 
+        CAPE_CYL_TICK(17); // idsLeft compaction
         const double kk = (double)((unsigned long long)maxInliers * (unsigned long long)maxInliers);
         const double oneOverSq = 1.0 / kk;
         const double a = 1 - ((sNx * sNx + sNy * sNy) + sNz * sNz) * oneOverSq;
@@ -313,22 +406,25 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 c.s_dist[i] = t2;
             }
             CAPE_CYL_SYNC();
-            for (int i = 0; i < N; ++i)
-                if (c.s_best[i])
-                    mse += c.s_dist[i];
+            CAPE_CYL_TICK(18); // MSE: parallel distances
+            // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach: scan all N entries
+            mse = ordered_sum_lds(c.s_dist, N, __builtin_inf());
             CAPE_CYL_SYNC();
         }
+        CAPE_CYL_TICK(19); // MSE: ordered sum
         mse /= (double)maxInliers;
 
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
         const int ql = lane < 10 ? lane : 0;
         double acc = 0.0; // Plane_Segment newMergedPlane: cleared sums
         staged_for_each<5>(
-                N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
+                N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, ballotInliers,
                 [&](int i, const double* rec) {
-                    if (c.s_best[i])
-                        acc += rec[ql];
+                    const double v = rec[ql];
+                    const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
+                    acc += inl ? v : 0.0;
                 });
+        CAPE_CYL_TICK(20); // merged plane sums, ordered pass
         double S[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -336,6 +432,10 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double cnt = __shfl(acc, 9);
         PlaneFit f;
         fit_plane(S, (uint32_t)cnt, f);
+        CAPE_CYL_TICK(21); // merged plane fit
+        CAPE_CYL_COUNT(24, 1);          // RANSAC rounds (outer while)
+        CAPE_CYL_COUNT(25, N);          // cells of the region
+        CAPE_CYL_COUNT(26, maxInliers); // inliers removed
 
         // ===== add_cylinder_to_features (:437-476): model selection on MSE
         if (f.mse < mse)
@@ -384,7 +484,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     c.s_cyl[c.s_list[i]] = (unsigned char)nCylLabels;
         }
         CAPE_CYL_SYNC();
-        CAPE_CYL_TICK(15); // LLS + MSE + merged plane + labels
+        CAPE_CYL_TICK(22); // model selection + labels
     }
 }
 

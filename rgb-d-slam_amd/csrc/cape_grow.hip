@@ -58,11 +58,13 @@ __host__ __device__ constexpr int kChunkDoubles(int) { return kChunk * kSumStrid
     {                                                                                                        \
         const unsigned long long _now = __builtin_amdgcn_s_memtime();                                        \
         if (lane == 0)                                                                                       \
-            p.debugCycles[(size_t)frame * 16 + (k)] += _now - _tick;                                         \
+            atomicAdd(&s_prof[(k)], _now - _tick); /* LDS, no return value: the tick does not stall the wave */ \
         _tick = _now;                                                                                        \
     } while (0)
 #define CAPE_TICK_INIT() unsigned long long _tick = __builtin_amdgcn_s_memtime()
+#define CAPE_TICK_RESTART() _tick = __builtin_amdgcn_s_memtime()
 #else
+#define CAPE_TICK_RESTART()
 #define CAPE_TICK(k)
 #define CAPE_TICK_INIT()
 #endif
@@ -245,6 +247,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
     double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64
+#ifdef CAPE_B_PROFILE
+    unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsPerWave - 8 * kProfileSlots);
+    if (lane < kProfileSlots)
+        s_prof[lane] = 0ull;
+#endif
     // centre-pixel depths of the boundary phase: C f32 = exactly the bytes of s_bins + s_list, both dead after the seed loop
     float* s_zc = reinterpret_cast<float*>(s_bins);
 
@@ -558,18 +565,22 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
             cc.s_idmask = s_idmask;
             cc.s_cur = s_cur;
             cc.s_best = s_best;
-            cc.scratch = p.cylScratch + cellBase * 6;
+            cc.scratch = p.cylScratch + cellBase * kCylStride;
             cc.s_stage = s_chunk;
             cc.s_seg = s_seg;
             cc.s_lab = s_lab;
             cc.s_cyl = s_cyl;
             cc.rec = p.records + frame;
-            cc.dbg = p.debugCycles + (size_t)frame * 16;
+#ifdef CAPE_B_PROFILE
+            cc.dbg = s_prof;
+#else
+            cc.dbg = nullptr;
+#endif
             bool planeOverflow = false;
             cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
             ++nCylFits;
             CAPE_WAVE_SYNC();
-            CAPE_TICK(8); // (cylinder phases are booked in slots 12..15)
+            CAPE_TICK_RESTART(); // the cylinder phases booked themselves in slots 12..15
             if (planeOverflow)
             {
                 status |= CAPE_FRAME_PLANE_OVERFLOW;
@@ -858,6 +869,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
         sum->status = status;
         sum->n_plane_segments = nSeg;
     }
+#ifdef CAPE_B_PROFILE
+    CAPE_WAVE_SYNC();
+    if (lane < kProfileSlots)
+        p.debugCycles[(size_t)frame * kProfileSlots + lane] = s_prof[lane];
+#endif
 }
 
 size_t grow_lds_bytes(int cells, bool cylinders)
@@ -872,7 +888,10 @@ size_t grow_lds_bytes(int cells, bool cylinders)
     b += (size_t)cells;                             // s_lab
     b += CAPE_MAX_PLANES;                           // s_mlab
     if (cylinders)
-        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8; // s_cyl, s_ids, masks, s_dist
+        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 64; // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
+#ifdef CAPE_B_PROFILE
+    b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots; // s_prof
+#endif
     return (b + 15) & ~(size_t)15;
 }
 

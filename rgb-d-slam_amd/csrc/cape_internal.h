@@ -17,6 +17,8 @@ namespace cape {
 //   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts) + centre depth
 //   cell_mse   [cells]     f64 : copy of the cell MSE, compact so the seed selection reads it coalesced
 constexpr int kSumStride = 10;
+constexpr int kProfileSlots = 32;   // phase counters per frame of a -DCAPE_B_PROFILE build (cape_debug_cycles)
+constexpr int kCylStride = 8;       // doubles per cell of the cylinder scratch: projected normal[3], projected centroid[3], their dot product, pad
 constexpr int kPlaneStride = 8;
 constexpr uint32_t kFlagPlanar = 1u << 31;
 constexpr uint32_t kFlagInorder = 1u << 30;
@@ -83,8 +85,8 @@ struct StageBParams
     const double* rngTable; // first rngCount doubles of uniform_real_distribution(mt19937(0)), random.hpp:17-30
     int rngCount;
     int ransacMaxIterations; // 43
-    double* cylScratch;      // [frames][cells][6] projected normals / centroids (only with CAPE_FLAG_CYLINDERS)
-    unsigned long long* debugCycles; // [frames][16] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
+    double* cylScratch;      // [frames][cells][kCylStride] projected normals / centroids / n.c (only with CAPE_FLAG_CYLINDERS)
+    unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
 };
 
 // N3: Depth_Map_Transformation::rectify_depth

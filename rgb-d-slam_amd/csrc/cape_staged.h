@@ -22,66 +22,128 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 // PIECES  : 16-byte pieces (double2) per record, 1..5
 // index(e): record number of element e (e.g. the activated-cell list), e in [0, N)
 // body(e, rec): called for e = 0..N-1 in order by ALL lanes (uniform); rec points at the 2*PIECES doubles in LDS
-template <int PIECES, typename IndexFn, typename Body>
-__device__ __forceinline__ void staged_for_each(int N, const double* base, int strideDoubles, int firstPiece, IndexFn index,
-                                                double* s_buf, int lane, Body body)
+//
+// Every lane moves its pieces UNCONDITIONALLY (indices clamped to the last element / last piece, so the surplus lanes
+// re-write a valid record into a slot nobody reads): predicated loads would put each one behind a divergent branch, and
+// the compiler's wait-count insertion then serialises them with `s_waitcnt vmcnt(0)` -- and would also wait for the
+// prefetched chunk before the first add of the current one.  For the same reason the caller's accumulators must not be
+// the destination of a still-pending global load: the entry drains the counters once.
+//
+// prep(c0, cn): called by all lanes right before the cn bodies of the chunk that starts at element c0 (e.g. to ballot a
+// per-element flag into a uniform mask, so that the bodies stay free of LDS look-ups and branches)
+template <int PIECES, typename IndexFn, typename Prep, typename Body>
+__device__ __forceinline__ void staged_for_each(int N_, const double* base, int strideDoubles, int firstPiece, IndexFn index,
+                                                double* s_buf, int lane, Prep prep, Body body)
 {
     constexpr int kPiecesPerChunk = kStageChunk * PIECES;
     constexpr int kPerLane = (kPiecesPerChunk + 63) / 64; // pieces each lane moves per chunk
     static_assert(PIECES >= 1 && PIECES <= 5 && kPerLane <= 5, "record / chunk too large for the staging registers");
-    double2 r0 = make_double2(0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
-
-#define CAPE_STAGE_SRC(q, c0_) \
-    (base + (size_t)index((c0_) + ((lane + 64 * (q)) / PIECES)) * strideDoubles + 2 * (firstPiece + ((lane + 64 * (q)) % PIECES)))
-#define CAPE_STAGE_DST(q) (s_buf + ((lane + 64 * (q)) / PIECES) * 2 * PIECES + 2 * ((lane + 64 * (q)) % PIECES))
-    auto issue = [&](int c0) {
-        const int np = ((N - c0 < kStageChunk) ? (N - c0) : kStageChunk) * PIECES;
-        if (lane < np)
-            r0 = *reinterpret_cast<const double2*>(CAPE_STAGE_SRC(0, c0));
-        if (kPerLane > 1 && lane + 64 < np)
-            r1 = *reinterpret_cast<const double2*>(CAPE_STAGE_SRC(1, c0));
-        if (kPerLane > 2 && lane + 128 < np)
-            r2 = *reinterpret_cast<const double2*>(CAPE_STAGE_SRC(2, c0));
-        if (kPerLane > 3 && lane + 192 < np)
-            r3 = *reinterpret_cast<const double2*>(CAPE_STAGE_SRC(3, c0));
-        if (kPerLane > 4 && lane + 256 < np)
-            r4 = *reinterpret_cast<const double2*>(CAPE_STAGE_SRC(4, c0));
-    };
-
-    if (N > 0)
-        issue(0);
-    for (int c0 = 0; c0 < N; c0 += kStageChunk)
-    {
+    // the element count is wave-uniform by contract; telling the compiler makes the loop control scalar, so the two
+    // exits below are real branches instead of exec-mask updates that funnel through one latch block
+    const int N = __builtin_amdgcn_readfirstlane(N_);
+    if (N <= 0)
+        return;
+    // named registers on purpose: an array captured by the lambda is not promoted out of scratch memory.
+    // Two register sets (A, B) = two chunks in flight while a third is being consumed from LDS.
+#define CAPE_STAGE_PIECE(q) ((lane + 64 * (q)) < kPiecesPerChunk ? (lane + 64 * (q)) : kPiecesPerChunk - 1)
+#define CAPE_STAGE_LOAD(q, c0_)                                                                                          \
+    *reinterpret_cast<const double2*>(                                                                                   \
+            base + (size_t)index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1) * \
+                           strideDoubles +                                                                               \
+            2 * (firstPiece + CAPE_STAGE_PIECE(q) % PIECES))
+#define CAPE_STAGE_DST(q) \
+    *reinterpret_cast<double2*>(s_buf + (CAPE_STAGE_PIECE(q) / PIECES) * 2 * PIECES + 2 * (CAPE_STAGE_PIECE(q) % PIECES))
+    double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
+    double2 b0 = a0, b1 = a0, b2 = a0, b3 = a0, b4 = a0;
+    // unconditional (clamped) on purpose, see above; at most two surplus chunks are fetched at the end of a call.
+    // The scheduling barriers keep the loads of one set together: the in-order vmcnt counter can only wait for "all
+    // but the k youngest", so interleaving the two sets would make every hand-over wait for both.
+#define CAPE_STAGE_ISSUE(S, c0_)              \
+    do                                        \
+    {                                         \
+        __builtin_amdgcn_sched_barrier(0);    \
+        S##0 = CAPE_STAGE_LOAD(0, c0_);       \
+        if (kPerLane > 1)                     \
+            S##1 = CAPE_STAGE_LOAD(1, c0_);   \
+        if (kPerLane > 2)                     \
+            S##2 = CAPE_STAGE_LOAD(2, c0_);   \
+        if (kPerLane > 3)                     \
+            S##3 = CAPE_STAGE_LOAD(3, c0_);   \
+        if (kPerLane > 4)                     \
+            S##4 = CAPE_STAGE_LOAD(4, c0_);   \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+#define CAPE_STAGE_STORE(S)                   \
+    do                                        \
+    {                                         \
+        CAPE_STAGE_DST(0) = S##0;             \
+        if (kPerLane > 1)                     \
+            CAPE_STAGE_DST(1) = S##1;         \
+        if (kPerLane > 2)                     \
+            CAPE_STAGE_DST(2) = S##2;         \
+        if (kPerLane > 3)                     \
+            CAPE_STAGE_DST(3) = S##3;         \
+        if (kPerLane > 4)                     \
+            CAPE_STAGE_DST(4) = S##4;         \
+    } while (0)
+    auto consume = [&](int c0) {
         const int cn = (N - c0 < kStageChunk) ? (N - c0) : kStageChunk;
-        const int np = cn * PIECES;
-        if (lane < np)
-            *reinterpret_cast<double2*>(CAPE_STAGE_DST(0)) = r0;
-        if (kPerLane > 1 && lane + 64 < np)
-            *reinterpret_cast<double2*>(CAPE_STAGE_DST(1)) = r1;
-        if (kPerLane > 2 && lane + 128 < np)
-            *reinterpret_cast<double2*>(CAPE_STAGE_DST(2)) = r2;
-        if (kPerLane > 3 && lane + 192 < np)
-            *reinterpret_cast<double2*>(CAPE_STAGE_DST(3)) = r3;
-        if (kPerLane > 4 && lane + 256 < np)
-            *reinterpret_cast<double2*>(CAPE_STAGE_DST(4)) = r4;
-        if (c0 + kStageChunk < N)
-            issue(c0 + kStageChunk);
         CAPE_STAGE_FENCE();
+        if (cn > 0)
+            prep(c0, cn);
         if (cn == kStageChunk)
         {
+#ifndef CAPE_STAGE_UNROLL
+#define CAPE_STAGE_UNROLL kStageChunk
+#endif
+            for (int cb = 0; cb < kStageChunk; cb += CAPE_STAGE_UNROLL)
+            {
 #pragma unroll
-            for (int ci = 0; ci < kStageChunk; ++ci)
-                body(c0 + ci, s_buf + ci * 2 * PIECES);
+                for (int u = 0; u < CAPE_STAGE_UNROLL; ++u)
+                    body(c0 + cb + u, s_buf + (cb + u) * 2 * PIECES);
+            }
         }
         else
         {
-            for (int ci = 0; ci < cn; ++ci)
+            int ci = 0;
+            for (; ci + 4 <= cn; ci += 4)
+            {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    body(c0 + ci + u, s_buf + (ci + u) * 2 * PIECES);
+            }
+            for (; ci < cn; ++ci)
                 body(c0 + ci, s_buf + ci * 2 * PIECES);
         }
         CAPE_STAGE_FENCE();
+    };
+
+    __builtin_amdgcn_s_waitcnt(0);
+    CAPE_STAGE_ISSUE(a, 0);
+    CAPE_STAGE_ISSUE(b, kStageChunk);
+    // one exit only, and no branch around the second half (consume() does nothing for an empty chunk): every path
+    // to the top of the loop carries "set a requested before set b", which is what the wait counts are derived from
+    for (int c0 = 0; c0 < N; c0 += 2 * kStageChunk)
+    {
+        CAPE_STAGE_STORE(a);
+        CAPE_STAGE_ISSUE(a, c0 + 2 * kStageChunk);
+        consume(c0);
+        CAPE_STAGE_STORE(b);
+        CAPE_STAGE_ISSUE(b, c0 + 3 * kStageChunk);
+        consume(c0 + kStageChunk);
     }
-#undef CAPE_STAGE_SRC
+#undef CAPE_STAGE_PIECE
+#undef CAPE_STAGE_LOAD
 #undef CAPE_STAGE_DST
+#undef CAPE_STAGE_ISSUE
+#undef CAPE_STAGE_STORE
+}
+
+template <int PIECES, typename IndexFn, typename Body>
+__device__ __forceinline__ void staged_for_each(int N, const double* base, int strideDoubles, int firstPiece, IndexFn index,
+                                                double* s_buf, int lane, Body body)
+{
+    staged_for_each<PIECES>(N, base, strideDoubles, firstPiece, index, s_buf, lane, [](int, int) {}, body);
 }
 
 } // namespace cape

@@ -246,7 +246,7 @@ class Extractor:
         return out
 
     def debug_cycles(self, n_frames):
-        out = np.zeros((n_frames, 16), np.uint64)
+        out = np.zeros((n_frames, 32), np.uint64)
         _check(self.L, self.L.cape_debug_cycles(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_debug_cycles")
         return out
 
