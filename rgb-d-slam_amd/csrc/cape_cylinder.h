@@ -173,7 +173,9 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             // records: (nx, ny, nz, d) of every activated cell, staged through LDS (2 pieces of cell_plane)
             staged_for_each<2>(
                     N, planeBase, kPlaneStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
-                    [&](int, const double* rec) { acc += rec[r] * rec[cc]; }); // (-a)*(-b) == a*b in the second half
+                    [&](int, const double* rec) { return rec[r] * rec[cc]; }, // (-a)*(-b) == a*b in the second half
+                    [&](int, double v) { acc += v; });
+            CAPE_CYL_TICK(28 + half); // covariance pass 1 / 2
         }
         cov6 = acc / (double)(2 * N - 1);
     }
@@ -329,6 +331,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
 
         // ===== LLS over all inliers, ascending i (:157-186): lanes 0-2 sumN, 3-5 sumC, 6 b
         double chain = 0.0;
+        static_assert(kStageChunk <= 32, "inlMask holds one bit per element of a chunk");
         unsigned inlMask = 0; // bit ci: element c0 + ci of the chunk being consumed is an inlier (uniform)
         auto ballotInliers = [&](int c0, int cn) {
             const int ci = lane & (kStageChunk - 1);
@@ -336,11 +339,10 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         };
         staged_for_each<4>(
                 N, c.scratch, kCylStride, 0, [&](int e) { return e; }, c.s_stage, lane, ballotInliers,
-                [&](int i, const double* t) {
-                    // lanes 0..5 take component `lane`, lane 6 the precomputed n.c product; a non-inlier adds +0.0, which
-                    // leaves the running sum unchanged bit for bit (the sum is never -0.0).  The operand is loaded
-                    // unconditionally: a load inside the selected arm would cost one LDS round trip per element.
-                    const double term = t[lane < 7 ? lane : 0];
+                // lanes 0..5 take component `lane`, lane 6 the precomputed n.c product; a non-inlier adds +0.0, which leaves
+                // the running sum unchanged bit for bit (the sum is never -0.0)
+                [&](int, const double* t) { return t[lane < 7 ? lane : 0]; },
+                [&](int i, double term) {
                     const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
                     chain += inl ? term : 0.0;
                 });
@@ -419,8 +421,8 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         double acc = 0.0; // Plane_Segment newMergedPlane: cleared sums
         staged_for_each<5>(
                 N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, ballotInliers,
-                [&](int i, const double* rec) {
-                    const double v = rec[ql];
+                [&](int, const double* rec) { return rec[ql]; },
+                [&](int i, double v) {
                     const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
                     acc += inl ? v : 0.0;
                 });

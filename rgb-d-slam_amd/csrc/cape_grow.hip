@@ -486,10 +486,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
         //      the point count.  The seed's own sums are counted twice (copy :325 + expand of the seed itself).
         CAPE_TICK(5); // list build
         const int ql = lane < 10 ? lane : 0;
-        double acc = sumsBase[(size_t)seed * kSumStride + ql];
+        // element 0 is the seed itself (0.0 + x == x exactly), so its sums travel with the first staged chunk instead of
+        // costing a memory round trip of their own
+        double acc = 0.0;
         staged_for_each<5>(
-                total, sumsBase, kSumStride, 0, [&](int e) { return (int)s_list[e]; }, s_chunk, lane,
-                [&](int, const double* rec) { acc += rec[ql]; });
+                total + 1, sumsBase, kSumStride, 0, [&](int e) { return e == 0 ? seed : (int)s_list[e - 1]; }, s_chunk, lane,
+                [&](int, const double* rec) { return rec[ql]; }, [&](int, double v) { acc += v; });
 
         CAPE_TICK(6); // ordered accumulation
         // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false

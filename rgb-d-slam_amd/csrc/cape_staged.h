@@ -21,7 +21,12 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 
 // PIECES  : 16-byte pieces (double2) per record, 1..5
 // index(e): record number of element e (e.g. the activated-cell list), e in [0, N)
-// body(e, rec): called for e = 0..N-1 in order by ALL lanes (uniform); rec points at the 2*PIECES doubles in LDS
+// load(e, rec) -> double : the lane's operand of element e, read from the record's 2*PIECES doubles in LDS (no side
+//                          effects; called for a whole group of elements before any of them is folded)
+// fold(e, v)             : the order-sensitive step (e.g. acc += v), called for e = 0..N-1 in order by ALL lanes
+// The split is what lets the LDS reads of sixteen elements be requested back to back while the dependent adds of the
+// previous sixteen run; a single body(e, rec) left that to the scheduler, which under register pressure emitted
+// read - wait - add per element (one LDS round trip each).
 //
 // Every lane moves its pieces UNCONDITIONALLY (indices clamped to the last element / last piece, so the surplus lanes
 // re-write a valid record into a slot nobody reads): predicated loads would put each one behind a divergent branch, and
@@ -31,9 +36,9 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 //
 // prep(c0, cn): called by all lanes right before the cn bodies of the chunk that starts at element c0 (e.g. to ballot a
 // per-element flag into a uniform mask, so that the bodies stay free of LDS look-ups and branches)
-template <int PIECES, typename IndexFn, typename Prep, typename Body>
+template <int PIECES, typename IndexFn, typename Prep, typename Load, typename Fold>
 __device__ __forceinline__ void staged_for_each(int N_, const double* base, int strideDoubles, int firstPiece, IndexFn index,
-                                                double* s_buf, int lane, Prep prep, Body body)
+                                                double* s_buf, int lane, Prep prep, Load load, Fold fold)
 {
     constexpr int kPiecesPerChunk = kStageChunk * PIECES;
     constexpr int kPerLane = (kPiecesPerChunk + 63) / 64; // pieces each lane moves per chunk
@@ -93,27 +98,39 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
             prep(c0, cn);
         if (cn == kStageChunk)
         {
-#ifndef CAPE_STAGE_UNROLL
-#define CAPE_STAGE_UNROLL kStageChunk
-#endif
-            for (int cb = 0; cb < kStageChunk; cb += CAPE_STAGE_UNROLL)
-            {
+            constexpr int kHalf = kStageChunk / 2;
+            double v0[kHalf], v1[kHalf];
 #pragma unroll
-                for (int u = 0; u < CAPE_STAGE_UNROLL; ++u)
-                    body(c0 + cb + u, s_buf + (cb + u) * 2 * PIECES);
-            }
+            for (int u = 0; u < kHalf; ++u)
+                v0[u] = load(c0 + u, s_buf + u * 2 * PIECES);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u)
+                v1[u] = load(c0 + kHalf + u, s_buf + (kHalf + u) * 2 * PIECES);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u)
+                fold(c0 + u, v0[u]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u)
+                fold(c0 + kHalf + u, v1[u]);
         }
         else
         {
             int ci = 0;
             for (; ci + 4 <= cn; ci += 4)
             {
+                double v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    body(c0 + ci + u, s_buf + (ci + u) * 2 * PIECES);
+                    v[u] = load(c0 + ci + u, s_buf + (ci + u) * 2 * PIECES);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    fold(c0 + ci + u, v[u]);
             }
             for (; ci < cn; ++ci)
-                body(c0 + ci, s_buf + ci * 2 * PIECES);
+                fold(c0 + ci, load(c0 + ci, s_buf + ci * 2 * PIECES));
         }
         CAPE_STAGE_FENCE();
     };
@@ -139,11 +156,11 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
 #undef CAPE_STAGE_STORE
 }
 
-template <int PIECES, typename IndexFn, typename Body>
+template <int PIECES, typename IndexFn, typename Load, typename Fold>
 __device__ __forceinline__ void staged_for_each(int N, const double* base, int strideDoubles, int firstPiece, IndexFn index,
-                                                double* s_buf, int lane, Body body)
+                                                double* s_buf, int lane, Load load, Fold fold)
 {
-    staged_for_each<PIECES>(N, base, strideDoubles, firstPiece, index, s_buf, lane, [](int, int) {}, body);
+    staged_for_each<PIECES>(N, base, strideDoubles, firstPiece, index, s_buf, lane, [](int, int) {}, load, fold);
 }
 
 } // namespace cape
