@@ -12,7 +12,7 @@ from cape_amd import Extractor, synth
 NAMES = ["hist prologue", "edge masks", "argmax+cands", "seed pick", "propagation", "list build", "ordered accum",
          "hist removal", "region fit", "seed-loop tail", "merge", "boundary+records", "cyl: cov+eigen", "cyl: projection", "cyl: RANSAC", "",
          "cyl: LLS ordered pass", "cyl: ids compaction", "cyl: MSE distances", "cyl: MSE ordered sum", "cyl: plane sums pass",
-         "cyl: plane fit", "cyl: select+labels", "", "#RANSAC rounds", "#cells in region", "#inliers", "#hypotheses", "cyl: cov pass 1", "cyl: cov pass 2", "", ""]
+         "cyl: plane fit", "cyl: select+labels", "cov staged: consume + other sets", "#RANSAC rounds", "#cells in region", "#inliers", "#hypotheses", "cyl: cov pass 1", "cyl: cov pass 2", "cov staged: hand-over of set a (vmcnt wait)", "cov staged: request of set a"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 scene = sys.argv[2] if len(sys.argv) > 2 else "room"
 u = synth.stream(scene, seed=100, n_frames=16)
@@ -22,7 +22,7 @@ cyl = len(sys.argv) > 3 and sys.argv[3] == "cyl"
 ex = Extractor(640, 480, max_batch=B, cylinders=cyl, **intr)
 ex.extract_device(d.data_ptr(), B, torch.cuda.current_stream().cuda_stream)
 cyc = ex.debug_cycles(B).astype(np.float64)
-tot = cyc[:, :23].sum(1) + cyc[:, 28:30].sum(1)
+tot = cyc[:, :23].sum(1) + cyc[:, 28:30].sum(1)  # slots 23, 30, 31 are sub-intervals of the covariance passes
 print(f"frames {B}: mean ticks/frame {tot.mean():.0f} (s_memtime = shader clock, ~2.3 GHz => {tot.mean() / 2300:.1f} us)  seeds/frame {ex.results(B, False).records['header']['n_seeds'].mean():.1f}")
 for k, nm in enumerate(NAMES):
     if nm.startswith("#"):

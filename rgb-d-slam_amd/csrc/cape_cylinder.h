@@ -73,11 +73,19 @@ struct CylCtx
     unsigned long long* dbg;      // per-frame phase ticks (profiling builds)
 };
 
-// The RANSAC distance pass streams the remaining cells four rounds (256 cells) at a time: the twelve 16-byte loads of
-// a trip are all requested before the first distance is computed, so a trip costs one memory round trip instead of four
+// The RANSAC distance pass.  The cells a lane evaluates (idsLeft[lane + 64 k]) do not change during one
+// run_ransac_loop, so with up to kCylCacheRounds x 64 cells left (the whole 640x480 grid) their six projected coordinates
+// are fetched ONCE into registers and every hypothesis is scored from there: the per-frame scratch (N x 64 B) would
+// otherwise be streamed once per hypothesis by every resident wave, which overflows the 4 MB L2 of an XCD (measured:
+// 48 % L2 misses, and more resident waves made the kernel slower).  The cylinder variant is built for one wave per
+// SIMD (its LDS footprint admits no more), so the 144 cache registers cost no occupancy.  Larger grids stream the cells
+// four rounds at a time, all twelve 16-byte loads of a trip requested before the first distance is computed.
+constexpr int kCylCacheRounds = 12;
+#define CAPE_CYL_ROUNDS(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
 #define CAPE_CYL_TRIP(F) F(0) F(1) F(2) F(3)
-#define CAPE_CYL_DECL(k) double2 cqa##k, cqb##k, cqc##k; int cqi##k;
+#define CAPE_CYL_DECL(k) double2 cqa##k = make_double2(0, 0), cqb##k = cqa##k, cqc##k = cqa##k; int cqi##k = 0;
 #define CAPE_CYL_FETCH(k)                                                                                    \
+    if (j0 + 64 * (k) < m)                                                                                   \
     {                                                                                                        \
         const int jj_ = j0 + lane + 64 * (k);                                                                \
         cqi##k = c.s_ids[jj_ < m ? jj_ : 0];                                                                 \
@@ -87,6 +95,7 @@ struct CylCtx
         cqc##k = t_[2];                                                                                      \
     }
 #define CAPE_CYL_SCORE(k)                                                                                    \
+    if (j0 + 64 * (k) < m)                                                                                   \
     {                                                                                                        \
         bool inl_;                                                                                           \
         const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
@@ -97,6 +106,7 @@ struct CylCtx
         }                                                                                                    \
     }
 #define CAPE_CYL_PARK(k)                                                                                     \
+    if (j0 + 64 * (k) < m)                                                                                   \
     {                                                                                                        \
         bool inl_;                                                                                           \
         const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
@@ -117,31 +127,31 @@ __device__ __forceinline__ int cyl_wave_sum(int v)
 
 // init-less ordered sum s[0] + s[1] + ... + s[n-1] (ascending, one rounding per add, like the reference's loops) of
 // NON-NEGATIVE addends parked in LDS.  The running sum of non-negative terms never decreases, so the scan may stop as
-// soon as it reaches `limit`: the caller only needs to know that the total is >= limit then.  Eight elements per
-// trip with the next eight already requested, so the LDS latency hides behind the dependent adds.  `s` is 16-byte
-// aligned and readable up to s[n + 7].
-__device__ __forceinline__ double ordered_sum_lds(const double* s, int n, double limit)
+// soon as it reaches `limit`: the caller only needs to know that the total is >= limit then.  Sixteen elements per
+// trip with the next sixteen already requested, so the LDS latency hides behind the dependent adds.  `s` is 16-byte
+// aligned and readable up to s[n + 15].
+__device__ __forceinline__ double ordered_sum_lds(const double* s, int n_, double limit)
 {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
     double sum = 0.0;
     int j = 0;
-    if (n >= 8)
+    if (n >= 16)
     {
         const double2* v = reinterpret_cast<const double2*>(s);
-        double2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-        for (; j + 8 <= n; j += 8)
+        double2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+        for (; j + 16 <= n; j += 16)
         {
-            const double2 b0 = v[j / 2 + 4], b1 = v[j / 2 + 5], b2 = v[j / 2 + 6], b3 = v[j / 2 + 7];
-            sum += a0.x;
-            sum += a0.y;
-            sum += a1.x;
-            sum += a1.y;
-            sum += a2.x;
-            sum += a2.y;
-            sum += a3.x;
-            sum += a3.y;
+            // the next sixteen are requested before the sixteen dependent adds (the barrier keeps the scheduler from
+            // sinking the reads next to their uses, which would expose one LDS round trip per pair)
+            const double2* w = v + j / 2 + 8;
+            const double2 b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3], b4 = w[4], b5 = w[5], b6 = w[6], b7 = w[7];
+            __builtin_amdgcn_sched_barrier(0);
+            sum += a0.x; sum += a0.y; sum += a1.x; sum += a1.y; sum += a2.x; sum += a2.y; sum += a3.x; sum += a3.y;
+            sum += a4.x; sum += a4.y; sum += a5.x; sum += a5.y; sum += a6.x; sum += a6.y; sum += a7.x; sum += a7.y;
+            __builtin_amdgcn_sched_barrier(0);
             if (sum >= limit)
                 return sum;
-            a0 = b0, a1 = b1, a2 = b2, a3 = b3;
+            a0 = b0, a1 = b1, a2 = b2, a3 = b3, a4 = b4, a5 = b5, a6 = b6, a7 = b7;
         }
     }
     for (; j < n; ++j)
@@ -171,10 +181,11 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         for (int half = 0; half < 2; ++half)
         {
             // records: (nx, ny, nz, d) of every activated cell, staged through LDS (2 pieces of cell_plane)
-            staged_for_each<2>(
-                    N, planeBase, kPlaneStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane,
-                    [&](int, const double* rec) { return rec[r] * rec[cc]; }, // (-a)*(-b) == a*b in the second half
-                    [&](int, double v) { acc += v; });
+            staged_for_each<2, CAPE_STAGE_DEPTH_CYL>(
+                    N, planeBase, kPlaneStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, [](int, int) {},
+                    [&](int, const double* rec) { return make_double2(rec[r], rec[cc]); },
+                    [&](int, double2 v) { acc += v.x * v.y; }, // (-a)*(-b) == a*b in the second half
+                    c.dbg);
             CAPE_CYL_TICK(28 + half); // covariance pass 1 / 2
         }
         cov6 = acc / (double)(2 * N - 1);
@@ -232,6 +243,13 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             int prevBestCount = 0; // size of the vector swapped out of finalInlierIndexes
             for (int j = lane; j < N; j += 64)
                 c.s_best[j] = 0;
+            const bool cached = m <= 64 * kCylCacheRounds;
+            CAPE_CYL_ROUNDS(CAPE_CYL_DECL)
+            if (cached)
+            {
+                constexpr int j0 = 0;
+                CAPE_CYL_ROUNDS(CAPE_CYL_FETCH)
+            }
             for (int it = 0; it < p.ransacMaxIterations; ++it)
             {
                 int id[3];
@@ -281,11 +299,18 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 };
                 int curLocal = 0;
                 double psum = 0.0;
-                for (int j0 = 0; j0 < m; j0 += 256)
+                if (cached)
                 {
-                    CAPE_CYL_TRIP(CAPE_CYL_DECL)
-                    CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                    CAPE_CYL_TRIP(CAPE_CYL_SCORE)
+                    constexpr int j0 = 0;
+                    CAPE_CYL_ROUNDS(CAPE_CYL_SCORE)
+                }
+                else
+                {
+                    for (int j0 = 0; j0 < m; j0 += 256)
+                    {
+                        CAPE_CYL_TRIP(CAPE_CYL_FETCH)
+                        CAPE_CYL_TRIP(CAPE_CYL_SCORE)
+                    }
                 }
                 const int curCount = cyl_wave_sum(curLocal);
 #pragma unroll
@@ -294,11 +319,18 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 double dist = minHyp;
                 if (!(psum * (1.0 - 0x1p-40) >= minHyp))
                 {
-                    for (int j0 = 0; j0 < m; j0 += 256)
+                    if (cached)
                     {
-                        CAPE_CYL_TRIP(CAPE_CYL_DECL)
-                        CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                        CAPE_CYL_TRIP(CAPE_CYL_PARK)
+                        constexpr int j0 = 0;
+                        CAPE_CYL_ROUNDS(CAPE_CYL_PARK)
+                    }
+                    else
+                    {
+                        for (int j0 = 0; j0 < m; j0 += 256)
+                        {
+                            CAPE_CYL_TRIP(CAPE_CYL_FETCH)
+                            CAPE_CYL_TRIP(CAPE_CYL_PARK)
+                        }
                     }
                     CAPE_CYL_SYNC();
                     dist = ordered_sum_lds(c.s_dist, m, minHyp);
@@ -337,7 +369,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             const int ci = lane & (kStageChunk - 1);
             inlMask = (unsigned)__ballot(lane < kStageChunk && ci < cn && c.s_best[c0 + ci] != 0);
         };
-        staged_for_each<4>(
+        staged_for_each<4, CAPE_STAGE_DEPTH_CYL>(
                 N, c.scratch, kCylStride, 0, [&](int e) { return e; }, c.s_stage, lane, ballotInliers,
                 // lanes 0..5 take component `lane`, lane 6 the precomputed n.c product; a non-inlier adds +0.0, which leaves
                 // the running sum unchanged bit for bit (the sum is never -0.0)
@@ -419,7 +451,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
         const int ql = lane < 10 ? lane : 0;
         double acc = 0.0; // Plane_Segment newMergedPlane: cleared sums
-        staged_for_each<5>(
+        staged_for_each<5, CAPE_STAGE_DEPTH_CYL>(
                 N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, ballotInliers,
                 [&](int, const double* rec) { return rec[ql]; },
                 [&](int i, double v) {

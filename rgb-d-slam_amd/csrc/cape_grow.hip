@@ -218,7 +218,7 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
 }
 
 template <typename MaskT, bool CYL>
-__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
+__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 2 : 3) void cape_grow_ke
         // element 0 is the seed itself (0.0 + x == x exactly), so its sums travel with the first staged chunk instead of
         // costing a memory round trip of their own
         double acc = 0.0;
-        staged_for_each<5>(
+        staged_for_each<5, CAPE_STAGE_DEPTH_MAIN>(
                 total + 1, sumsBase, kSumStride, 0, [&](int e) { return e == 0 ? seed : (int)s_list[e - 1]; }, s_chunk, lane,
                 [&](int, const double* rec) { return rec[ql]; }, [&](int, double v) { acc += v; });
 
@@ -890,7 +890,7 @@ size_t grow_lds_bytes(int cells, bool cylinders)
     b += (size_t)cells;                             // s_lab
     b += CAPE_MAX_PLANES;                           // s_mlab
     if (cylinders)
-        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 64; // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
+        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 128; // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots; // s_prof
 #endif

@@ -17,16 +17,24 @@ namespace cape {
 #endif
 constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buffer must hold kStageChunk * 2 * PIECES doubles
 
+// chunks in flight: the plane-only grow kernel runs three waves per SIMD and has ~20 registers to spare, the cylinder
+// variant one wave per SIMD and plenty
+#ifndef CAPE_STAGE_DEPTH_MAIN
+#define CAPE_STAGE_DEPTH_MAIN 2
+#endif
+#ifndef CAPE_STAGE_DEPTH_CYL
+#define CAPE_STAGE_DEPTH_CYL 2
+#endif
 #define CAPE_STAGE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
 // PIECES  : 16-byte pieces (double2) per record, 1..5
 // index(e): record number of element e (e.g. the activated-cell list), e in [0, N)
-// load(e, rec) -> double : the lane's operand of element e, read from the record's 2*PIECES doubles in LDS (no side
-//                          effects; called for a whole group of elements before any of them is folded)
+// load(e, rec) -> value  : the lane's operand(s) of element e, plain reads of the record's 2*PIECES doubles in LDS (no
+//                          arithmetic, no side effects; called for a whole group of elements before any is folded)
 // fold(e, v)             : the order-sensitive step (e.g. acc += v), called for e = 0..N-1 in order by ALL lanes
-// The split is what lets the LDS reads of sixteen elements be requested back to back while the dependent adds of the
-// previous sixteen run; a single body(e, rec) left that to the scheduler, which under register pressure emitted
-// read - wait - add per element (one LDS round trip each).
+// The split is what lets the LDS reads of eight elements be requested back to back while the dependent adds of the
+// previous eight run; a single body(e, rec) left that to the scheduler, which emitted read - wait - use per element
+// (one LDS round trip each) -- and it does the same inside load() if load() computes on what it reads.
 //
 // Every lane moves its pieces UNCONDITIONALLY (indices clamped to the last element / last piece, so the surplus lanes
 // re-write a valid record into a slot nobody reads): predicated loads would put each one behind a divergent branch, and
@@ -36,20 +44,23 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 //
 // prep(c0, cn): called by all lanes right before the cn bodies of the chunk that starts at element c0 (e.g. to ballot a
 // per-element flag into a uniform mask, so that the bodies stay free of LDS look-ups and branches)
-template <int PIECES, typename IndexFn, typename Prep, typename Load, typename Fold>
+// DEPTH (2..4): chunks requested ahead of the one being consumed; each costs ceil(32 * PIECES / 64) double2 registers.
+template <int PIECES, int DEPTH, typename IndexFn, typename Prep, typename Load, typename Fold>
 __device__ __forceinline__ void staged_for_each(int N_, const double* base, int strideDoubles, int firstPiece, IndexFn index,
-                                                double* s_buf, int lane, Prep prep, Load load, Fold fold)
+                                                double* s_buf, int lane, Prep prep, Load load, Fold fold,
+                                                unsigned long long* prof = nullptr)
 {
     constexpr int kPiecesPerChunk = kStageChunk * PIECES;
     constexpr int kPerLane = (kPiecesPerChunk + 63) / 64; // pieces each lane moves per chunk
     static_assert(PIECES >= 1 && PIECES <= 5 && kPerLane <= 5, "record / chunk too large for the staging registers");
+    static_assert(DEPTH >= 2 && DEPTH <= 4, "two to four chunks in flight");
     // the element count is wave-uniform by contract; telling the compiler makes the loop control scalar, so the two
     // exits below are real branches instead of exec-mask updates that funnel through one latch block
     const int N = __builtin_amdgcn_readfirstlane(N_);
     if (N <= 0)
         return;
     // named registers on purpose: an array captured by the lambda is not promoted out of scratch memory.
-    // Two register sets (A, B) = two chunks in flight while a third is being consumed from LDS.
+    // DEPTH register sets (a, b, c, d) = DEPTH chunks in flight while one more is being consumed from LDS.
 #define CAPE_STAGE_PIECE(q) ((lane + 64 * (q)) < kPiecesPerChunk ? (lane + 64 * (q)) : kPiecesPerChunk - 1)
 #define CAPE_STAGE_LOAD(q, c0_)                                                                                          \
     *reinterpret_cast<const double2*>(                                                                                   \
@@ -60,22 +71,24 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
     *reinterpret_cast<double2*>(s_buf + (CAPE_STAGE_PIECE(q) / PIECES) * 2 * PIECES + 2 * (CAPE_STAGE_PIECE(q) % PIECES))
     double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
     double2 b0 = a0, b1 = a0, b2 = a0, b3 = a0, b4 = a0;
+    double2 g0 = a0, g1 = a0, g2 = a0, g3 = a0, g4 = a0;
+    double2 d0 = a0, d1 = a0, d2 = a0, d3 = a0, d4 = a0;
     // unconditional (clamped) on purpose, see above; at most two surplus chunks are fetched at the end of a call.
     // The scheduling barriers keep the loads of one set together: the in-order vmcnt counter can only wait for "all
     // but the k youngest", so interleaving the two sets would make every hand-over wait for both.
-#define CAPE_STAGE_ISSUE(S, c0_)              \
+#define CAPE_STAGE_ISSUE(S, at_)              \
     do                                        \
     {                                         \
         __builtin_amdgcn_sched_barrier(0);    \
-        S##0 = CAPE_STAGE_LOAD(0, c0_);       \
+        S##0 = CAPE_STAGE_LOAD(0, at_);       \
         if (kPerLane > 1)                     \
-            S##1 = CAPE_STAGE_LOAD(1, c0_);   \
+            S##1 = CAPE_STAGE_LOAD(1, at_);   \
         if (kPerLane > 2)                     \
-            S##2 = CAPE_STAGE_LOAD(2, c0_);   \
+            S##2 = CAPE_STAGE_LOAD(2, at_);   \
         if (kPerLane > 3)                     \
-            S##3 = CAPE_STAGE_LOAD(3, c0_);   \
+            S##3 = CAPE_STAGE_LOAD(3, at_);   \
         if (kPerLane > 4)                     \
-            S##4 = CAPE_STAGE_LOAD(4, c0_);   \
+            S##4 = CAPE_STAGE_LOAD(4, at_);   \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 #define CAPE_STAGE_STORE(S)                   \
@@ -98,33 +111,51 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
             prep(c0, cn);
         if (cn == kStageChunk)
         {
-            constexpr int kHalf = kStageChunk / 2;
-            double v0[kHalf], v1[kHalf];
+            // groups of kGroup elements: the LDS reads of group g + 1 are all requested (scheduling barrier) before the
+            // dependent folds of group g run, so one LDS round trip overlaps kGroup chain steps
+            constexpr int kGroup = 8;
+            constexpr int kGroups = kStageChunk / kGroup;
+            static_assert(kStageChunk % (2 * kGroup) == 0, "chunk = even number of groups");
+            using Value = decltype(load(0, s_buf));
+            Value va[kGroup], vb[kGroup];
 #pragma unroll
-            for (int u = 0; u < kHalf; ++u)
-                v0[u] = load(c0 + u, s_buf + u * 2 * PIECES);
+            for (int u = 0; u < kGroup; ++u)
+                va[u] = load(c0 + u, s_buf + u * 2 * PIECES);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kHalf; ++u)
-                v1[u] = load(c0 + kHalf + u, s_buf + (kHalf + u) * 2 * PIECES);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < kGroups; g += 2)
+            {
 #pragma unroll
-            for (int u = 0; u < kHalf; ++u)
-                fold(c0 + u, v0[u]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < kGroup; ++u)
+                    vb[u] = load(c0 + (g + 1) * kGroup + u, s_buf + ((g + 1) * kGroup + u) * 2 * PIECES);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kHalf; ++u)
-                fold(c0 + kHalf + u, v1[u]);
+                for (int u = 0; u < kGroup; ++u)
+                    fold(c0 + g * kGroup + u, va[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < kGroups)
+                {
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u)
+                        va[u] = load(c0 + (g + 2) * kGroup + u, s_buf + ((g + 2) * kGroup + u) * 2 * PIECES);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < kGroup; ++u)
+                    fold(c0 + (g + 1) * kGroup + u, vb[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         else
         {
             int ci = 0;
             for (; ci + 4 <= cn; ci += 4)
             {
-                double v[4];
+                decltype(load(0, s_buf)) v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     v[u] = load(c0 + ci + u, s_buf + (ci + u) * 2 * PIECES);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     fold(c0 + ci + u, v[u]);
@@ -138,17 +169,51 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
     __builtin_amdgcn_s_waitcnt(0);
     CAPE_STAGE_ISSUE(a, 0);
     CAPE_STAGE_ISSUE(b, kStageChunk);
-    // one exit only, and no branch around the second half (consume() does nothing for an empty chunk): every path
-    // to the top of the loop carries "set a requested before set b", which is what the wait counts are derived from
-    for (int c0 = 0; c0 < N; c0 += 2 * kStageChunk)
+    if (DEPTH >= 3)
+        CAPE_STAGE_ISSUE(g, 2 * kStageChunk);
+    if (DEPTH >= 4)
+        CAPE_STAGE_ISSUE(d, 3 * kStageChunk);
+    // one exit only, and no branch around the later sets (consume() does nothing for an empty chunk): every path to the
+    // top of the loop carries the sets in the order a, b, g, d, which is what the wait counts are derived from
+#ifdef CAPE_B_PROFILE
+#define CAPE_STAGE_T(k)                                                   \
+    if (prof)                                                             \
+    {                                                                     \
+        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) only */         \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();       \
+        if (lane == 0)                                                    \
+            atomicAdd(&prof[k], n_ - pt_);                                \
+        pt_ = n_;                                                         \
+    }
+    unsigned long long pt_ = __builtin_amdgcn_s_memtime();
+#else
+#define CAPE_STAGE_T(k)
+#endif
+    for (int c0 = 0; c0 < N; c0 += DEPTH * kStageChunk)
     {
+        CAPE_STAGE_T(23)
         CAPE_STAGE_STORE(a);
-        CAPE_STAGE_ISSUE(a, c0 + 2 * kStageChunk);
+        CAPE_STAGE_T(30)
+        CAPE_STAGE_ISSUE(a, c0 + DEPTH * kStageChunk);
+        CAPE_STAGE_T(31)
         consume(c0);
         CAPE_STAGE_STORE(b);
-        CAPE_STAGE_ISSUE(b, c0 + 3 * kStageChunk);
+        CAPE_STAGE_ISSUE(b, c0 + (DEPTH + 1) * kStageChunk);
         consume(c0 + kStageChunk);
+        if (DEPTH >= 3)
+        {
+            CAPE_STAGE_STORE(g);
+            CAPE_STAGE_ISSUE(g, c0 + (DEPTH + 2) * kStageChunk);
+            consume(c0 + 2 * kStageChunk);
+        }
+        if (DEPTH >= 4)
+        {
+            CAPE_STAGE_STORE(d);
+            CAPE_STAGE_ISSUE(d, c0 + (DEPTH + 3) * kStageChunk);
+            consume(c0 + 3 * kStageChunk);
+        }
     }
+#undef CAPE_STAGE_T
 #undef CAPE_STAGE_PIECE
 #undef CAPE_STAGE_LOAD
 #undef CAPE_STAGE_DST
@@ -156,11 +221,11 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
 #undef CAPE_STAGE_STORE
 }
 
-template <int PIECES, typename IndexFn, typename Load, typename Fold>
+template <int PIECES, int DEPTH, typename IndexFn, typename Load, typename Fold>
 __device__ __forceinline__ void staged_for_each(int N, const double* base, int strideDoubles, int firstPiece, IndexFn index,
                                                 double* s_buf, int lane, Load load, Fold fold)
 {
-    staged_for_each<PIECES>(N, base, strideDoubles, firstPiece, index, s_buf, lane, [](int, int) {}, load, fold);
+    staged_for_each<PIECES, DEPTH>(N, base, strideDoubles, firstPiece, index, s_buf, lane, [](int, int) {}, load, fold);
 }
 
 } // namespace cape
