@@ -56,6 +56,14 @@ struct cape_handle_s
     float* ratioRow = nullptr;
     double* rng = nullptr;
     double* cylScratch = nullptr;
+    uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
+    // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
+    // (never waited for) before the next call; above kSinglePassAbove of the frames the plane-only pass is not worth it
+    uint32_t* handedOverHost = nullptr;
+    hipEvent_t handedOverReady = nullptr;
+    int handedOverFrames = 0;  // frames of the call the pending count belongs to (0: nothing pending)
+    bool singlePass = false;
+    int callsSinceProbe = 0;
     unsigned long long* debugCycles = nullptr;
     // rectify_depth (N3): float copies of the back-projection factors + collision keys (allocated on first use)
     float* xpre = nullptr;
@@ -134,6 +142,11 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->ratioRow);
     (void)hipFree(h->rng);
     (void)hipFree(h->cylScratch);
+    (void)hipFree(h->needCylinder);
+    if (h->handedOverHost)
+        (void)hipHostFree(h->handedOverHost);
+    if (h->handedOverReady)
+        (void)hipEventDestroy(h->handedOverReady);
     (void)hipFree(h->debugCycles);
     (void)hipFree(h->xpre);
     (void)hipFree(h->ypre);
@@ -208,6 +221,8 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     b.boundary += F * (size_t)h->boundaryCap * 3;
     if (b.cylScratch)
         b.cylScratch += F * C * cape::kCylStride;
+    if (b.needCylinder)
+        b.needCylinder += 2 * F; // a sub-batch of n frames uses 1 + n entries of its own
     b.debugCycles += F * cape::kProfileSlots;
 }
 
@@ -258,7 +273,28 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     cape::launch_cell_plane(a, frames, st);
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
-    cape::launch_grow(b, frames, st);
+    cape::StageBParams bb = b;
+    if (bb.needCylinder)
+    {
+        constexpr double kSinglePassAbove = 0.6;
+        constexpr int kProbeEvery = 32; // a single-pass handle re-measures with a two-pass call now and then
+        if (h->handedOverFrames > 0 && hipEventQuery(h->handedOverReady) == hipSuccess)
+        {
+            h->singlePass = (double)*h->handedOverHost > kSinglePassAbove * (double)h->handedOverFrames;
+            h->handedOverFrames = 0;
+        }
+        const bool probe = h->singlePass && ++h->callsSinceProbe >= kProbeEvery;
+        bb.twoPass = (!h->singlePass || probe) ? 1 : 0;
+        if (probe)
+            h->callsSinceProbe = 0;
+    }
+    cape::launch_grow(bb, frames, st);
+    if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0)
+    {
+        CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost, bb.needCylinder, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CAPE_HIP_TRY(hipEventRecord(h->handedOverReady, st));
+        h->handedOverFrames = frames;
+    }
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[3], st));
     return CAPE_OK;
@@ -347,7 +383,12 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellAux, B * C));
     CAPE_ALLOC(dalloc(h->cellMse, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
+    {
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * cape::kCylStride));
+        CAPE_ALLOC(dalloc(h->needCylinder, 2 * B + 2));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), sizeof(uint32_t)));
+        CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
+    }
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     CAPE_ALLOC(dalloc(h->records, B));
@@ -463,6 +504,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.planeSeedCount = static_cast<int>(static_cast<unsigned>((0.8 / 100.0) * h->cells));
     b.minCellActivated = static_cast<int>(static_cast<unsigned>((0.65 / 100.0) * h->cells));
     b.cylScratch = h->cylScratch;
+    b.needCylinder = h->needCylinder;
+    b.twoPass = h->needCylinder ? 1 : 0;
     b.debugCycles = h->debugCycles;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;

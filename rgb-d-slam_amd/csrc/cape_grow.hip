@@ -223,9 +223,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int frame = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    int frame = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (frame >= nFrames)
         return; // whole wave leaves; there is no workgroup barrier in this kernel
+    if (CYL && p.twoPass)
+    {
+        // second pass of the two-pass schedule: wave k takes the k-th frame the plane-only pass gave up on
+        if (frame >= (int)p.needCylinder[0])
+            return;
+        frame = (int)p.needCylinder[1 + frame];
+    }
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     const int C = p.cells, HC = p.hCells, VC = p.vCells;
     const size_t cellBase = (size_t)frame * C;
@@ -551,6 +558,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
             for (int i = lane; i < total; i += 64)
                 s_lab[s_list[i]] = (unsigned char)nSeg;
             CAPE_WAVE_SYNC();
+        }
+        else if (!CYL && p.twoPass && total > 5)
+        {
+            // first pass of the two-pass schedule: this region goes to cylinder_fitting, which the plane-only kernel does
+            // not carry -- hand the whole frame to the cylinder kernel (it starts over; nothing written so far counts)
+            if (lane == 0)
+                p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
+            return;
         }
         else if (CYL && total > 5)
         {
@@ -918,29 +933,49 @@ int grow_waves_per_cu(const StageBParams& p)
     return e == hipSuccess ? blocks * wpg : 0;
 }
 
-void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
+namespace {
+
+template <bool CYL>
+void launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 {
-    const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
-    const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl);
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL);
     int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the 160 KB of LDS admit (<= kWavesPerGroup)
     while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
         --wpg;
     const size_t lds = (size_t)ldsPerWave * wpg;
     const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
-    {
-        if (cyl)
-            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, true>), grid, block, lds, stream, p, nFrames, ldsPerWave);
-        else
-            hipLaunchKernelGGL((cape_grow_kernel<uint32_t, false>), grid, block, lds, stream, p, nFrames, ldsPerWave);
-    }
+        hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     else
+        hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+}
+
+} // namespace
+
+// With cylinders enabled the kernel that carries cylinder_fitting holds one wave per SIMD (four frames per CU) against
+// twelve for the plane-only kernel, and most frames of most scenes never take the cylinder branch.  So every frame is
+// first grown by the plane-only kernel; a frame whose seed loop reaches a cylinder-candidate region (score <= 100 and
+// more than 5 cells, primitive_detection.cpp:385-388) is abandoned there and appended to a list, and the cylinder kernel
+// -- launched for the worst case, wave k takes the k-th listed frame, the others leave at once -- redoes exactly those
+// frames from the start (densely packed: a workgroup of the cylinder kernel owns 60 % of a CU's LDS, so idle waves in
+// it would cost real occupancy).  A frame that never
+// takes the branch is bit-identical in both kernels (the branch is their only difference).
+void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
+{
+    const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    if (!cyl)
     {
-        if (cyl)
-            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, true>), grid, block, lds, stream, p, nFrames, ldsPerWave);
-        else
-            hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, false>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+        launch_grow_variant<false>(p, nFrames, stream);
+        return;
     }
+    if (!p.twoPass)
+    {
+        launch_grow_variant<true>(p, nFrames, stream); // nearly every frame needs it anyway: skip the plane-only pass
+        return;
+    }
+    (void)hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream); // [0] = number of handed-over frames, [1..] = which
+    launch_grow_variant<false>(p, nFrames, stream);
+    launch_grow_variant<true>(p, nFrames, stream);
 }
 
 } // namespace cape

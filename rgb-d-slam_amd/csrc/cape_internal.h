@@ -86,6 +86,11 @@ struct StageBParams
     int rngCount;
     int ransacMaxIterations; // 43
     double* cylScratch;      // [frames][cells][kCylStride] projected normals / centroids / n.c (only with CAPE_FLAG_CYLINDERS)
+    // Two-pass scheduling of the cylinder variant (see launch_grow): the plane-only kernel runs first on every frame and
+    // appends a frame to the list needCylinder[1..] (count in [0]) -- abandoning it -- when one of its regions takes the
+    // cylinder branch; the cylinder kernel then redoes exactly the listed frames.  nullptr: single pass.
+    uint32_t* needCylinder;
+    int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
 };
 
