@@ -200,27 +200,45 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         return;
     const double ax = eg.q[0][0], ay = eg.q[1][0], az = eg.q[2][0];
 
-    // ---- projection on the plane orthogonal to the axis (:107-125)
-    for (int j = lane; j < N; j += 64)
+    // ---- projection on the plane orthogonal to the axis (:107-125); four rounds (256 cells) per trip with the sixteen
+    //      16-byte loads of a trip requested before the first result is needed: one memory round trip per trip
+    for (int j0 = 0; j0 < N; j0 += 256)
     {
-        const double* pl = planeBase + (size_t)c.s_list[j] * kPlaneStride;
-        const double nx = pl[0], ny = pl[1], nz = pl[2], cx = pl[4], cy = pl[5], cz = pl[6];
-        const double cdt = dot3(ax, ay, az, cx, cy, cz);
-        const double ndt = dot3(ax, ay, az, nx, ny, nz);
-        const double px = nx - ndt * ax, py = ny - ndt * ay, pz = nz - ndt * az;
-        const double nrm = sqrt((px * px + py * py) + pz * pz);
-        double* o = c.scratch + (size_t)j * kCylStride;
-        const double o0 = px / nrm, o1 = py / nrm, o2 = pz / nrm;
-        const double o3 = cx - cdt * ax, o4 = cy - cdt * ay, o5 = cz - cdt * az;
-        o[0] = o0;
-        o[1] = o1;
-        o[2] = o2;
-        o[3] = o3;
-        o[4] = o4;
-        o[5] = o5;
-        o[6] = (o0 * o3 + o1 * o4) + o2 * o5; // the LLS term b += n.dot(c) (cylinder_segment.cpp:171), ready for the ordered pass
-        c.s_ids[j] = (unsigned short)j;
-        c.s_idmask[j] = 1;
+        double2 q0[4], q1[4], q2[4], q3[4]; // (nx ny) (nz d) (cx cy) (cz mse) of cell_plane
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const int j = j0 + lane + 64 * k;
+            const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)c.s_list[j < N ? j : 0] * kPlaneStride);
+            q0[k] = pl[0];
+            q1[k] = pl[1];
+            q2[k] = pl[2];
+            q3[k] = pl[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const int j = j0 + lane + 64 * k;
+            if (j < N)
+            {
+                const double nx = q0[k].x, ny = q0[k].y, nz = q1[k].x, cx = q2[k].x, cy = q2[k].y, cz = q3[k].x;
+                const double cdt = dot3(ax, ay, az, cx, cy, cz);
+                const double ndt = dot3(ax, ay, az, nx, ny, nz);
+                const double px = nx - ndt * ax, py = ny - ndt * ay, pz = nz - ndt * az;
+                const double nrm = sqrt((px * px + py * py) + pz * pz);
+                const double o0 = px / nrm, o1 = py / nrm, o2 = pz / nrm;
+                const double o3 = cx - cdt * ax, o4 = cy - cdt * ay, o5 = cz - cdt * az;
+                double2* o = reinterpret_cast<double2*>(c.scratch + (size_t)j * kCylStride);
+                o[0] = make_double2(o0, o1);
+                o[1] = make_double2(o2, o3);
+                o[2] = make_double2(o4, o5);
+                // the LLS term b += n.dot(c) (cylinder_segment.cpp:171), ready for the ordered pass
+                o[3] = make_double2((o0 * o3 + o1 * o4) + o2 * o5, 0.0);
+                c.s_ids[j] = (unsigned short)j;
+                c.s_idmask[j] = 1;
+            }
+        }
     }
     CAPE_CYL_SYNC();
 
@@ -424,20 +442,37 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         {
             // the per-cell squared distances are independent: all lanes compute them (cx, cy, cz straight from
             // cell_plane) into LDS, then they are added in ascending order like the reference's loop
-            for (int i = lane; i < N; i += 64)
+            for (int i0 = 0; i0 < N; i0 += 256)
             {
-                double t2 = 0.0;
-                if (c.s_best[i])
+                double2 w0[4], w1[4]; // (cx cy) (cz mse) of cell_plane
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
                 {
-                    const double* pl = planeBase + (size_t)c.s_list[i] * kPlaneStride;
-                    const double wx = pl[4] - P2x, wy = pl[5] - P2y, wz = pl[6] - P2z;
-                    const double crx = dy * wz - dz * wy;
-                    const double cry = dz * wx - dx * wz;
-                    const double crz = dx * wy - dy * wx;
-                    const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
-                    t2 = t * t;
+                    const int i = i0 + lane + 64 * k;
+                    const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)c.s_list[i < N ? i : 0] * kPlaneStride);
+                    w0[k] = pl[2];
+                    w1[k] = pl[3];
                 }
-                c.s_dist[i] = t2;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const int i = i0 + lane + 64 * k;
+                    if (i < N)
+                    {
+                        double t2 = 0.0;
+                        if (c.s_best[i])
+                        {
+                            const double wx = w0[k].x - P2x, wy = w0[k].y - P2y, wz = w1[k].x - P2z;
+                            const double crx = dy * wz - dz * wy;
+                            const double cry = dz * wx - dx * wz;
+                            const double crz = dx * wy - dy * wx;
+                            const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
+                            t2 = t * t;
+                        }
+                        c.s_dist[i] = t2;
+                    }
+                }
             }
             CAPE_CYL_SYNC();
             CAPE_CYL_TICK(18); // MSE: parallel distances

@@ -696,6 +696,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     cape_primitive_summary* sum = p.summaries + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
     const double acolCenter = p.acol[(lane < HC ? lane : 0) * kCell + kCell / 2];
+    const double browCenterOfLane = p.brow[(lane < VC ? lane : 0) * kCell + kCell / 2]; // row r's value is broadcast below
     int nBoundary = 0;
     int nPlanesOut = 0;
     for (int pi = 0; pi < nSeg; ++pi)
@@ -736,16 +737,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                 const MaskT ringRow = shfl_mask<MaskT>(ring, r);
                 if (ringRow == 0)
                     continue;
+                const double browCenter = __shfl(browCenterOfLane, r); // p.brow[r * kCell + kCell / 2] without a memory round trip per row
                 bool hit = false;
                 double px = 0, py = 0, pz = 0;
                 if (lane < HC && ((ringRow >> lane) & (MaskT)1))
                 {
-                    const int centerY = r * kCell + kCell / 2;
                     const double dpt = (double)s_zc[r * HC + lane]; // depthImage(centerY, centerX), staged by stage A
                     if (dpt > 0)
                     {
                         px = dpt * acolCenter;
-                        py = dpt * p.brow[centerY];
+                        py = dpt * browCenter;
                         pz = dpt;
                         const double dist = dot3(A.nx, A.ny, A.nz, px, py, pz) + A.d;
                         hit = fabs(dist) < maxBoundaryDistance;
