@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Long randomised GPU-vs-oracle parity sweep (not part of the test suite: minutes, not seconds).
+usage: fuzz_parity.py [n_frames=512] [seed=1]   -- every observable of every frame must be bit-identical."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("rgb-d-slam_amd/python", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import cape_oracle_py as O
+from cape_amd import Extractor, synth
+from test_gpu_parity import compare_frame
+
+n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+names = ["room", "tumlike", "tunnel", "facets", "facets", "tunnel"]
+intr = synth.DEFAULT_INTRINSICS
+B = 64
+bad = 0
+stats = {"cyl_labels": 0, "planes": 0, "merged": 0, "cyl_frames": 0}
+orc = {c: O.Oracle(640, 480, cylinders=c, **intr) for c in (False, True)}
+ex = {c: Extractor(640, 480, cylinders=c, max_batch=B, **intr) for c in (False, True)}
+done = 0
+while done < n_total:
+    frames = []
+    for k in range(B):
+        d = synth.SCENES[names[int(rng.integers(0, len(names)))]](seed=int(rng.integers(0, 100000)), frame=int(rng.integers(0, 2000)))
+        mode = int(rng.integers(0, 8))
+        if mode == 1:
+            d[rng.random(d.shape) < rng.uniform(0.02, 0.3)] = 0
+        elif mode == 2:
+            d += (rng.standard_normal(d.shape) * rng.uniform(0.5, 8)).astype(np.float32) * (d > 0)
+        elif mode == 3:
+            y, x = int(rng.integers(0, 400)), int(rng.integers(0, 560))
+            d[y:y + 80, x:x + 80] *= np.float32(rng.uniform(0.3, 0.9))
+        elif mode == 4:
+            d = np.ascontiguousarray(d[:, ::-1])
+        elif mode == 5:
+            d = np.ascontiguousarray(d[::-1, :])
+        elif mode == 6:
+            d *= np.float32(rng.uniform(0.3, 3.0))
+        frames.append(d)
+    frames = np.stack(frames)
+    for cyl in (True, False):
+        n = ex[cyl].extract_host(frames)
+        res = ex[cyl].results(n)
+        for k in range(n):
+            r = orc[cyl].run(frames[k])
+            try:
+                compare_frame(r, ex[cyl], res, k, check_cells=False)
+            except AssertionError as e:
+                bad += 1
+                print(f"MISMATCH batch@{done} frame {k} cylinders={cyl}: {str(e)[:200]}", flush=True)
+            if cyl:
+                stats["cyl_labels"] += int(r.cyl_labels.max() > 0)
+                stats["planes"] += len(r.planes)
+                stats["merged"] += int((r.merge_labels != np.arange(len(r.merge_labels))).sum())
+                stats["cyl_frames"] += int((r.seed_outcome == 2).any())
+    done += B
+    print(f"{done} frames x 2 modes checked, mismatches so far {bad}", flush=True)
+print("coverage:", stats)
+print("RESULT", "OK" if bad == 0 else f"{bad} MISMATCHES")
+sys.exit(1 if bad else 0)
