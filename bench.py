@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--cylinders", action="store_true", help="planes + cylinder RANSAC (BASELINE.json configs[2], [4])")
     ap.add_argument("--match", action="store_true",
                     help="also run the consecutive-frame plane matcher every step (the 'IoU matching' of BASELINE.json configs[4])")
+    ap.add_argument("--u16", action="store_true",
+                    help="feed raw uint16 sensor depth (1/5 mm units, the TUM PNG format) through cape_extract_u16 instead of float32 mm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
     args = ap.parse_args()
@@ -136,7 +138,13 @@ def main():
     U = min(args.unique, B)
     unique = synth.stream(args.scene, seed=100 + rank, n_frames=U, width=W, height=H)
     reps = -(-B // U)
-    depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
+    if args.u16:
+        # raw = round(5 * mm), the device multiplies by 1/5 like examples/main_TUM.cpp:242; the CPU baseline is fed the same values
+        raw = np.clip(np.rint(unique * 5.0), 0, 65535).astype(np.uint16)
+        unique = raw.astype(np.float32) * np.float32(0.2)
+        depth = torch.from_numpy(raw.view(np.int16)).cuda().repeat(reps, 1, 1)[:B].contiguous()
+    else:
+        depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()
 
     ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B, sub_batches=args.sub_batches, **intr)
@@ -154,7 +162,10 @@ def main():
     step_no = [0]
 
     def step():
-        ex.extract_device(depth.data_ptr(), B, stream)
+        if args.u16:
+            ex.extract_device_u16(depth.data_ptr(), 0.2, B, stream)
+        else:
+            ex.extract_device(depth.data_ptr(), B, stream)
         if args.match:
             ex.match_consecutive(B, 0, stream)
         if use_dist:
@@ -210,7 +221,7 @@ def main():
         #   A2 cell plane   : reads those 96 B, writes 88 B per cell (plane, score, tolerance, flags, bin)
         #   B  grow         : reads 168 B per cell (sums + plane + tol/flags/bin), writes label grids + primitive lists
         kernels = {
-            "cape_cell_moments_kernel": (a1_ms, fpl * (W * H * 4 + cells * 96)),
+            "cape_cell_moments_kernel": (a1_ms, fpl * (W * H * (2 if args.u16 else 4) + cells * 96)),
             "cape_cell_plane_kernel": (a2_ms, fpl * (cells * (96 + 88))),
             "cape_grow_kernel": (b_ms, fpl * (cells * 168 + 2 * cells * 4 + 32 * 128)),
         }
@@ -226,7 +237,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        e2e_bytes_per_frame = W * H * 4 + 2 * cells * 4 + 32 * 128  # 1 239 040 B at 640x480
+        e2e_bytes_per_frame = W * H * (2 if args.u16 else 4) + 2 * cells * 4 + 32 * 128  # 1 239 040 B at 640x480
         out = {
             "metric": "depth frames/s primitive extraction (640x480)" if (W, H) == (640, 480)
                       else f"depth frames/s primitive extraction ({W}x{H})",
@@ -245,7 +256,8 @@ def main():
                 "workload": (f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])"
                              if (args.scene == "room" and not args.cylinders) else
                              f"{W}x{H} synthetic {args.scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only")
-                             + (" + consecutive-frame plane matching" if args.match else "")),
+                             + (" + consecutive-frame plane matching" if args.match else "")
+                             + (", raw uint16 input" if args.u16 else "")),
                 "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene, "sub_batches": args.sub_batches,
                 "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
             },

@@ -19,6 +19,8 @@
 // a per-cell z-range guard decides whether that holds, otherwise A2 redoes the cell in the reference's pixel order.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cape_device.h"
 #include "cape_internal.h"
 
@@ -215,26 +217,46 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         // rows in groups of kGroup, ping-pong buffered: the loads of group g+1 are in flight while group g is summed
         constexpr int kGroup = CAPE_A_GROUP, kGroups = kCell / kGroup;
         static_assert(kCell % kGroup == 0 && kGroups % 2 == 0, "the ping-pong loop consumes two groups per trip");
-        float4 bufA[kGroup], bufB[kGroup];
-        auto load_group = [&](float4 (&buf)[kGroup], int g) {
+        // the buffers hold what was LOADED (float4, or the raw ushort4 of the U16 variant): converting at load time would
+        // make every load wait for its data on the spot and serialise the prefetch with the arithmetic
+        using Raw = typename std::conditional<U16, ushort4, float4>::type;
+        Raw bufA[kGroup], bufB[kGroup];
+        auto load_group = [&](Raw (&buf)[kGroup], int g) {
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
             {
-                if (U16)
-                {
-                    // N4: the PNG payload of the TUM / CAPE datasets, converted exactly like
-                    // cv::Mat::convertTo(CV_32F, scale) does (examples/main_TUM.cpp:242): float(raw) * float(scale)
-                    const ushort4 rw = *reinterpret_cast<const ushort4*>(base16 + (size_t)(kGroup * g + i) * W);
-                    buf[i] = make_float4((float)rw.x * scale16, (float)rw.y * scale16, (float)rw.z * scale16,
-                                         (float)rw.w * scale16);
-                }
+                if constexpr (U16)
+                    buf[i] = *reinterpret_cast<const ushort4*>(base16 + (size_t)(kGroup * g + i) * W);
                 else
-                {
                     buf[i] = *reinterpret_cast<const float4*>(base + (size_t)(kGroup * g + i) * W);
-                }
             }
         };
-        auto sum_group = [&](const float4 (&buf)[kGroup], int g) {
+        auto to_f4 = [&](const Raw& rw) {
+            if constexpr (U16)
+            {
+                // N4: the PNG payload of the TUM / CAPE datasets, converted exactly like
+                // cv::Mat::convertTo(CV_32F, scale) does (examples/main_TUM.cpp:242): float(raw) * float(scale)
+                // one v_mul_f32 each, spelled out: left to itself the SLP vectoriser pairs them into v_pk_mul_f32, which
+                // costs two issue slots on gfx950's 32-wide SIMDs plus the moves that build the register pairs
+                // (measured: 2.00 ms per 4 096 frames packed, 1.54 ms scalar)
+                auto mul1 = [](float a, float b) {
+                    float r;
+                    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+                    return r;
+                };
+                return make_float4(mul1((float)rw.x, scale16), mul1((float)rw.y, scale16), mul1((float)rw.z, scale16),
+                                   mul1((float)rw.w, scale16));
+            }
+            else
+            {
+                return rw;
+            }
+        };
+        auto sum_group = [&](const Raw (&rawbuf)[kGroup], int g) {
+            float4 buf[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+                buf[i] = to_f4(rawbuf[i]);
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
             {
