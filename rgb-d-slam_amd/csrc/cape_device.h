@@ -395,7 +395,7 @@ __device__ __forceinline__ bool can_be_merged(double pnx, double pny, double pnz
 {
     const double cosAngle = dot3(pnx, pny, pnz, cnx, cny, cnz);
     const double dist = dot3(pnx, pny, pnz, ccx, ccy, ccz) + pd;
-    return (cosAngle > cosMerge) && (fabs(dist) < maxDist);
+    return (cosAngle > cosMerge) & (fabs(dist) < maxDist); // no short-circuit: keeps the callers branch-free
 }
 
 } // namespace cape

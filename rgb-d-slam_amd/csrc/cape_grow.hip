@@ -310,6 +310,95 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     //   EL bit c : parent (r,c-1) -> child (r,c)      ER bit c : parent (r,c+1) -> child (r,c)
     //   EU bit c : parent (r-1,c) -> child (r,c)      ED bit c : parent (r+1,c) -> child (r,c)
     // =========================================================================================
+    if (HC <= 32)
+    {
+        // Grids up to 32 cells wide: the two halves of the wave take two rows per step (lane = 32 * (row & 1) + column),
+        // which halves both the arithmetic and the number of exposed memory round trips.  The row above comes from the
+        // other half: row 2t for the odd half (same step), row 2t - 1 for the even half (the odd half's previous step).
+        const int h = lane >> 5, col = lane & 31;
+        const bool in = col < HC;
+        double pnx = 0, pny = 0, pnz = 0, pd = 0, pcx = 0, pcy = 0, pcz = 0, ptol = 0; // this lane's previous step
+        struct RowRec
+        {
+            double2 v0, v1, v2, v3; // (nx ny) (nz d) (cx cy) (cz mse)
+            float tol;
+            uint32_t fl;
+        };
+        // unconditional (row clamped): three steps are kept in flight, and a load behind a branch would make the
+        // wait-count insertion drain all of them (see cape_staged.h)
+        auto fetch_row = [&](RowRec& q, int t) {
+            const int r = 2 * t + h;
+            const int ci = (r < VC ? r : VC - 1) * HC + (in ? col : 0);
+            const double2* pl = reinterpret_cast<const double2*>(p.cell_plane + (cellBase + ci) * kPlaneStride);
+            q.v0 = pl[0];
+            q.v1 = pl[1];
+            q.v2 = pl[2];
+            q.v3 = pl[3];
+            q.tol = p.cell_tol[cellBase + ci];
+            q.fl = p.cell_flags[cellBase + ci];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step = [&](const RowRec& q, int t) {
+            const int r = 2 * t + h;
+            const bool rowIn = in && r < VC;
+            const double nx = q.v0.x, ny = q.v0.y, nz = q.v1.x, d = q.v1.y, cx = q.v2.x, cy = q.v2.y, cz = q.v3.x;
+            const double tol = (double)q.tol;
+            const bool planar = rowIn && (q.fl & kFlagPlanar);
+            // left neighbour (lane - 1, same half)
+            const double lnx = __shfl_up(nx, 1), lny = __shfl_up(ny, 1), lnz = __shfl_up(nz, 1), ld = __shfl_up(d, 1);
+            const double lcx = __shfl_up(cx, 1), lcy = __shfl_up(cy, 1), lcz = __shfl_up(cz, 1), ltol = __shfl_up(tol, 1);
+            const bool hasL = rowIn && col > 0;
+            const bool l2m = hasL & can_be_merged(lnx, lny, lnz, ld, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
+            const bool m2l = hasL & can_be_merged(nx, ny, nz, d, lnx, lny, lnz, lcx, lcy, lcz, ltol, p.cosMerge);
+            // row above: the even half sends this step's values, the odd half last step's
+            const int other = lane ^ 32;
+            const double unx = __shfl(h ? pnx : nx, other), uny = __shfl(h ? pny : ny, other), unz = __shfl(h ? pnz : nz, other);
+            const double ud = __shfl(h ? pd : d, other);
+            const double ucx = __shfl(h ? pcx : cx, other), ucy = __shfl(h ? pcy : cy, other), ucz = __shfl(h ? pcz : cz, other);
+            const double utol = __shfl(h ? ptol : tol, other);
+            const bool hasU = rowIn && r > 0;
+            const bool u2m = hasU & can_be_merged(unx, uny, unz, ud, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
+            const bool m2u = hasU & can_be_merged(nx, ny, nz, d, unx, uny, unz, ucx, ucy, ucz, utol, p.cosMerge);
+            const unsigned long long bU = __ballot(planar);
+            const unsigned long long bL2M = __ballot(l2m);
+            const unsigned long long bM2L = __ballot(m2l);
+            const unsigned long long bU2M = __ballot(u2m);
+            const unsigned long long bM2U = __ballot(m2u);
+            // low words: row 2t, high words: row 2t + 1 ; lane q keeps row q's masks (rows past the grid give zeros)
+            if (lane == 2 * t)
+            {
+                U = (MaskT)(uint32_t)bU;
+                EL = (MaskT)(uint32_t)bL2M;
+                ER = (MaskT)((uint32_t)bM2L >> 1);
+                EU = (MaskT)(uint32_t)bU2M;
+                ED = (MaskT)(uint32_t)(bM2U >> 32); // parent row 2t + 1 -> child row 2t, evaluated by the odd half
+            }
+            if (lane == 2 * t + 1)
+            {
+                U = (MaskT)(uint32_t)(bU >> 32);
+                EL = (MaskT)(uint32_t)(bL2M >> 32);
+                ER = (MaskT)((uint32_t)(bM2L >> 32) >> 1);
+                EU = (MaskT)(uint32_t)(bU2M >> 32);
+            }
+            if (lane == 2 * t - 1)
+                ED = (MaskT)(uint32_t)bM2U;
+            pnx = nx; pny = ny; pnz = nz; pd = d; pcx = cx; pcy = cy; pcz = cz; ptol = tol;
+        };
+        RowRec q0, q1, q2;
+        fetch_row(q0, 0);
+        fetch_row(q1, 1);
+        fetch_row(q2, 2);
+        for (int t = 0; 2 * t < VC; t += 3)
+        {
+            step(q0, t);
+            fetch_row(q0, t + 3);
+            step(q1, t + 1);
+            fetch_row(q1, t + 4);
+            step(q2, t + 2);
+            fetch_row(q2, t + 5);
+        }
+    }
+    else
     {
         double unx = 0, uny = 0, unz = 0, ud = 0, ucx = 0, ucy = 0, ucz = 0, utol = 0; // row above, same column
         const bool in = lane < HC;
