@@ -268,26 +268,55 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 constexpr int j0 = 0;
                 CAPE_CYL_ROUNDS(CAPE_CYL_FETCH)
             }
-            for (int it = 0; it < p.ransacMaxIterations; ++it)
+            // The draws of this loop (3 per hypothesis, <= 192) are fetched once, one per lane, and handed out by lane
+            // index; the three sample cells of hypothesis it + 1 are requested while hypothesis it is evaluated.  Both
+            // take a dependent memory round trip per hypothesis off the critical path of this one-wave-per-SIMD kernel.
+            const int rngBase = rngPos;
+            double rr0, rr1, rr2;
             {
-                int id[3];
+                const int last = p.rngCount - 1;
+                const int i0 = rngBase + lane, i1 = i0 + 64, i2 = i0 + 128;
+                rr0 = p.rngTable[i0 < last ? i0 : last];
+                rr1 = p.rngTable[i1 < last ? i1 : last];
+                rr2 = p.rngTable[i2 < last ? i2 : last];
+            }
+            auto sample_of = [&](int drawIndex) { // drawIndex = 3 * it + q, uniform
+                const double v0 = __shfl(rr0, drawIndex & 63), v1 = __shfl(rr1, drawIndex & 63), v2 = __shfl(rr2, drawIndex & 63);
+                double U = drawIndex < 64 ? v0 : (drawIndex < 128 ? v1 : v2);
+                if (rngBase + drawIndex >= p.rngCount)
+                    U = 0.0; // table exhausted: flagged when (if) the hypothesis is actually evaluated
+                return (int)c.s_ids[(unsigned)floor(U * (double)(unsigned)m)];
+            };
+            struct Triplet
+            {
+                double2 a[3], b[3], c[3]; // (n.x n.y) (n.z c.x) (c.y c.z) of the three sample cells
+            };
+            auto fetch_triplet = [&](Triplet& T, int it) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                 {
-                    double U = 0.0;
-                    if (rngPos < p.rngCount)
-                        U = p.rngTable[rngPos];
-                    else
-                        status |= CAPE_FRAME_RNG_EXHAUSTED;
-                    ++rngPos;
-                    id[q] = c.s_ids[(unsigned)floor(U * (double)(unsigned)m)];
+                    const double2* t_ = reinterpret_cast<const double2*>(c.scratch + (size_t)sample_of(3 * it + q) * kCylStride);
+                    T.a[q] = t_[0];
+                    T.b[q] = t_[1];
+                    T.c[q] = t_[2];
                 }
-                const double* t1 = c.scratch + (size_t)id[0] * kCylStride;
-                const double* t2 = c.scratch + (size_t)id[1] * kCylStride;
-                const double* t3 = c.scratch + (size_t)id[2] * kCylStride;
-                const double n1x = t1[0], n1y = t1[1], n1z = t1[2], c1x = t1[3], c1y = t1[4], c1z = t1[5];
-                const double n2x = t2[0], n2y = t2[1], n2z = t2[2], c2x = t2[3], c2y = t2[4], c2z = t2[5];
-                const double n3x = t3[0], n3y = t3[1], n3z = t3[2], c3x = t3[3], c3y = t3[4], c3z = t3[5];
+            };
+            if (p.ransacMaxIterations * 3 > 192)
+                status |= CAPE_FRAME_RNG_EXHAUSTED; // cannot happen with the reference's constants (43 iterations)
+            Triplet cur;
+            fetch_triplet(cur, 0);
+            for (int it = 0; it < p.ransacMaxIterations; ++it)
+            {
+                if (rngBase + 3 * it + 2 >= p.rngCount)
+                    status |= CAPE_FRAME_RNG_EXHAUSTED;
+                rngPos = rngBase + 3 * (it + 1);
+                Triplet nxt;
+                fetch_triplet(nxt, it + 1 < p.ransacMaxIterations ? it + 1 : it);
+                __builtin_amdgcn_sched_barrier(0);
+                const double n1x = cur.a[0].x, n1y = cur.a[0].y, n1z = cur.b[0].x, c1x = cur.b[0].y, c1y = cur.c[0].x, c1z = cur.c[0].y;
+                const double n2x = cur.a[1].x, n2y = cur.a[1].y, n2z = cur.b[1].x, c2x = cur.b[1].y, c2y = cur.c[1].x, c2z = cur.c[1].y;
+                const double n3x = cur.a[2].x, n3y = cur.a[2].y, n3z = cur.b[2].x, c3x = cur.b[2].y, c3y = cur.c[2].x, c3z = cur.c[2].y;
+                cur = nxt;
                 const double sNx = (n1x + n2x) + n3x, sNy = (n1y + n2y) + n3y, sNz = (n1z + n2z) + n3z;
                 const double sCx = (c1x + c2x) + c3x, sCy = (c1y + c2y) + c3y, sCz = (c1z + c2z) + c3z;
                 const double a = 1.0 - ((sNx * sNx + sNy * sNy) + sNz * sNz) / 9.0;
