@@ -540,3 +540,37 @@ def test_cylinder_schedules_agree(oracle_mod):
         for k in range(n):
             compare_frame(expected[name][k], ex, res, k, check_cells=(call == 0))
     ex.close()
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+def test_sub_batch_pipeline_matches_single_chain(oracle_mod, cyl):
+    """cape_config.sub_batches > 1 cuts a batch into sub-batches that alternate between two internal streams; results
+    (records, label grids, boundary points, summaries order) must not depend on it."""
+    from cape_amd import Extractor, synth
+
+    intr = _intr("room")
+    frames = np.stack([synth.tunnel(seed=5, frame=f) if f % 3 == 0 else synth.room(seed=5, frame=f) for f in range(22)])
+    ref = Extractor(640, 480, cylinders=cyl, max_batch=len(frames), **intr)
+    n = ref.extract_host(frames)
+    want = ref.results(n)
+    ref.close()
+    for sb in (2, 3, 5):
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=len(frames), sub_batches=sb, **intr)
+        for _ in range(2):  # second call: the pipeline's events and streams are reused
+            assert ex.extract_host(frames) == n
+            got = ex.results(n)
+            assert np.array_equal(got.plane_labels, want.plane_labels), f"sub_batches={sb}"
+            assert np.array_equal(got.cyl_labels, want.cyl_labels), f"sub_batches={sb}"
+            assert np.array_equal(got.records["header"], want.records["header"]), f"sub_batches={sb}"
+            for f in range(n):
+                k = int(want.records["header"]["n_plane_segments"][f])
+                assert got.records["segments"][f][:k].tobytes() == want.records["segments"][f][:k].tobytes(), (sb, f)
+                nb = int(want.records["header"]["n_boundary_points"][f])
+                assert np.array_equal(got.boundary[f][:nb], want.boundary[f][:nb])
+        ex.close()
+    orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+    for f in (0, 1, 21):
+        ex = Extractor(640, 480, cylinders=cyl, max_batch=len(frames), sub_batches=3, **intr)
+        ex.extract_host(frames)
+        compare_frame(orc.run(frames[f]), ex, ex.results(n), f, check_cells=False)
+        ex.close()
