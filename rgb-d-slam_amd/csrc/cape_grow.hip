@@ -976,6 +976,18 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         sum->status = status;
         sum->n_plane_segments = nSeg;
     }
+    // unused slots of the gather payload are zeroed, so that what travels between GPUs depends on this frame only
+    {
+        constexpr int kPlaneDoubles = sizeof(sum->planes[0]) / 8, kCylDoubles = sizeof(sum->cylinders[0]) / 8;
+        double* sp = reinterpret_cast<double*>(&sum->planes[0]);
+        const int usedP = (nPlanesOut < CAPE_SUMMARY_PLANES ? nPlanesOut : CAPE_SUMMARY_PLANES) * kPlaneDoubles;
+        for (int i = usedP + lane; i < CAPE_SUMMARY_PLANES * kPlaneDoubles; i += 64)
+            sp[i] = 0.0;
+        double* sc = reinterpret_cast<double*>(&sum->cylinders[0]);
+        const int usedC = (nCylOut < CAPE_SUMMARY_CYLINDERS ? nCylOut : CAPE_SUMMARY_CYLINDERS) * kCylDoubles;
+        for (int i = usedC + lane; i < CAPE_SUMMARY_CYLINDERS * kCylDoubles; i += 64)
+            sc[i] = 0.0;
+    }
 #ifdef CAPE_B_PROFILE
     CAPE_WAVE_SYNC();
     if (lane < kProfileSlots)

@@ -317,6 +317,11 @@ def test_summaries_visible_to_torch_without_copy():
         k = min(len(pl), 16)
         assert np.array_equal(s["planes"]["normal"][f, :k], pl["out_normal"][:k])
         assert np.array_equal(s["planes"]["d"][f, :k], pl["d"][:k])
+    # the payload depends on the current frames only: an empty batch after a busy one leaves nothing behind
+    ex.extract_host(np.zeros_like(frames))
+    t = torch.as_tensor(DevMem(ex.summaries_pointer(), 3 * SUMMARY_DTYPE.itemsize), device="cuda")
+    raw = np.frombuffer(t.cpu().numpy().tobytes(), dtype=np.uint8).reshape(3, SUMMARY_DTYPE.itemsize)
+    assert not raw.any(), "stale primitives in the gather payload"
     ex.close()
 
 
