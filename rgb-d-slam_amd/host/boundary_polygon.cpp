@@ -450,6 +450,230 @@ bool Polygon::contains(const vector2& point) const noexcept { return _ring.size(
 
 vector3 Polygon::get_normal() const noexcept { return cross(_xAxis, _yAxis); }
 
+Polygon Polygon::transform(const vector3& nextNormal, const vector3& nextCenter) const
+{
+    const auto axes = get_plane_coordinate_system(nextNormal);
+    return transform(axes.first, axes.second, nextCenter);
+}
+
+Polygon Polygon::transform(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const
+{
+    auto cross = [](const vector3& a, const vector3& b) {
+        return vector3 {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    };
+    // R_from = [x y x^y] (orthonormal: inverse = transpose), R_to likewise: R = R_to R_from^T
+    const vector3 zF = cross(_xAxis, _yAxis), zT = cross(nextXAxis, nextYAxis);
+    const vector3 from[3] = {_xAxis, _yAxis, zF}, to[3] = {nextXAxis, nextYAxis, zT};
+    std::vector<vector2> ring;
+    ring.reserve(_ring.size());
+    for (const vector2& q : _ring)
+    {
+        const vector3 p3 = get_point_from_plane_coordinates(q, _center, _xAxis, _yAxis);
+        vector3 moved {nextCenter[0] - _center[0], nextCenter[1] - _center[1], nextCenter[2] - _center[2]};
+        for (int k = 0; k < 3; ++k)
+        {
+            const double coord = from[k][0] * p3[0] + from[k][1] * p3[1] + from[k][2] * p3[2]; // (R_from^T p)_k
+            for (int i = 0; i < 3; ++i)
+                moved[i] += to[k][i] * coord;
+        }
+        ring.push_back(get_projected_plan_coordinates(moved, nextCenter, nextXAxis, nextYAxis));
+    }
+    return Polygon(ring, nextXAxis, nextYAxis, nextCenter);
+}
+
+namespace {
+
+// Outer boundary of the union of two simple rings (any orientation), counter-clockwise; empty if degenerate.
+std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std::vector<vector2>& B)
+{
+    double scale = 1.0;
+    for (const auto* r : {&A, &B})
+        for (const vector2& p : *r)
+            scale = std::max(scale, std::max(std::abs(p[0]), std::abs(p[1])));
+    const double eps = 1e-9 * scale;
+    auto same = [&](const vector2& a, const vector2& b) { return std::abs(a[0] - b[0]) <= eps && std::abs(a[1] - b[1]) <= eps; };
+    auto cross2 = [](const vector2& o, const vector2& a, const vector2& b) {
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);
+    };
+    struct Seg
+    {
+        vector2 a, b;
+        std::vector<double> cuts; // parameters in (0, 1) where the segment is split
+    };
+    std::vector<Seg> segs;
+    for (const auto* r : {&A, &B})
+        for (size_t i = 0; i < r->size(); ++i)
+        {
+            const vector2 &a = (*r)[i], &b = (*r)[(i + 1) % r->size()];
+            if (!same(a, b))
+                segs.push_back({a, b, {}});
+        }
+    const size_t nA = [&] {
+        size_t n = 0;
+        for (size_t i = 0; i < A.size(); ++i)
+            n += !same(A[i], A[(i + 1) % A.size()]);
+        return n;
+    }();
+    auto param_on = [&](const Seg& s, const vector2& p, double& t) {
+        // is p on segment s (within eps)?  t = position along it
+        const double dx = s.b[0] - s.a[0], dy = s.b[1] - s.a[1];
+        const double len2 = dx * dx + dy * dy;
+        const double c = cross2(s.a, s.b, p);
+        if (std::abs(c) > eps * std::sqrt(len2))
+            return false;
+        t = ((p[0] - s.a[0]) * dx + (p[1] - s.a[1]) * dy) / len2;
+        return t > 0 && t < 1 && !same(p, s.a) && !same(p, s.b);
+    };
+    for (size_t i = 0; i < nA; ++i)
+        for (size_t j = nA; j < segs.size(); ++j)
+        {
+            Seg &s = segs[i], &u = segs[j];
+            double t;
+            // endpoints lying on the other segment (T junctions, collinear overlaps)
+            if (param_on(s, u.a, t))
+                s.cuts.push_back(t);
+            if (param_on(s, u.b, t))
+                s.cuts.push_back(t);
+            if (param_on(u, s.a, t))
+                u.cuts.push_back(t);
+            if (param_on(u, s.b, t))
+                u.cuts.push_back(t);
+            // proper crossing
+            const double d1 = cross2(u.a, u.b, s.a), d2 = cross2(u.a, u.b, s.b);
+            const double d3 = cross2(s.a, s.b, u.a), d4 = cross2(s.a, s.b, u.b);
+            if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0)))
+            {
+                const double ts = d1 / (d1 - d2), tu = d3 / (d3 - d4);
+                const vector2 x {s.a[0] + ts * (s.b[0] - s.a[0]), s.a[1] + ts * (s.b[1] - s.a[1])};
+                if (!same(x, s.a) && !same(x, s.b))
+                    s.cuts.push_back(ts);
+                if (!same(x, u.a) && !same(x, u.b))
+                    u.cuts.push_back(tu);
+            }
+        }
+    // nodes and undirected edges of the arrangement
+    std::vector<vector2> nodes;
+    auto node_of = [&](const vector2& p) {
+        for (size_t k = 0; k < nodes.size(); ++k)
+            if (same(nodes[k], p))
+                return k;
+        nodes.push_back(p);
+        return nodes.size() - 1;
+    };
+    std::vector<std::vector<size_t>> adj;
+    auto link = [&](size_t a, size_t b) {
+        if (a == b)
+            return;
+        if (adj.size() < nodes.size())
+            adj.resize(nodes.size());
+        if (std::find(adj[a].begin(), adj[a].end(), b) == adj[a].end())
+        {
+            adj[a].push_back(b);
+            adj[b].push_back(a);
+        }
+    };
+    for (Seg& s : segs)
+    {
+        std::sort(s.cuts.begin(), s.cuts.end());
+        size_t prev = node_of(s.a);
+        for (const double t : s.cuts)
+        {
+            const size_t cur = node_of({s.a[0] + t * (s.b[0] - s.a[0]), s.a[1] + t * (s.b[1] - s.a[1])});
+            link(prev, cur);
+            prev = cur;
+        }
+        link(prev, node_of(s.b));
+    }
+    if (nodes.size() < 3)
+        return {};
+    adj.resize(nodes.size());
+    // walk the outer face counter-clockwise from the lowest of the leftmost nodes, always taking the sharpest right turn
+    size_t start = 0;
+    for (size_t k = 1; k < nodes.size(); ++k)
+        if (nodes[k][0] < nodes[start][0] - eps || (std::abs(nodes[k][0] - nodes[start][0]) <= eps && nodes[k][1] < nodes[start][1]))
+            start = k;
+    auto next_of = [&](size_t v, const vector2& back) -> size_t {
+        // first neighbour met when rotating counter-clockwise from direction `back` (the way we came from)
+        const double ba = std::atan2(back[1], back[0]);
+        size_t best = v;
+        double bestAngle = 1e300;
+        for (const size_t w : adj[v])
+        {
+            double ang = std::atan2(nodes[w][1] - nodes[v][1], nodes[w][0] - nodes[v][0]) - ba;
+            while (ang <= 1e-12)
+                ang += 2 * M_PI; // going straight back is the last resort (angle 2 pi)
+            if (ang < bestAngle)
+            {
+                bestAngle = ang;
+                best = w;
+            }
+        }
+        return best;
+    };
+    std::vector<vector2> ring;
+    size_t v = start;
+    vector2 back {0.0, 1.0}; // we reach the leftmost node heading south
+    const size_t first = next_of(start, back);
+    if (first == start)
+        return {};
+    size_t cur = start, nxt = first;
+    for (size_t guard = 0; guard < 4 * nodes.size() + 8; ++guard)
+    {
+        ring.push_back(nodes[cur]);
+        back = {nodes[cur][0] - nodes[nxt][0], nodes[cur][1] - nodes[nxt][1]};
+        const size_t after = next_of(nxt, back);
+        cur = nxt;
+        nxt = after;
+        if (cur == start && nxt == first)
+            return ring;
+    }
+    (void)v;
+    return {}; // did not close: degenerate input
+}
+
+// drop vertices that lie on the segment joining their neighbours (repeated until stable)
+void drop_collinear(std::vector<vector2>& r)
+{
+    bool changed = true;
+    while (changed && r.size() > 3)
+    {
+        changed = false;
+        for (size_t i = 0; i < r.size() && r.size() > 3; ++i)
+        {
+            const vector2 &a = r[(i + r.size() - 1) % r.size()], &b = r[i], &c = r[(i + 1) % r.size()];
+            const double cr = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+            const double len = std::hypot(c[0] - a[0], c[1] - a[1]);
+            if (std::abs(cr) <= 1e-9 * std::max(1.0, len * len))
+            {
+                r.erase(r.begin() + static_cast<long>(i));
+                changed = true;
+                --i;
+            }
+        }
+    }
+}
+
+} // namespace
+
+bool Polygon::merge_union(const Polygon& other)
+{
+    const Polygon o = other.project(_xAxis, _yAxis, _center);
+    if (_ring.size() < 3 || o._ring.size() < 3)
+        return false;
+    std::vector<vector2> outer = rings_union_outer(_ring, o._ring);
+    drop_collinear(outer);
+    const double outerArea = outer.size() >= 3 ? std::abs(ring_area_signed(outer)) : 0.0;
+    // two disjoint pieces: union_one keeps the biggest one of the multi-polygon (polygon.cpp:474-492)
+    const double areaA = area(), areaB = o.area();
+    if (outerArea + 1e-9 * std::max(areaA, areaB) < std::max(areaA, areaB))
+        outer = areaA >= areaB ? _ring : o._ring;
+    if (outer.size() < 3 || !ring_is_simple(outer))
+        return false; // "Merge of two polygons produces no overlaps, returning without merge operation"
+    *this = Polygon(outer, _xAxis, _yAxis, _center);
+    simplify();
+    return true;
+}
+
 std::vector<vector3> Polygon::get_unprojected_boundary() const
 {
     std::vector<vector3> out;

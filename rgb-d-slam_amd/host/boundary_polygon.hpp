@@ -56,6 +56,18 @@ class Polygon
     [[nodiscard]] double inter_area(const Polygon& other) const;
     [[nodiscard]] double union_area(const Polygon& other) const;
     [[nodiscard]] double inter_over_union(const Polygon& other) const;
+    // Polygon::transform (polygon.cpp:384-451): the polygon moved rigidly with its frame -- every boundary point is
+    // lifted to 3D, mapped by get_transformation_matrix (point_coordinates.cpp:24-70: R_to R_from^-1 p + c_to - c_from,
+    // the rotation being about the origin like the reference) and re-expressed in the new frame
+    [[nodiscard]] Polygon transform(const vector3& nextNormal, const vector3& nextCenter) const;
+    [[nodiscard]] Polygon transform(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const;
+    // Polygon::merge_union (polygon.cpp:325-336 over union_one :463-493): this polygon becomes the outer boundary of
+    // (this U other), `other` being projected into this frame first; two disjoint polygons leave the larger one (the
+    // reference keeps the biggest piece of the multi-polygon), then simplify().  Holes that a union can enclose are not
+    // represented (the reference would keep them as interior rings).  Returns false (and changes nothing) if the
+    // result is empty.  Dependency-free: outer-face walk over the arrangement of the two rings, touching vertices and
+    // collinear overlaps included.
+    bool merge_union(const Polygon& other);
     // polygon from an explicit ring in a given frame (polygon.cpp:236-266)
     Polygon(const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center);
 

@@ -140,6 +140,67 @@ int main()
             far.push_back({v[0] + 5000.0, v[1], v[2]});
         EXPECT(polygon.inter_area(Polygon(far, normal, center)) == 0.0);
     }
+    {
+        // SquareTests.Unions (reference tests/test_polygons.cpp:91-152), step for step
+        const vector3 normal {0, 0, 1}, center {0, 0, 0};
+        Polygon rectangle({{-1000.0, 1000.0, 0.0}, {1000.0, 1000.0, 0.0}, {-1000.0, -1000.0, 0.0}, {1000.0, -1000.0, 0.0}}, normal, center);
+        Polygon diamond({{-1000.0, 0.0, 0.0}, {1000.0, 0.0, 0.0}, {0.0, -1000.0, 0.0}, {0.0, 1000.0, 0.0}}, normal, center);
+        auto near = [](double a, double b) { return std::abs(a - b) < 1e-3; };
+        EXPECT(near(diamond.area(), 2e6));
+        EXPECT(rectangle.merge_union(diamond));          // diamond inside, its corners ON the rectangle's edges
+        EXPECT(near(rectangle.area(), 4e6) && rectangle.boundary_length() == 4);
+        diamond = diamond.transform(normal, {1000.0, 0.0, 0.0}); // shift the shape by half a length
+        EXPECT(near(diamond.area(), 2e6));
+        EXPECT(rectangle.merge_union(diamond));
+        EXPECT(rectangle.boundary_length() == 5 && near(rectangle.area(), 4e6 + 1e6));
+        diamond = diamond.transform(normal, {-1000.0, 0.0, 0.0}); // offset to the left
+        EXPECT(rectangle.merge_union(diamond));
+        EXPECT(rectangle.boundary_length() == 6 && near(rectangle.area(), 4e6 + 2e6));
+        diamond = diamond.transform(normal, {0.0, 1000.0, 0.0});  // offset to the top
+        EXPECT(rectangle.merge_union(diamond));
+        EXPECT(rectangle.boundary_length() == 5 && near(rectangle.area(), 4e6 + 3e6)); // reduced by the simplification
+        diamond = diamond.transform(normal, {0.0, -1000.0, 0.0}); // offset to the bottom
+        EXPECT(rectangle.merge_union(diamond));
+        EXPECT(rectangle.boundary_length() == 4 && near(rectangle.area(), 4e6 + 4e6));
+        EXPECT(rectangle.is_valid() && rectangle.contains({0, 1900}) && !rectangle.contains({1500, 1500}));
+
+        // beyond the reference's cases: proper crossings, containment both ways, disjoint, random agreement with union_area
+        Polygon a({{0, 0, 0}, {400, 0, 0}, {400, 400, 0}, {0, 400, 0}}, normal, center);
+        Polygon b({{200, 200, 0}, {600, 200, 0}, {600, 600, 0}, {200, 600, 0}}, normal, center);
+        Polygon u = a;
+        EXPECT(u.merge_union(b) && near(u.area(), 2 * 160000.0 - 40000.0) && u.boundary_length() == 8);
+        Polygon big({{-100, -100, 0}, {700, -100, 0}, {700, 700, 0}, {-100, 700, 0}}, normal, center);
+        u = a;
+        EXPECT(u.merge_union(big) && near(u.area(), 640000.0) && u.boundary_length() == 4);
+        u = big;
+        EXPECT(u.merge_union(a) && near(u.area(), 640000.0) && u.boundary_length() == 4);
+        Polygon farAway({{5000, 0, 0}, {5100, 0, 0}, {5100, 100, 0}, {5000, 100, 0}}, normal, center);
+        u = a;
+        EXPECT(u.merge_union(farAway) && near(u.area(), 160000.0)); // disjoint: the bigger piece stays (polygon.cpp:474-492)
+        u = farAway;
+        EXPECT(u.merge_union(a) && near(u.area(), 160000.0));
+        std::mt19937 gen(7);
+        std::uniform_real_distribution<double> d(-300.0, 300.0), sz(150.0, 500.0);
+        for (int rep = 0; rep < 200; ++rep)
+        {
+            // a random convex quadrilateral around a random centre against the fixed square: area(outer boundary of the
+            // union) must equal area(a) + area(q) - inter_area, as long as the union encloses no hole (convex U convex)
+            const double cx = d(gen) + 200, cy = d(gen) + 200, r = sz(gen);
+            std::vector<vector3> pts;
+            for (int k = 0; k < 4; ++k)
+            {
+                const double ang = (k + 0.15 * (d(gen) / 300.0)) * M_PI / 2 + 0.4;
+                pts.push_back({cx + r * std::cos(ang), cy + r * std::sin(ang), 0.0});
+            }
+            Polygon q(pts, normal, center);
+            if (!q.is_valid() || a.inter_area(q) <= 0)
+                continue;
+            Polygon m = a;
+            EXPECT(m.merge_union(q));
+            EXPECT(std::abs(m.area() - a.union_area(q)) < 0.02 * a.union_area(q)); // simplify() may shave slivers
+            EXPECT(m.is_valid());
+        }
+    }
     std::printf(failures ? "%d FAILURES\n" : "all polygon tests passed\n", failures);
     return failures ? 1 : 0;
 }
