@@ -407,6 +407,17 @@ Polygon::Polygon(const std::vector<vector2>& ring, const vector3& xAxis, const v
     _area = area();
 }
 
+Polygon::Polygon(OpenRing, const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center) :
+    _ring(ring),
+    _center(center),
+    _xAxis(xAxis),
+    _yAxis(yAxis)
+{
+    if (ring_area_signed(_ring) > 0)
+        std::reverse(_ring.begin(), _ring.end());
+    _area = area();
+}
+
 Polygon Polygon::project(const vector3& nextNormal, const vector3& nextCenter) const
 {
     const auto axes = get_plane_coordinate_system(nextNormal);
@@ -420,7 +431,7 @@ Polygon Polygon::project(const vector3& nextXAxis, const vector3& nextYAxis, con
     for (const vector2& p : _ring)
         ring.push_back(get_projected_plan_coordinates(get_point_from_plane_coordinates(p, _center, _xAxis, _yAxis), nextCenter,
                                                       nextXAxis, nextYAxis));
-    return Polygon(ring, nextXAxis, nextYAxis, nextCenter);
+    return Polygon(OpenRing {}, ring, nextXAxis, nextYAxis, nextCenter);
 }
 
 double Polygon::inter_area(const Polygon& other) const
@@ -478,7 +489,7 @@ Polygon Polygon::transform(const vector3& nextXAxis, const vector3& nextYAxis, c
         }
         ring.push_back(get_projected_plan_coordinates(moved, nextCenter, nextXAxis, nextYAxis));
     }
-    return Polygon(ring, nextXAxis, nextYAxis, nextCenter);
+    return Polygon(OpenRing {}, ring, nextXAxis, nextYAxis, nextCenter);
 }
 
 namespace {

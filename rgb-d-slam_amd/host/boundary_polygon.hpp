@@ -75,6 +75,12 @@ class Polygon
     static std::vector<vector2> compute_convex_hull(const std::vector<vector2>& points) noexcept;
 
   private:
+    struct OpenRing
+    {
+    };
+    // internal: `ring` is already open (no repeated closing vertex), so a degenerate ring whose first and last vertices
+    // coincide -- e.g. a projection onto a perpendicular plane -- keeps all its vertices
+    Polygon(OpenRing, const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center);
     std::vector<vector2> _ring; // open ring (first vertex not repeated), clockwise like the reference
     vector3 _center {0, 0, 0}, _xAxis {1, 0, 0}, _yAxis {0, 1, 0};
     double _area = 0.0;

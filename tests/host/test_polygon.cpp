@@ -141,6 +141,27 @@ int main()
         EXPECT(polygon.inter_area(Polygon(far, normal, center)) == 0.0);
     }
     {
+        // SquareTests.SimpleFitting, second half (reference tests/test_polygons.cpp:44-66): the mirrored polygon and transform()
+        const std::vector<vector3> points {{-1000.0, 1000.0, 0.0}, {1000.0, 1000.0, 0.0}, {-1000.0, -1000.0, 0.0}, {1000.0, -1000.0, 0.0}};
+        const vector3 normal {0, 0, 1}, minusNormal {0, 0, -1}, center {0, 0, 0};
+        auto eq3 = [](const vector3& a, const vector3& b) { return std::abs(a[0] - b[0]) + std::abs(a[1] - b[1]) + std::abs(a[2] - b[2]) < 1e-12; };
+        Polygon polygon(points, normal, center), polygonInverse(points, minusNormal, center);
+        EXPECT(eq3(polygonInverse.get_normal(), minusNormal));
+        EXPECT(std::abs(polygon.get_area() - polygon.union_area(polygonInverse)) < 0.1);
+        EXPECT(std::abs(polygon.get_area() - polygon.inter_area(polygonInverse)) < 0.1);
+        const Polygon inversed = polygon.transform(minusNormal, center);
+        EXPECT(eq3(inversed.get_normal(), minusNormal) && eq3(inversed.get_center(), center));
+        const Polygon shiftedT = polygon.transform(normal, {500.0, 500.0, 0.0});
+        EXPECT(eq3(shiftedT.get_normal(), normal) && eq3(shiftedT.get_center(), {500.0, 500.0, 0.0}));
+        EXPECT(shiftedT.get_area() == polygon.get_area());
+        const Polygon turned = polygon.transform({1.0, 0.0, 0.0}, center);
+        EXPECT(eq3(turned.get_normal(), {1.0, 0.0, 0.0}) && eq3(turned.get_center(), center) && turned.boundary_length() == 4);
+        const Polygon shiftedP = polygon.project(normal, {500.0, 500.0, 0.0});
+        EXPECT(eq3(shiftedP.get_normal(), normal) && eq3(shiftedP.get_center(), {500.0, 500.0, 0.0}) && shiftedP.get_area() == polygon.get_area());
+        const Polygon turnedP = polygon.project({1.0, 0.0, 0.0}, {1000.0, 0.0, 0.0});
+        EXPECT(eq3(turnedP.get_normal(), {1.0, 0.0, 0.0}) && turnedP.boundary_length() == 4 && turnedP.get_area() == 0.0);
+    }
+    {
         // SquareTests.Unions (reference tests/test_polygons.cpp:91-152), step for step
         const vector3 normal {0, 0, 1}, center {0, 0, 0};
         Polygon rectangle({{-1000.0, 1000.0, 0.0}, {1000.0, 1000.0, 0.0}, {-1000.0, -1000.0, 0.0}, {1000.0, -1000.0, 0.0}}, normal, center);
