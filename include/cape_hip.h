@@ -23,7 +23,9 @@ extern "C" {
 #endif
 
 #define CAPE_CELL_SIZE 20          /* parameters::detection::depthMapPatchSize_px, src/parameters.hpp:79-80 */
-#define CAPE_MAX_PLANES 32         /* capacity of _planeSegments per frame (reference: unbounded std::vector) */
+#define CAPE_MAX_PLANES 64         /* capacity of _planeSegments per frame (reference: unbounded std::vector); frames with
+                                      up to 32 segments run entirely in the fast kernels, the others are redone by a
+                                      64-segment instance */
 #define CAPE_MAX_CYLINDERS 16      /* capacity of cylinder2regionMap per frame */
 
 typedef enum cape_status
@@ -45,7 +47,7 @@ enum
 /* per-frame status bits (cape_frame_header.status) */
 enum
 {
-    CAPE_FRAME_PLANE_OVERFLOW = 1u << 0,    /* more than CAPE_MAX_PLANES plane segments: frame truncated */
+    CAPE_FRAME_PLANE_OVERFLOW = 1u << 0,    /* more than CAPE_MAX_PLANES (64) plane segments: frame truncated */
     CAPE_FRAME_BOUNDARY_OVERFLOW = 1u << 1, /* boundary point capacity exceeded */
     CAPE_FRAME_CYL_OVERFLOW = 1u << 2,
     CAPE_FRAME_BIN_NEAR_EDGE = 1u << 3,     /* a cell's histogram angle fell within 1e-9 of a bin edge (libm tie risk) */

@@ -16,7 +16,7 @@ namespace cape {
 void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
-size_t grow_lds_bytes(int cells, bool cylinders);
+size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 void launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 int grow_waves_per_group();
@@ -57,6 +57,7 @@ struct cape_handle_s
     double* rng = nullptr;
     double* cylScratch = nullptr;
     uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
+    uint32_t* redoList = nullptr;     // [0] count, [1..] frames that need more than 32 plane-segment slots
     // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
     // (never waited for) before the next call; above kSinglePassAbove of the frames the plane-only pass is not worth it
     uint32_t* handedOverHost = nullptr;
@@ -143,6 +144,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->rng);
     (void)hipFree(h->cylScratch);
     (void)hipFree(h->needCylinder);
+    (void)hipFree(h->redoList);
     if (h->handedOverHost)
         (void)hipHostFree(h->handedOverHost);
     if (h->handedOverReady)
@@ -223,6 +225,7 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
         b.cylScratch += F * C * cape::kCylStride;
     if (b.needCylinder)
         b.needCylinder += 2 * F; // a sub-batch of n frames uses 1 + n entries of its own
+    b.redoList += 2 * F;
     b.debugCycles += F * cape::kProfileSlots;
 }
 
@@ -389,6 +392,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), sizeof(uint32_t)));
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
+    CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     CAPE_ALLOC(dalloc(h->records, B));
@@ -505,6 +509,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.minCellActivated = static_cast<int>(static_cast<unsigned>((0.65 / 100.0) * h->cells));
     b.cylScratch = h->cylScratch;
     b.needCylinder = h->needCylinder;
+    b.redoList = h->redoList;
     b.twoPass = h->needCylinder ? 1 : 0;
     b.debugCycles = h->debugCycles;
     b.rngTable = h->rng;
@@ -520,7 +525,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         for (auto& e : h->pipeJoin)
             CAPE_ALLOC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0) > 160 * 1024)
+    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > 160 * 1024)
     {
         free_all(h);
         delete h;

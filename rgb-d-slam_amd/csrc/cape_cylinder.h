@@ -70,6 +70,7 @@ struct CylCtx
     unsigned char* s_lab;
     unsigned char* s_cyl;
     cape_frame_record* rec;
+    int maxPlanes;                // segment slots of this kernel instance
     unsigned long long* dbg;      // per-frame phase ticks (profiling builds)
 };
 
@@ -538,7 +539,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         // ===== add_cylinder_to_features (:437-476): model selection on MSE
         if (f.mse < mse)
         {
-            if (nSeg >= CAPE_MAX_PLANES)
+            if (nSeg >= c.maxPlanes)
             {
                 planeOverflow = true;
                 return;

@@ -217,7 +217,10 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
     r[8] = cof(2, 2) * invdet;
 }
 
-template <typename MaskT, bool CYL>
+// MAXP: plane segments a frame may hold in this instance.  The two everyday instances keep kFastPlanes (32) segments in
+// LDS; a frame that needs more is handed to the MAXP = CAPE_MAX_PLANES (64) instance through p.redoList, exactly like
+// cylinder-branch frames are handed from the plane-only to the cylinder instance.
+template <typename MaskT, bool CYL, int MAXP>
 __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -226,7 +229,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     int frame = blockIdx.x * (int)(blockDim.x >> 6) + wave;
     if (frame >= nFrames)
         return; // whole wave leaves; there is no workgroup barrier in this kernel
-    if (CYL && p.twoPass)
+    constexpr bool kRedo = MAXP > kFastPlanes;
+    if (kRedo)
+    {
+        // third pass: wave k takes the k-th frame that ran out of segment slots in one of the 32-segment instances
+        if (frame >= (int)p.redoList[0])
+            return;
+        frame = (int)p.redoList[1 + frame];
+    }
+    else if (CYL && p.twoPass)
     {
         // second pass of the two-pass schedule: wave k takes the k-th frame the plane-only pass gave up on
         if (frame >= (int)p.needCylinder[0])
@@ -239,16 +250,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
 
     // ---- LDS carve (all offsets multiples of 16)
     // ---- LDS carve (every offset a multiple of 8; 13.4 KB for 640x480 plane-only -> 12 waves per CU)
-    double* s_seg = reinterpret_cast<double*>(smem);                              // CAPE_MAX_PLANES x 20 f64
-    double* s_chunk = s_seg + CAPE_MAX_PLANES * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
+    double* s_seg = reinterpret_cast<double*>(smem);                              // MAXP x 20 f64
+    double* s_chunk = s_seg + MAXP * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
     unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // 32 u64
-    int* s_hist = reinterpret_cast<int*>(s_adj + CAPE_MAX_PLANES);                // 400 i32
+    int* s_hist = reinterpret_cast<int*>(s_adj + MAXP);                // 400 i32
     short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
     unsigned char* s_mlab = s_lab + C;                                            // 32 u8 merge labels
     // cylinder variant only (see grow_lds_bytes)
-    unsigned char* s_cyl = s_mlab + CAPE_MAX_PLANES;                              // C u8  cylinder labels
+    unsigned char* s_cyl = s_mlab + MAXP;                              // C u8  cylinder labels
     unsigned short* s_ids = reinterpret_cast<unsigned short*>(s_cyl + C + (C & 1)); // C u16 idsLeft
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
     unsigned char* s_cur = s_idmask + C;                                          // C u8
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
 
     for (int i = lane; i < kHistBins; i += 64)
         s_hist[i] = 0;
-    for (int i = lane; i < CAPE_MAX_PLANES; i += 64)
+    for (int i = lane; i < MAXP; i += 64)
     {
         s_adj[i] = 0ull;
         s_mlab[i] = (unsigned char)i;
@@ -632,8 +643,15 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         if (f.score > 100)
         {
             // add_plane_segment_to_features (:391-411): push_back copies the segment (one more normalisation)
-            if (nSeg >= CAPE_MAX_PLANES)
+            if (nSeg >= MAXP)
             {
+                if (!kRedo && p.redoList)
+                {
+                    // out of LDS segment slots: the 64-segment instance redoes this frame from the start
+                    if (lane == 0)
+                        p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                    return;
+                }
                 status |= CAPE_FRAME_PLANE_OVERFLOW;
                 break;
             }
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                 s_lab[s_list[i]] = (unsigned char)nSeg;
             CAPE_WAVE_SYNC();
         }
-        else if (!CYL && p.twoPass && total > 5)
+        else if (!CYL && !kRedo && p.twoPass && total > 5)
         {
             // first pass of the two-pass schedule: this region goes to cylinder_fitting, which the plane-only kernel does
             // not carry -- hand the whole frame to the cylinder kernel (it starts over; nothing written so far counts)
@@ -677,6 +695,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
             cc.s_lab = s_lab;
             cc.s_cyl = s_cyl;
             cc.rec = p.records + frame;
+            cc.maxPlanes = MAXP;
 #ifdef CAPE_B_PROFILE
             cc.dbg = s_prof;
 #else
@@ -689,6 +708,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
             CAPE_TICK_RESTART(); // the cylinder phases booked themselves in slots 12..15
             if (planeOverflow)
             {
+                if (!kRedo && p.redoList)
+                {
+                    if (lane == 0)
+                        p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                    return;
+                }
                 status |= CAPE_FRAME_PLANE_OVERFLOW;
                 break;
             }
@@ -995,17 +1020,17 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
 #endif
 }
 
-size_t grow_lds_bytes(int cells, bool cylinders)
+size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes)
 {
     size_t b = 0;
-    b += (size_t)CAPE_MAX_PLANES * kSegDoubles * 8; // s_seg
+    b += (size_t)maxPlanes * kSegDoubles * 8; // s_seg
     b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk
-    b += (size_t)CAPE_MAX_PLANES * 8;               // s_adj
+    b += (size_t)maxPlanes * 8;               // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins  } after the seed loop these two hold s_zc
     b += (size_t)cells * 2;                         // s_list  }
     b += (size_t)cells;                             // s_lab
-    b += CAPE_MAX_PLANES;                           // s_mlab
+    b += maxPlanes;                           // s_mlab
     if (cylinders)
         b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 128; // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
 #ifdef CAPE_B_PROFILE
@@ -1020,36 +1045,36 @@ int grow_waves_per_group() { return kWavesPerGroup; }
 int grow_waves_per_cu(const StageBParams& p)
 {
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
-    const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl);
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl, kFastPlanes);
     int wpg = kWavesPerGroup;
     while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
         --wpg;
     int blocks = 0;
     hipError_t e;
     if (p.hCells <= 32)
-        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true>, 64 * wpg, (size_t)ldsPerWave * wpg)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg);
     else
-        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, true>, 64 * wpg, (size_t)ldsPerWave * wpg)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, true, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, false, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg);
     return e == hipSuccess ? blocks * wpg : 0;
 }
 
 namespace {
 
-template <bool CYL>
+template <bool CYL, int MAXP>
 void launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 {
-    const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL);
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL, MAXP);
     int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the 160 KB of LDS admit (<= kWavesPerGroup)
     while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
         --wpg;
     const size_t lds = (size_t)ldsPerWave * wpg;
     const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
-        hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+        hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     else
-        hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+        hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
 }
 
 } // namespace
@@ -1065,19 +1090,28 @@ void launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
 {
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    // counters of the two hand-over lists ([0] = count, [1..] = frames), zeroed together: they are adjacent
+    if (p.redoList)
+        (void)hipMemsetAsync(p.redoList, 0, sizeof(uint32_t), stream);
     if (!cyl)
     {
-        launch_grow_variant<false>(p, nFrames, stream);
+        launch_grow_variant<false, kFastPlanes>(p, nFrames, stream);
+        if (p.redoList)
+            launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream); // frames with more than 32 segments (rare)
         return;
     }
     if (!p.twoPass)
     {
-        launch_grow_variant<true>(p, nFrames, stream); // nearly every frame needs it anyway: skip the plane-only pass
-        return;
+        launch_grow_variant<true, kFastPlanes>(p, nFrames, stream); // nearly every frame needs it anyway: skip the plane-only pass
     }
-    (void)hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream); // [0] = number of handed-over frames, [1..] = which
-    launch_grow_variant<false>(p, nFrames, stream);
-    launch_grow_variant<true>(p, nFrames, stream);
+    else
+    {
+        (void)hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream);
+        launch_grow_variant<false, kFastPlanes>(p, nFrames, stream);
+        launch_grow_variant<true, kFastPlanes>(p, nFrames, stream);
+    }
+    if (p.redoList)
+        launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream);
 }
 
 } // namespace cape

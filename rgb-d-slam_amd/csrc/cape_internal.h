@@ -17,6 +17,7 @@ namespace cape {
 //   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts) + centre depth
 //   cell_mse   [cells]     f64 : copy of the cell MSE, compact so the seed selection reads it coalesced
 constexpr int kSumStride = 10;
+constexpr int kFastPlanes = 32;     // plane segments the everyday grow-kernel instances hold in LDS (CAPE_MAX_PLANES = 64 in the redo instance)
 constexpr int kProfileSlots = 32;   // phase counters per frame of a -DCAPE_B_PROFILE build (cape_debug_cycles)
 constexpr int kCylStride = 8;       // doubles per cell of the cylinder scratch: projected normal[3], projected centroid[3], their dot product, pad
 constexpr int kPlaneStride = 8;
@@ -90,6 +91,7 @@ struct StageBParams
     // appends a frame to the list needCylinder[1..] (count in [0]) -- abandoning it -- when one of its regions takes the
     // cylinder branch; the cylinder kernel then redoes exactly the listed frames.  nullptr: single pass.
     uint32_t* needCylinder;
+    uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
 };

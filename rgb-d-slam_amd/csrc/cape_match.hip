@@ -12,7 +12,7 @@ namespace cape {
 
 namespace {
 
-constexpr int kWavesPerGroup = 4;
+constexpr int kWavesPerGroup = 2;
 constexpr int P = CAPE_MAX_PLANES;
 
 // label -> output plane index table of one frame, in LDS: map[0] = -1 (no plane), map[k + 1] = index among the
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void cape_match_kernel(MatchPa
 
     for (int k = lane; k < P * P; k += 64)
         inter[k] = 0;
-    if (lane < 2 * P)
-        area[lane] = 0;
+    for (int k = lane; k < 2 * P; k += 64)
+        area[k] = 0;
 
     int nPrev = 0;
     const int nCur = build_label_map(p.records[frame], lane, mapCur, s_seg[wave] + P);

@@ -13,7 +13,7 @@ PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # rgb-d-sl
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
 LIB_PATH = os.environ.get("CAPE_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcape_hip.so")  # env: kernel experiments
 
-CAPE_MAX_PLANES = 32
+CAPE_MAX_PLANES = 64
 CAPE_MAX_CYLINDERS = 16
 CAPE_FLAG_CYLINDERS = 1
 
@@ -66,8 +66,8 @@ SUMMARY_DTYPE = np.dtype([
     ("cylinders", np.dtype([("axis", "<f8", 3), ("radius", "<f8")]), 8)], align=True)
 assert SUMMARY_DTYPE.itemsize == 1296
 MATCH_DTYPE = np.dtype([
-    ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", 32), ("area_prev", "<u2", 32), ("area_cur", "<u2", 32),
-    ("inter", "<u2", (32, 32))], align=True)
+    ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", CAPE_MAX_PLANES), ("area_prev", "<u2", CAPE_MAX_PLANES),
+    ("area_cur", "<u2", CAPE_MAX_PLANES), ("inter", "<u2", (CAPE_MAX_PLANES, CAPE_MAX_PLANES))], align=True)
 MATCH_ADVANCED = 1
 MATCH_ALLOW_INDEX0 = 2
 

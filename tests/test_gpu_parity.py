@@ -579,3 +579,28 @@ def test_sub_batch_pipeline_matches_single_chain(oracle_mod, cyl):
         ex.extract_host(frames)
         compare_frame(orc.run(frames[f]), ex, ex.results(n), f, check_cells=False)
         ex.close()
+
+
+def test_more_than_32_plane_segments(oracle_mod):
+    """The everyday kernels keep 32 plane segments in LDS; a frame that needs more is redone by the 64-segment
+    instance.  This 1280x960 room frame (depth scaled x2.13: noisy far walls, dozens of cylinder-branch regions whose
+    inliers fit planes better) yields 34 segments in the reference algorithm; it sits between ordinary frames."""
+    from cape_amd import Extractor, synth
+
+    W, H = 1280, 960
+    intr = _intr("room", 2.0)
+    big = synth.room(seed=85969, frame=1635, width=W, height=H, intr=intr) * np.float32(2.128972746525244)
+    frames = np.stack([synth.room(seed=1, frame=0, width=W, height=H, intr=intr), big,
+                       synth.tunnel(seed=1, frame=0, width=W, height=H, intr=intr), big])
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    want = [orc.run(f) for f in frames]
+    assert len(want[1].segments) == 34
+    ex = Extractor(W, H, cylinders=True, max_batch=len(frames), **intr)
+    for _ in range(2):
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        assert int(res.records["header"]["status"][1]) & 1 == 0, "frame flagged as truncated"
+        assert int(res.records["header"]["n_plane_segments"][1]) == 34
+        for k in range(n):
+            compare_frame(want[k], ex, res, k, check_cells=False)
+    ex.close()
