@@ -26,7 +26,7 @@ extern "C" {
 #define CAPE_MAX_PLANES 64         /* capacity of _planeSegments per frame (reference: unbounded std::vector); frames with
                                       up to 32 segments run entirely in the fast kernels, the others are redone by a
                                       64-segment instance */
-#define CAPE_MAX_CYLINDERS 16      /* capacity of cylinder2regionMap per frame */
+#define CAPE_MAX_CYLINDERS 64      /* capacity of cylinder2regionMap per frame (records live in HBM only: no LDS cost) */
 
 typedef enum cape_status
 {

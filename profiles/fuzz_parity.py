@@ -51,7 +51,7 @@ while done < n_total:
         for k in range(n):
             r = orc[cyl].run(frames[k])
             if int(res.records["header"]["status"][k]) & 0x7:
-                # fixed per-frame capacity exceeded (64 plane segments / 16 cylinder labels / boundary points): the
+                # fixed per-frame capacity exceeded (64 plane segments / 64 cylinder labels / boundary points): the
                 # frame is truncated AND flagged, by design -- the reference's vectors are unbounded
                 stats["capacity_flagged"] = stats.get("capacity_flagged", 0) + 1
                 assert len(r.segments) > 64 or len(r.cylinders) >= 0

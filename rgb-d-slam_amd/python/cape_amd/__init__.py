@@ -14,7 +14,7 @@ REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
 LIB_PATH = os.environ.get("CAPE_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcape_hip.so")  # env: kernel experiments
 
 CAPE_MAX_PLANES = 64
-CAPE_MAX_CYLINDERS = 16
+CAPE_MAX_CYLINDERS = 64
 CAPE_FLAG_CYLINDERS = 1
 
 FRAME_PLANE_OVERFLOW = 1 << 0

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert cape_amd.PLANE_SEGMENT_DTYPE.itemsize == 30 * 8 + 6 * 4
     assert cape_amd.CYLINDER_DTYPE.itemsize == 40
     assert cape_amd.HEADER_DTYPE.itemsize == 32
-    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 16 * 40
+    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 64 * 40
     assert cape_amd.SUMMARY_DTYPE.itemsize == 1296
     assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4
     assert cape_amd.MATCH_DTYPE.itemsize == 8 + 64 * 4 + 2 * 64 * 2 + 64 * 64 * 2
