@@ -117,6 +117,15 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "rgb-d-slam_amd", "lib", "libcape_hip.so")) and local_rank == 0:
+        # fresh checkout: the libraries are git-ignored build products (what __graft_entry__.build() makes)
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "rgb-d-slam_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
+    for _ in range(600):  # the other ranks wait for rank 0's build
+        if os.path.exists(os.path.join(ROOT, "rgb-d-slam_amd", "lib", "libcape_hip.so")):
+            break
+        time.sleep(0.5)
     from cape_amd import SUMMARY_DTYPE, Extractor, synth
 
     if not torch.cuda.is_available():
