@@ -273,7 +273,8 @@ bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame
     matches.clear();
     if (!_handle || n_frames < 0)
         return false;
-    const uint32_t flags = (useAdvancedSearch ? CAPE_MATCH_ADVANCED : 0u) | (allowIndexZero ? CAPE_MATCH_ALLOW_INDEX0 : 0u);
+    const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
+                           (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
     matches.resize(n_frames);
     if (cape_match_consecutive(_handle, n_frames, flags, nullptr) != CAPE_OK ||
         cape_copy_matches(_handle, n_frames, matches.data()) != CAPE_OK)
