@@ -200,7 +200,7 @@ int cape_get_layout(cape_handle h, cape_layout* out);
 /*
  * Replaces, for a batch of frames: get_organized_cloud_array (depth_map_transformation.hpp:36-39) followed by
  * find_primitives (primitive_detection.hpp:41-44).  `depth_dev` is a DEVICE pointer to n_frames row-major
- * float32 images in millimetres (0 = invalid), already resident in HBM.  Asynchronous on `stream`.
+ * float32 images in millimetres (0 = invalid), already resident in HBM, 16-byte aligned.  Asynchronous on `stream`.
  * Results stay on the device until fetched (cape_copy_results) or gathered (cape_device_results).
  */
 int cape_extract(cape_handle h, const float* depth_dev, int32_t n_frames, void* stream);

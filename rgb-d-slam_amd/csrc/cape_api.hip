@@ -583,6 +583,9 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
     if (n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
+    // the streaming kernel reads four pixels per lane with one vector load
+    if ((depth_dev && reinterpret_cast<uintptr_t>(depth_dev) % 16 != 0) || (depth_u16 && reinterpret_cast<uintptr_t>(depth_u16) % 8 != 0))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "depth must be aligned to four pixels (16 bytes of float32, 8 bytes of uint16)");
     h->lastFrames = n_frames;
     if (n_frames == 0)
         return CAPE_OK;

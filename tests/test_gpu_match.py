@@ -116,3 +116,22 @@ def test_match_argument_checks():
     m = ex.matches(2)
     assert m["n_prev"][1] == m["n_cur"][0]
     ex.close()
+
+
+def test_extract_rejects_misaligned_device_pointers():
+    """The streaming kernel loads four pixels per lane: a device pointer that is not aligned to four pixels is an
+    argument error, not a fault."""
+    import torch
+    from cape_amd import CapeError, Extractor, synth
+
+    ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
+    buf = torch.zeros(640 * 480 + 8, dtype=torch.float32, device="cuda")
+    with pytest.raises(CapeError):
+        ex.extract_device(buf.data_ptr() + 4, 1)
+    raw = torch.zeros(640 * 480 + 8, dtype=torch.int16, device="cuda")
+    with pytest.raises(CapeError):
+        ex.extract_device_u16(raw.data_ptr() + 2, 0.2, 1)
+    ex.extract_device(buf.data_ptr() + 16, 1)      # aligned offsets are fine
+    ex.extract_device_u16(raw.data_ptr() + 8, 0.2, 1)
+    torch.cuda.synchronize()
+    ex.close()
