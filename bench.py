@@ -273,6 +273,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic,
+                # also against the 6.29 TB/s a streaming kernel can actually reach (MI355X_MICROARCH.md)
+                "frac_of_achievable_6p29TBps": achieved * 1e9 / 6.29e12,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
                 "kernel_ms": {"cape_cell_moments_kernel": a1_ms, "cape_cell_plane_kernel": a2_ms, "cape_grow_kernel": b_ms},
                 "stage_b": {"us_per_frame": 1e3 * b_ms / fpl, "frames_in_flight": ex.grow_frames_per_cu * ex.compute_units,
