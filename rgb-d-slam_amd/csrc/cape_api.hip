@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -59,12 +60,16 @@ struct cape_handle_s
     uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
     uint32_t* redoList = nullptr;     // [0] count, [1..] frames that need more than 32 plane-segment slots
     // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
-    // (never waited for) before the next call; above kSinglePassAbove of the frames the plane-only pass is not worth it
+    // (never waited for) before the next call.  The cylinder kernel works in rounds of cylSlots resident frames; the
+    // plane-only first pass pays off when it saves at least one such round (see launch_chain)
     uint32_t* handedOverHost = nullptr;
     hipEvent_t handedOverReady = nullptr;
     int handedOverFrames = 0;  // frames of the call the pending count belongs to (0: nothing pending)
+    double handedOverFraction = 0.0; // last measured share of frames that took the cylinder branch
+    int cylSlots = 1024;             // frames the cylinder kernel keeps resident on the device (occupancy x CUs)
     bool singlePass = false;
     int callsSinceProbe = 0;
+    int forcedSchedule = 0; // debug knob CAPE_SCHEDULE=two|single (read at create): 1 = always two-pass, 2 = always single
     unsigned long long* debugCycles = nullptr;
     // rectify_depth (N3): float copies of the back-projection factors + collision keys (allocated on first use)
     float* xpre = nullptr;
@@ -279,15 +284,29 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     cape::StageBParams bb = b;
     if (bb.needCylinder)
     {
-        constexpr double kSinglePassAbove = 0.6;
+        // Cost model, in rounds of the cylinder kernel (one round = cylSlots resident frames, ~0.25 ms at 640x480):
+        //   cylinder kernel alone      ceil(frames / slots)
+        //   plane-only pass first      kPlanePassPerRound * frames / slots  +  ceil(handed_over / slots)
+        // kPlanePassPerRound = 0.29 is the measured cost of growing one round's worth of frames with the plane-only
+        // kernel (profiles/schedule_crossover.py).  A single handed-over frame is cheaper alone; a batch that hands
+        // over half of its frames usually saves a round.
+        constexpr double kPlanePassPerRound = 0.29;
         constexpr int kProbeEvery = 32; // a single-pass handle re-measures with a two-pass call now and then
         if (h->handedOverFrames > 0 && hipEventQuery(h->handedOverReady) == hipSuccess)
         {
-            h->singlePass = (double)*h->handedOverHost > kSinglePassAbove * (double)h->handedOverFrames;
+            h->handedOverFraction = (double)*h->handedOverHost / (double)h->handedOverFrames;
             h->handedOverFrames = 0;
+        }
+        {
+            const double slots = (double)(h->cylSlots > 0 ? h->cylSlots : 1024);
+            const double alone = std::ceil((double)frames / slots);
+            const double twoPass = kPlanePassPerRound * (double)frames / slots + std::ceil(h->handedOverFraction * (double)frames / slots);
+            h->singlePass = twoPass >= alone;
         }
         const bool probe = h->singlePass && ++h->callsSinceProbe >= kProbeEvery;
         bb.twoPass = (!h->singlePass || probe) ? 1 : 0;
+        if (h->forcedSchedule)
+            bb.twoPass = h->forcedSchedule == 1 ? 1 : 0;
         if (probe)
             h->callsSinceProbe = 0;
     }
@@ -511,6 +530,15 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.needCylinder = h->needCylinder;
     b.redoList = h->redoList;
     b.twoPass = h->needCylinder ? 1 : 0;
+    if (h->needCylinder)
+    {
+        hipDeviceProp_t prop;
+        const int perCu = cape::grow_waves_per_cu(h->pb);
+        if (perCu > 0 && hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess)
+            h->cylSlots = perCu * prop.multiProcessorCount;
+    }
+    if (const char* sched = std::getenv("CAPE_SCHEDULE"))
+        h->forcedSchedule = std::string(sched) == "two" ? 1 : (std::string(sched) == "single" ? 2 : 0);
     b.debugCycles = h->debugCycles;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;
