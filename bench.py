@@ -2,10 +2,13 @@
 """bench.py -- depth frames/s of CAPE primitive extraction on MI355X (BASELINE.json metric).
 
 Workload (N=1): BASELINE.json configs[1], "640x480 synthetic planar-room depth stream, 1xMI355X, plane extraction
-only".  A *step* is one pass of the hot path (stage A cell fit + stage B grow/merge/boundary) over one batch of
-`--frames` synthetic frames that are already resident in HBM.  With N>1 (one process per GPU, launched by
-torch.distributed.run) every rank runs the same per-GPU batch on its own stream of frames (weak scaling) and the
-per-frame primitive lists are exchanged with one RCCL all-gather per step.
+only": a 4 096-frame stream, every frame distinct, rendered on the GPU (cape_amd.synth_gpu) and resident in HBM.  A *step*
+is one pass of the hot path (stage A cell fit + stage B grow/merge/boundary) over that batch.
+Workload (N>1, one process per GPU launched by torch.distributed.run): BASELINE.json configs[3], "batched 640x480 TUM
+fr1_desk stream sharded across 8xMI355X, RCCL gather of primitive lists": ONE TUM-like stream of N x 2 048 frames cut
+in contiguous blocks (cape_amd.dist.shard_range), rank r extracts frames [a_r, b_r), and every step ends with ONE
+ncclAllGather of the packed primitive lists, issued by libcape_hip itself (cape_gather_primitives) on its own stream so
+that it runs under the next step's kernels.  `--scaling strong` keeps the stream at 8 x 2 048 frames for every N.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description) with two extra objects:
   roofline     -- the dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the
@@ -49,7 +52,7 @@ def available_cores():
     return n
 
 
-def cpu_baseline(unique_frames, intr, budget_s=12.0, cylinders=False):
+def cpu_baseline(unique_frames, intr, budget_s=12.0, cylinders=False, scene="room"):
     """Oracle (port of the reference CPU path) on this host: 1 thread (how the reference runs it), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import concurrent.futures as cf
@@ -81,7 +84,8 @@ def cpu_baseline(unique_frames, intr, budget_s=12.0, cylinders=False):
     n_all = cores * len(per_thread)
     return {
         "value": n / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{n} frames of the same room stream, oracle/libcape_oracle.so (g++ -O2 -ffp-contract=off), "
+        "sample": f"{n} frames of the same {scene} stream ({unique_frames.shape[0]} distinct, read back from the device), "
+                  f"oracle/libcape_oracle.so (g++ -O2 -ffp-contract=off), "
                   f"{dt1:.1f} s single thread",
         "all_cores": {"value": n_all / dtn, "cores": cores, "seconds": dtn, "frames": n_all},
     }
@@ -92,16 +96,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per step per GPU (resident in HBM)")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames generated per GPU, tiled to --frames")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per step per GPU, resident in HBM (default: 4096 at N=1, 2048 per GPU at N>1)")
+    ap.add_argument("--unique", type=int, default=0,
+                    help="distinct frames per GPU, tiled to --frames (default: every frame distinct)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--scene", default="room")
+    ap.add_argument("--scene", default="", help="room | tumlike | tunnel (default: room at N=1, tumlike at N>1)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = 2048 frames per GPU (stream of N x 2048), strong = one 8 x 2048-frame stream for every N")
+    ap.add_argument("--gather", default="native", choices=["native", "torch", "none"],
+                    help="N>1 exchange of the packed primitive lists: native = ncclAllGather issued by libcape_hip "
+                         "(cape_gather_primitives), torch = torch.distributed all_gather_into_tensor, none = no exchange")
     ap.add_argument("--cylinders", action="store_true", help="planes + cylinder RANSAC (BASELINE.json configs[2], [4])")
     ap.add_argument("--match", action="store_true",
                     help="also run the consecutive-frame plane matcher every step (the 'IoU matching' of BASELINE.json configs[4])")
     ap.add_argument("--u16", action="store_true",
                     help="feed raw uint16 sensor depth (1/5 mm units, the TUM PNG format) through cape_extract_u16 instead of float32 mm")
+    ap.add_argument("--host-synth", action="store_true", help="render the frames with the numpy generators (slow; parity fixtures use these)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
     args = ap.parse_args()
@@ -126,48 +138,65 @@ def main():
         if os.path.exists(os.path.join(ROOT, "rgb-d-slam_amd", "lib", "libcape_hip.so")):
             break
         time.sleep(0.5)
-    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+    from cape_amd import Extractor, synth, synth_gpu
+    from cape_amd import dist as cdist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    # CAPE_BENCH_FORCE_GATHER=1 exercises the RCCL gather path on a single GPU (validation only)
-    use_dist = world > 1 or os.environ.get("CAPE_BENCH_FORCE_GATHER") == "1"
-    if use_dist:
+    # CAPE_BENCH_FORCE_GATHER=1 exercises the multi-GPU exchange on a single GPU (world 1; validation only)
+    force = os.environ.get("CAPE_BENCH_FORCE_GATHER") == "1"
+    multi = world > 1 or force
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    W, H, B = args.width, args.height, args.frames
+    W, H = args.width, args.height
+    scene = args.scene or ("tumlike" if multi else "room")
+    # frames of this rank: a contiguous block of ONE stream (configs[3]) -- at N=1 the block is the whole stream
+    if multi:
+        per_gpu = args.frames or 2048
+        total = 8 * per_gpu if args.scaling == "strong" else world * per_gpu
+        first, last = cdist.shard_range(total, rank, world)
+        B = last - first
+        B_max = cdist.largest_shard(total, world)
+    else:
+        B = B_max = args.frames or 4096
+        total, first = B, 0
     scale = W / 640.0
-    base_intr = synth.TUM_FR1_INTRINSICS if args.scene == "tumlike" else synth.DEFAULT_INTRINSICS
+    base_intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
     intr = {k: v * scale for k, v in base_intr.items()}
 
     # ---- synthetic stream, resident in HBM before the timed region
-    U = min(args.unique, B)
-    unique = synth.stream(args.scene, seed=100 + rank, n_frames=U, width=W, height=H)
+    U = min(args.unique or B, B)
     reps = -(-B // U)
-    if args.u16:
-        # raw = round(5 * mm), the device multiplies by 1/5 like examples/main_TUM.cpp:242; the CPU baseline is fed the same values
-        raw = np.clip(np.rint(unique * 5.0), 0, 65535).astype(np.uint16)
-        unique = raw.astype(np.float32) * np.float32(0.2)
-        depth = torch.from_numpy(raw.view(np.int16)).cuda().repeat(reps, 1, 1)[:B].contiguous()
+    if args.host_synth:
+        unique_host = synth.stream(scene, seed=100, n_frames=U, width=W, height=H, start=first)
+        if args.u16:
+            raw = np.clip(np.rint(unique_host * 5.0), 0, 65535).astype(np.uint16)
+            unique_dev = torch.from_numpy(raw.view(np.int16)).cuda()
+        else:
+            unique_dev = torch.from_numpy(unique_host).cuda()
     else:
-        depth = torch.from_numpy(unique).cuda().repeat(reps, 1, 1)[:B].contiguous()
+        # frame ids [first, first + U) of the stream: what rank r renders depends on its block only
+        unique_dev = synth_gpu.stream(scene, 100, U, width=W, height=H, start=first, device="cuda",
+                                      chunk=64 if W <= 640 else 16, raw_u16=args.u16)
+    depth = unique_dev if reps == 1 else unique_dev.repeat(reps, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()
 
-    ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B, sub_batches=args.sub_batches, **intr)
+    ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B_max, sub_batches=args.sub_batches, **intr)
     stream = torch.cuda.current_stream().cuda_stream
-    summ_bytes = B * SUMMARY_DTYPE.itemsize
-    summ_t = None
-    stage, gathered, works = None, None, [None, None]
-    if use_dist:
-        # one RCCL all-gather of the 1296-B primitive lists per batch.  The lists are copied out of the library's
-        # buffer (5 MB, D2D) and gathered asynchronously, so the collective of batch k runs under the kernels of batch
-        # k+1; a staging slot is reused only after its gather has completed.
-        summ_t = torch.as_tensor(_DevMem(ex.summaries_pointer(), summ_bytes), device="cuda")
-        stage = [torch.empty(summ_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        gathered = [torch.empty(world * summ_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    gather = args.gather if multi else "none"
+    lay, recv, works, local_view = None, None, [None, None], [None, None]
+    if gather != "none":
+        # planes_per_frame = 16 is a budget for the whole shard (a frame may hold up to 64); an overflow would be
+        # reported in the packed header, and is checked after the timed region
+        lay = ex.gather_configure(B_max, planes_per_frame=16, cylinders_per_frame=8)
+        recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+        if gather == "native":
+            uid = cdist.broadcast_unique_id(ex.comm_unique_id, rank, device="cuda")
+            ex.comm_init(uid, rank, world)
     step_no = [0]
 
     def step():
@@ -177,15 +206,23 @@ def main():
             ex.extract_device(depth.data_ptr(), B, stream)
         if args.match:
             ex.match_consecutive(B, 0, stream)
-        if use_dist:
+        if gather == "native":
+            # pack kernels on this stream, ONE ncclAllGather on the handle's communication stream behind an event: the
+            # collective of step k runs under the kernels of step k+1 (two staging slots, two receive buffers)
+            ex.gather(B, first, recv[step_no[0] & 1].data_ptr(), stream)
+            step_no[0] += 1
+        elif gather == "torch":
             k = step_no[0] & 1
             step_no[0] += 1
             if works[k] is not None:
                 works[k].wait()
-            stage[k].copy_(summ_t, non_blocking=True)
-            works[k] = dist.all_gather_into_tensor(gathered[k], stage[k], async_op=True)
+            ptr = ex.pack(B, first, stream)
+            local_view[k] = torch.as_tensor(_DevMem(ptr, lay["bytes_per_rank"]), device="cuda")
+            works[k] = dist.all_gather_into_tensor(recv[k], local_view[k], async_op=True)
 
     def drain():
+        if gather == "native":
+            ex.gather_wait(host_sync=True)
         for k in range(2):
             if works[k] is not None:
                 works[k].wait()
@@ -195,7 +232,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if use_dist:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     ex.reset_timings()
@@ -205,7 +242,7 @@ def main():
         step()
     drain()  # every gather has landed before the clock stops
     torch.cuda.synchronize()
-    if use_dist:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -213,12 +250,26 @@ def main():
     tm = ex.timings()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if use_dist:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    gather_check = None
+    if gather != "none":
+        # outside the timed region: what arrived is every rank's shard, in rank order, nothing dropped
+        shards = cdist.unpack_gathered(recv[(step_no[0] - 1) & 1].cpu().numpy(), world, lay)
+        spans = [cdist.shard_range(total, r, world) for r in range(world)]
+        ok = all(sh.first_frame == spans[r][0] and int(sh.header["n_frames"]) == spans[r][1] - spans[r][0]
+                 for r, sh in enumerate(shards))
+        gather_check = {"ok": bool(ok), "frames": int(sum(int(sh.header["n_frames"]) for sh in shards)),
+                        "planes": int(sum(int(sh.header["n_planes_total"]) for sh in shards)),
+                        "overflow": int(max(int(sh.header["overflow"]) for sh in shards)),
+                        "bytes_per_rank": int(lay["bytes_per_rank"])}
+        if not ok:
+            raise SystemExit(f"gathered shards are inconsistent: {gather_check}")
+
     if rank == 0:
-        frames_total = world * B * args.steps
+        frames_total = total * args.steps if multi else B * args.steps
         cells = (W // 20) * (H // 20)
         calls = max(1, tm["calls"])
         fpl = tm["frames"] / calls  # frames per kernel launch (= B unless the batch is cut in sub-batches)
@@ -237,16 +288,28 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel") == dom and tj.get("frames_per_launch") == fpl and tj.get("width") == W:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/traffic.json: static, from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                      "profiles/collect.sh over this same command -- not measured by this run")
             except Exception:
                 traffic = None
         e2e_bytes_per_frame = W * H * (2 if args.u16 else 4) + 2 * cells * 4 + 32 * 128  # 1 239 040 B at 640x480
+        if multi:
+            workload = (f"{W}x{H} synthetic TUM-like depth stream of {total} frames sharded in contiguous blocks over {world} GPU(s), "
+                        f"planes" + (" + cylinder RANSAC" if args.cylinders else " only") +
+                        f", one ncclAllGather of the packed primitive lists per step (BASELINE.json configs[3])" if scene == "tumlike"
+                        else f"{W}x{H} synthetic {scene} depth stream of {total} frames sharded over {world} GPU(s)")
+        elif scene == "room" and not args.cylinders:
+            workload = f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])"
+        else:
+            workload = (f"{W}x{H} synthetic {scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only"))
+        workload += (" + consecutive-frame plane matching" if args.match else "") + (", raw uint16 input" if args.u16 else "")
         out = {
             "metric": "depth frames/s primitive extraction (640x480)" if (W, H) == (640, 480)
                       else f"depth frames/s primitive extraction ({W}x{H})",
@@ -257,22 +320,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if multi else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"{W}x{H} synthetic planar-room depth stream, plane extraction only (BASELINE.json configs[1])"
-                             if (args.scene == "room" and not args.cylinders) else
-                             f"{W}x{H} synthetic {args.scene} depth stream, planes" + (" + cylinder RANSAC" if args.cylinders else " only")
-                             + (" + consecutive-frame plane matching" if args.match else "")
-                             + (", raw uint16 input" if args.u16 else "")),
-                "frames_per_step_per_gpu": B, "unique_frames_per_gpu": U, "scene": args.scene, "sub_batches": args.sub_batches,
-                "sharding": "contiguous frame blocks per GPU" + (", RCCL all-gather of 1296-B primitive lists per step" if world > 1 else ""),
+                "workload": workload,
+                "frames_per_step_per_gpu": B, "stream_frames": total, "unique_frames_per_gpu": U, "scene": scene,
+                "sub_batches": args.sub_batches, "frames_rendered_on": "host (numpy)" if args.host_synth else "device (torch)",
+                "sharding": "contiguous frame blocks per GPU (cape_amd.dist.shard_range)" +
+                            (f", packed primitive lists all-gathered once per step ({gather})" if gather != "none" else ""),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
-                "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic,
+                "frac": achieved * 1e9 / HBM_PEAK_BYTES_S, "traffic": traffic, "traffic_source": traffic_source,
                 # also against the 6.29 TB/s a streaming kernel can actually reach (MI355X_MICROARCH.md)
                 "frac_of_achievable_6p29TBps": achieved * 1e9 / 6.29e12,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
@@ -283,14 +344,23 @@ def main():
                 "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
             },
         }
+        if gather_check is not None:
+            out["gather"] = gather_check
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(unique, intr, cylinders=args.cylinders)
+            n_host = min(U, 64)
+            if args.u16:
+                sample = unique_dev[:n_host].cpu().numpy().view(np.uint16).astype(np.float32) * np.float32(0.2)
+            else:
+                sample = unique_dev[:n_host].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample, intr, cylinders=args.cylinders, scene=scene)
         result_line = json.dumps(out)
     else:
         result_line = None
 
+    if gather == "native":
+        ex.comm_destroy()
     ex.close()
-    if use_dist:
+    if multi:
         dist.destroy_process_group()
     if result_line is not None:
         print(result_line, flush=True)

@@ -52,7 +52,8 @@ enum
     CAPE_FRAME_CYL_OVERFLOW = 1u << 2,
     CAPE_FRAME_BIN_NEAR_EDGE = 1u << 3,     /* a cell's histogram angle fell within 1e-9 of a bin edge (libm tie risk) */
     CAPE_FRAME_INORDER_CELLS = 1u << 4,     /* >=1 cell took the in-order accumulation path (exactness guard) */
-    CAPE_FRAME_RNG_EXHAUSTED = 1u << 5      /* RANSAC asked for more draws than the precomputed mt19937 table */
+    CAPE_FRAME_RNG_EXHAUSTED = 1u << 5,     /* RANSAC asked for more draws than the precomputed mt19937 table */
+    CAPE_FRAME_SEED_LIMIT = 1u << 6         /* the seed loop hit its iteration guard (4 * cells + 1024; provably unreachable) */
 };
 
 /*
@@ -118,7 +119,8 @@ typedef struct cape_frame_header
     int32_t n_planar_cells;
 } cape_frame_header;
 
-/* Fixed-capacity per-frame record; this is what the multi-GPU gather exchanges. */
+/* Fixed-capacity per-frame record (stays on the producing GPU / goes to its host; the multi-GPU gather ships the packed
+ * lists below). */
 typedef struct cape_frame_record
 {
     cape_frame_header header;
@@ -126,31 +128,83 @@ typedef struct cape_frame_record
     cape_cylinder cylinders[CAPE_MAX_CYLINDERS];
 } cape_frame_record;
 
-/* Compact per-frame primitive list: what plane_container / cylinder_container hold after find_primitives
- * (shape_primitives.hpp:129-130), without polygons.  This is the payload of the multi-GPU gather
- * (SURVEY.md 8e): 1296 bytes per frame; the full cape_frame_record, label grids and boundary points stay on the
- * producing GPU. */
-#define CAPE_SUMMARY_PLANES 16
-#define CAPE_SUMMARY_CYLINDERS 8
-typedef struct cape_primitive_summary
+/*
+ * Multi-GPU exchange (BASELINE.json configs[3], [4]).  Frames shard by contiguous blocks, one GPU per
+ * block, no collective inside a frame; once per batch the ranks all-gather what plane_container / cylinder_container
+ * hold after find_primitives (shape_primitives.hpp:129-130), optionally with the two label grids.  The lists are ragged,
+ * so each rank PACKS its shard on the device into one buffer of a fixed byte count (what ncclAllGather needs):
+ *
+ *   cape_packed_header | frames_capacity x cape_packed_frame | planes_capacity x cape_packed_plane |
+ *   cylinders_capacity x cape_packed_cylinder | [frames_capacity x cells u8 plane labels | same, cylinder labels]
+ *
+ * planes_capacity = frames_capacity x planes_per_frame is a budget for the whole shard, not per frame: nothing is
+ * truncated unless the shard's TOTAL exceeds it, which the header reports (planes_per_frame = CAPE_MAX_PLANES can never
+ * overflow).  Sections start on 16-byte boundaries; cape_gather_layout has the offsets.
+ */
+#define CAPE_PACKED_MAGIC 0x43415045u /* "CAPE" */
+enum
 {
-    int32_t n_planes;       /* may exceed CAPE_SUMMARY_PLANES: only the first 16 are listed */
-    int32_t n_cylinders;
-    uint32_t status;        /* CAPE_FRAME_* */
+    CAPE_GATHER_LABELS = 1u << 0 /* also ship _gridPlaneSegmentMap / _gridCylinderSegMap, one byte per cell each */
+};
+enum
+{
+    CAPE_PACKED_PLANES_DROPPED = 1u << 0,   /* cape_packed_header.overflow */
+    CAPE_PACKED_CYLINDERS_DROPPED = 1u << 1
+};
+typedef struct cape_packed_header
+{
+    uint32_t magic;             /* CAPE_PACKED_MAGIC */
+    int32_t n_frames;           /* frames of this shard */
+    int32_t first_frame;        /* index of the shard's first frame in the whole batch (caller supplied) */
+    int32_t n_planes_total;     /* planes found in the shard; only min(total, capacity) are listed */
+    int32_t n_cylinders_total;
+    int32_t planes_capacity;
+    int32_t cylinders_capacity;
+    uint32_t overflow;          /* CAPE_PACKED_*_DROPPED */
+    uint32_t status_or;         /* OR of the frames' CAPE_FRAME_* bits */
+    int32_t cells;
+    int32_t frames_capacity;
+    uint32_t flags;             /* CAPE_GATHER_* */
+} cape_packed_header;
+typedef struct cape_packed_frame
+{
+    int32_t plane_offset;       /* first plane of the frame in the planes section */
+    int32_t n_planes;           /* planeContainer.size() before the polygon validity test */
+    int32_t cylinder_offset;
+    int32_t n_cylinders;        /* cylinderContainer.size() */
+    uint32_t status;            /* CAPE_FRAME_* */
     int32_t n_plane_segments;
-    struct
-    {
-        double normal[3];   /* Plane::get_normal() */
-        double d;           /* Plane::get_d() */
-        double centroid[3];
-        double mse;
-    } planes[CAPE_SUMMARY_PLANES];
-    struct
-    {
-        double axis[3];
-        double radius;
-    } cylinders[CAPE_SUMMARY_CYLINDERS];
-} cape_primitive_summary;
+} cape_packed_frame;
+typedef struct cape_packed_plane /* SURVEY.md 8e record: what Plane(planeSeg, polygon) is built from, minus the polygon */
+{
+    double normal[3];           /* Plane::get_normal() */
+    double d;                   /* Plane::get_d() */
+    double centroid[3];
+    double mse;
+    double score;
+    double sums[9];             /* Sx Sy Sz Sxs Sys Szs Sxy Syz Szx: get_point_cloud_covariance() follows from them */
+    uint32_t point_count;
+    uint32_t segment;           /* index of the segment in the producing frame's record */
+} cape_packed_plane;
+typedef struct cape_packed_cylinder
+{
+    double axis[3];
+    double radius;              /* NaN, as in the reference */
+} cape_packed_cylinder;
+
+typedef struct cape_gather_config
+{
+    int32_t frames_capacity;     /* largest shard (frames per rank) this handle will pack; <= max_batch */
+    int32_t planes_per_frame;    /* budget: planes_capacity = frames_capacity x planes_per_frame; 0 = 16; CAPE_MAX_PLANES never overflows */
+    int32_t cylinders_per_frame; /* 0 = 8 */
+    uint32_t flags;              /* CAPE_GATHER_LABELS */
+} cape_gather_config;
+typedef struct cape_gather_layout
+{
+    uint64_t bytes_per_rank;
+    uint64_t frames_offset, planes_offset, cylinders_offset, plane_labels_offset, cyl_labels_offset; /* labels: 0 if absent */
+    int32_t frames_capacity, planes_capacity, cylinders_capacity, cells;
+} cape_gather_layout;
 
 /* Per-cell statistics (debug / parity access to Primitive_Detection::_planeGrid, _cellDistanceTols,
  * Histogram::_bins; primitive_detection.hpp:205-218).  One struct per cell, cell-row-major. */
@@ -263,8 +317,30 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
  * (_gridPlaneSegmentMap / _gridCylinderSegMap, primitive_detection.hpp:212-214) ; boundary: n_frames x
  * boundary_capacity x 3 doubles (compute_plane_segment_boundary, primitive_detection.cpp:650-703). */
 int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, int32_t** cyl_labels, double** boundary);
-/* Device pointer to n_frames x cape_primitive_summary of the last cape_extract (the gather payload). */
-int cape_device_summaries(cape_handle h, void** summaries);
+/* Sizes the packed buffer (two staging slots of bytes_per_rank on the device) and reports its layout.  May be called
+ * again to change the capacities (synchronises). */
+int cape_gather_configure(cape_handle h, const cape_gather_config* cfg, cape_gather_layout* layout_out);
+/* Packs the results of the last cape_extract (frames [0, n_frames) of it) into the next staging slot, asynchronously on
+ * `stream`; first_frame goes into the header.  *packed_dev (optional) receives the slot's device address. */
+int cape_pack_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void** packed_dev, void* stream);
+/* Synchronous copy of the slot filled by the last cape_pack_primitives / cape_gather_primitives (bytes_per_rank bytes). */
+int cape_copy_packed(cape_handle h, void* packed_host);
+
+/* RCCL communicator of the handle (librccl is dlopen'ed on first use).  Rank 0 makes the 128-byte id with
+ * cape_comm_unique_id and hands it to the other ranks by any means (file, socket, MPI, torch.distributed store);
+ * every rank then calls cape_comm_init, which is collective (ncclCommInitRank on the handle's device). */
+#define CAPE_COMM_ID_BYTES 128
+int cape_comm_unique_id(void* id_out);
+int cape_comm_init(cape_handle h, const void* id, int32_t rank, int32_t world);
+int cape_comm_destroy(cape_handle h);
+/* One batch's exchange: cape_pack_primitives on `stream`, then ONE ncclAllGather of bytes_per_rank per rank on the
+ * handle's own communication stream (behind an event, so it runs under whatever the caller enqueues next on `stream`).
+ * recv_dev: world x bytes_per_rank device bytes, rank r's shard at r x bytes_per_rank; it must stay untouched until the
+ * gather has completed.  A staging slot is reused only after the gather that read it is done (two slots). */
+int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void* recv_dev, void* stream);
+/* Orders after the last cape_gather_primitives: with host_sync != 0 the call returns when the gather has landed,
+ * otherwise `stream` is made to wait for it (hipStreamWaitEvent). */
+int cape_gather_wait(cape_handle h, void* stream, int32_t host_sync);
 
 /* Synchronous D2H of the results of the last cape_extract.  Any pointer may be NULL. */
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
@@ -272,6 +348,11 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
 
 /* Debug / parity: per-cell stats of one frame of the last batch (synchronous). */
 int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* cells_out);
+
+/* Debug / parity: the seed cells of one frame of the last batch in the order grow_planes_and_cylinders tried them
+ * (primitive_detection.cpp:277-307; header.n_seeds of them, at most `capacity` are copied, *n_out = header.n_seeds).
+ * Synchronous. */
+int cape_copy_seed_sequence(cape_handle h, int32_t frame, int32_t* seeds_out, int32_t capacity, int32_t* n_out);
 
 /* show_statistics (primitive_detection.hpp:46-49): stage timings from HIP events recorded on the caller's stream
  * around each kernel of every cape_extract made while timing is enabled.  cape_get_timings synchronises the

@@ -14,12 +14,20 @@
 #include "cape_internal.h"
 
 namespace cape {
-void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
-void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
-void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
+// every launcher returns the error of its own launch(es) (hipGetLastError right behind hipLaunchKernelGGL)
+hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
-void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
-void launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_pack(const PackParams& p, hipStream_t stream);
+const char* rccl_load(); // nullptr on success, else the reason
+int rccl_unique_id(RcclUniqueId* id);
+int rccl_comm_init(void** comm, int world, const RcclUniqueId& id, int rank);
+int rccl_comm_destroy(void* comm);
+int rccl_all_gather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t stream);
+const char* rccl_error_string(int code);
 int grow_waves_per_group();
 int grow_waves_per_cu(const StageBParams& p);
 } // namespace cape
@@ -43,6 +51,39 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 constexpr int kRngTable = 40000; // upper bound on RANSAC draws per frame (cylinder section)
+
+// Every entry point that allocates, copies, launches or synchronises runs with the HANDLE's device current, whatever
+// the calling thread had selected (one process may drive several GPUs, torch may leave another device current), and
+// gives the caller its device back on the way out.
+class DeviceGuard
+{
+  public:
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&_prev) != hipSuccess)
+            _prev = -1;
+        _err = (_prev == device) ? hipSuccess : hipSetDevice(device);
+        _restore = (_err == hipSuccess) && _prev >= 0 && _prev != device;
+    }
+    ~DeviceGuard()
+    {
+        if (_restore)
+            (void)hipSetDevice(_prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    hipError_t error() const { return _err; }
+
+  private:
+    int _prev = -1;
+    hipError_t _err = hipSuccess;
+    bool _restore = false;
+};
+
+#define CAPE_ON_DEVICE(h)                                                                                    \
+    DeviceGuard _deviceGuard((h)->cfg.device);                                                               \
+    if (_deviceGuard.error() != hipSuccess)                                                                  \
+    return fail(CAPE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_deviceGuard.error()))
 
 } // namespace
 
@@ -87,9 +128,9 @@ struct cape_handle_s
     int32_t* cellBins = nullptr;
     cape::CellAux* cellAux = nullptr;
     double* cellMse = nullptr;
+    uint16_t* seedSeq = nullptr;
     // results
     cape_frame_record* records = nullptr;
-    cape_primitive_summary* summaries = nullptr;
     int32_t* planeLabels = nullptr;
     int32_t* cylLabels = nullptr;
     double* boundary = nullptr;
@@ -113,6 +154,25 @@ struct cape_handle_s
     hipEvent_t pipeJoin[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> pipeStage;
     int lastFrames = 0;
+    // Per-handle scratch (depth staging, rectify keys, hand-over feedback, result buffers) is reused from call to call
+    // without per-buffer events: ONE stream is in flight per handle.  A call that arrives on another stream first waits
+    // for everything the handle enqueued on the previous one (enter_stream).
+    hipStream_t lastStream = nullptr;
+    bool hasLastStream = false;
+    // multi-GPU gather: two packed staging slots, the RCCL communicator and its stream
+    cape_gather_config gatherCfg{};
+    cape_gather_layout gatherLayout{};
+    unsigned char* packed[2] = {nullptr, nullptr};
+    hipEvent_t packedFree[2] = {nullptr, nullptr}; // recorded behind the gather that read the slot
+    bool packedBusy[2] = {false, false};
+    int packSlot = 1;                              // slot filled by the last cape_pack_primitives
+    hipEvent_t packReady = nullptr;
+    void* comm = nullptr;
+    int commRank = 0, commWorld = 0;
+    hipStream_t commStream = nullptr;
+    hipEvent_t gatherDone = nullptr;
+    bool gatherPending = false;
+    int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
     cape::StageBParams pb{};
 };
@@ -167,12 +227,27 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cellBins);
     (void)hipFree(h->cellAux);
     (void)hipFree(h->cellMse);
+    (void)hipFree(h->seedSeq);
     (void)hipFree(h->records);
-    (void)hipFree(h->summaries);
     (void)hipFree(h->planeLabels);
     (void)hipFree(h->cylLabels);
     (void)hipFree(h->boundary);
     (void)hipFree(h->depthStage);
+    if (h->comm)
+        (void)cape::rccl_comm_destroy(h->comm);
+    h->comm = nullptr;
+    for (int k = 0; k < 2; ++k)
+    {
+        (void)hipFree(h->packed[k]);
+        if (h->packedFree[k])
+            (void)hipEventDestroy(h->packedFree[k]);
+    }
+    if (h->packReady)
+        (void)hipEventDestroy(h->packReady);
+    if (h->gatherDone)
+        (void)hipEventDestroy(h->gatherDone);
+    if (h->commStream)
+        (void)hipStreamDestroy(h->commStream);
     for (auto& t : h->evPool)
     {
         for (auto& e : t.e)
@@ -222,7 +297,6 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     b.cell_flags = a.cell_flags;
     b.cell_bins = a.cell_bins;
     b.records += F;
-    b.summaries += F;
     b.plane_labels += F * C;
     b.cyl_labels += F * C;
     b.boundary += F * (size_t)h->boundaryCap * 3;
@@ -231,6 +305,7 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
     if (b.needCylinder)
         b.needCylinder += 2 * F; // a sub-batch of n frames uses 1 + n entries of its own
     b.redoList += 2 * F;
+    b.seed_sequence += F * C;
     b.debugCycles += F * cape::kProfileSlots;
 }
 
@@ -266,6 +341,16 @@ int acquire_events(cape_handle_s* h, int frames, cape_handle_s::EvTriple** out)
     return CAPE_OK;
 }
 
+// one stream in flight per handle (see cape_handle_s::lastStream)
+int enter_stream(cape_handle_s* h, hipStream_t st)
+{
+    if (h->hasLastStream && h->lastStream != st)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    h->lastStream = st;
+    h->hasLastStream = true;
+    return CAPE_OK;
+}
+
 // one kernel chain (A1 -> A2 -> B) on `st`, optionally bracketed by timing events
 int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::StageBParams& b, int frames, hipStream_t st)
 {
@@ -275,10 +360,10 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         return rc;
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[0], st));
-    cape::launch_cell_moments(a, frames, st);
+    CAPE_HIP_TRY(cape::launch_cell_moments(a, frames, st));
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
-    cape::launch_cell_plane(a, frames, st);
+    CAPE_HIP_TRY(cape::launch_cell_plane(a, frames, st));
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
     cape::StageBParams bb = b;
@@ -310,7 +395,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         if (probe)
             h->callsSinceProbe = 0;
     }
-    cape::launch_grow(bb, frames, st);
+    CAPE_HIP_TRY(cape::launch_grow(bb, frames, st));
     if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0)
     {
         CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost, bb.needCylinder, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -367,12 +452,17 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         return fail(CAPE_ERR_NO_DEVICE, "no HIP device: libcape_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    CAPE_HIP_TRY(hipSetDevice(cfg->device));
+    DeviceGuard deviceGuard(cfg->device);
+    if (deviceGuard.error() != hipSuccess)
+        return fail(CAPE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(deviceGuard.error()));
+    int ldsLimit = 0;
+    CAPE_HIP_TRY(hipDeviceGetAttribute(&ldsLimit, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device));
 
     cape_handle_s* h = new (std::nothrow) cape_handle_s();
     if (!h)
         return fail(CAPE_ERR_HIP, "out of host memory");
     h->cfg = *cfg;
+    h->ldsLimit = ldsLimit;
     h->hCells = cfg->width / CAPE_CELL_SIZE;
     h->vCells = cfg->height / CAPE_CELL_SIZE;
     h->cells = h->hCells * h->vCells;
@@ -404,6 +494,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->cellBins, B * C));
     CAPE_ALLOC(dalloc(h->cellAux, B * C));
     CAPE_ALLOC(dalloc(h->cellMse, B * C));
+    CAPE_ALLOC(dalloc(h->seedSeq, B * C));
     if (cfg->flags & CAPE_FLAG_CYLINDERS)
     {
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * cape::kCylStride));
@@ -415,7 +506,6 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     CAPE_ALLOC(dalloc(h->records, B));
-    CAPE_ALLOC(dalloc(h->summaries, B));
     CAPE_ALLOC(dalloc(h->planeLabels, B * C));
     CAPE_ALLOC(dalloc(h->cylLabels, B * C));
     CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
@@ -471,7 +561,6 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(hipMemcpy(h->ratioRow, rr.data(), rr.size() * sizeof(float), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
-    CAPE_ALLOC(hipMemset(h->summaries, 0, B * sizeof(cape_primitive_summary)));
 
     // ---- kernel parameter blocks
     cape::StageAParams& a = h->pa;
@@ -517,7 +606,6 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cell_aux = h->cellAux;
     b.cell_mse = h->cellMse;
     b.records = h->records;
-    b.summaries = h->summaries;
     b.plane_labels = h->planeLabels;
     b.cyl_labels = h->cylLabels;
     b.boundary = h->boundary;
@@ -530,6 +618,14 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.needCylinder = h->needCylinder;
     b.redoList = h->redoList;
     b.twoPass = h->needCylinder ? 1 : 0;
+    b.ldsLimitBytes = h->ldsLimit;
+    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > (size_t)h->ldsLimit)
+    {
+        free_all(h);
+        delete h;
+        return fail(CAPE_ERR_UNSUPPORTED, "cell grid too large for the LDS-resident grow kernel on this device (" +
+                                                  std::to_string(ldsLimit) + " bytes of LDS per workgroup)");
+    }
     if (h->needCylinder)
     {
         hipDeviceProp_t prop;
@@ -540,6 +636,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     if (const char* sched = std::getenv("CAPE_SCHEDULE"))
         h->forcedSchedule = std::string(sched) == "two" ? 1 : (std::string(sched) == "single" ? 2 : 0);
     b.debugCycles = h->debugCycles;
+    b.seed_sequence = h->seedSeq;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;
     // cylinder_segment.cpp:132
@@ -553,12 +650,6 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         for (auto& e : h->pipeJoin)
             CAPE_ALLOC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > 160 * 1024)
-    {
-        free_all(h);
-        delete h;
-        return fail(CAPE_ERR_UNSUPPORTED, "cell grid too large for the LDS-resident grow kernel");
-    }
     *out = h;
     return CAPE_OK;
 }
@@ -567,8 +658,12 @@ void cape_destroy(cape_handle h)
 {
     if (!h)
         return;
-    (void)hipSetDevice(h->cfg.device);
-    free_all(h);
+    {
+        DeviceGuard deviceGuard(h->cfg.device);
+        if (h->hasLastStream)
+            (void)hipStreamSynchronize(h->lastStream); // nothing of the handle's may still be running on its buffers
+        free_all(h);
+    }
     delete h;
 }
 
@@ -576,6 +671,7 @@ int cape_get_layout(cape_handle h, cape_layout* out)
 {
     if (!h || !out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    CAPE_ON_DEVICE(h);
     {
         hipDeviceProp_t prop;
         out->compute_units = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -617,8 +713,10 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     h->lastFrames = n_frames;
     if (n_frames == 0)
         return CAPE_OK;
-    CAPE_HIP_TRY(hipSetDevice(h->cfg.device)); // the handle's device, whatever the calling thread had current
+    CAPE_ON_DEVICE(h); // the handle's device, whatever the calling thread had current
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
+        return rc;
     h->pa.depth = depth_dev;
     h->pa.depth_u16 = depth_u16;
     h->pa.u16_scale = scale;
@@ -650,17 +748,17 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
                 return rc;
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[0], h->pipeStream[0]));
-            cape::launch_cell_moments(a, f1 - f0, h->pipeStream[0]);
+            CAPE_HIP_TRY(cape::launch_cell_moments(a, f1 - f0, h->pipeStream[0]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[1], h->pipeStream[0]));
             CAPE_HIP_TRY(hipEventRecord(h->pipeStage[i], h->pipeStream[0]));
             CAPE_HIP_TRY(hipStreamWaitEvent(h->pipeStream[1], h->pipeStage[i], 0));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e2b, h->pipeStream[1]));
-            cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]);
+            CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
-            cape::launch_grow(b, f1 - f0, h->pipeStream[1]);
+            CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));
         }
@@ -670,16 +768,9 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
             CAPE_HIP_TRY(hipEventRecord(h->pipeJoin[i], h->pipeStream[i]));
             CAPE_HIP_TRY(hipStreamWaitEvent(stream, h->pipeJoin[i], 0));
         }
-        CAPE_HIP_TRY(hipGetLastError());
         return CAPE_OK;
     }
-    {
-        const int rc = launch_chain(h, h->pa, h->pb, n_frames, stream);
-        if (rc != CAPE_OK)
-            return rc;
-    }
-    CAPE_HIP_TRY(hipGetLastError());
-    return CAPE_OK;
+    return launch_chain(h, h->pa, h->pb, n_frames, stream);
 }
 
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream_)
@@ -688,7 +779,10 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
     if (n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
+    CAPE_ON_DEVICE(h);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
+        return rc;
     const size_t bytes = (size_t)h->cfg.max_batch * h->cfg.width * h->cfg.height * sizeof(float);
     if (!h->depthStage)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), bytes));
@@ -717,7 +811,7 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
 {
     if (!h || n_frames < 0 || n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
-    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
+    CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)n_frames, C = (size_t)h->cells;
     if (records)
@@ -735,6 +829,7 @@ int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* out)
 {
     if (!h || !out || frame < 0 || frame >= h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame");
+    CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     const size_t C = (size_t)h->cells, off = (size_t)frame * C;
     std::vector<double> sums(C * cape::kSumStride), plane(C * cape::kPlaneStride), score(C);
@@ -768,6 +863,25 @@ int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* out)
     return CAPE_OK;
 }
 
+int cape_copy_seed_sequence(cape_handle h, int32_t frame, int32_t* seeds_out, int32_t capacity, int32_t* n_out)
+{
+    if (!h || !n_out || frame < 0 || frame >= h->cfg.max_batch || capacity < 0 || (capacity > 0 && !seeds_out))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame / buffer");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    cape_frame_header hdr;
+    CAPE_HIP_TRY(hipMemcpy(&hdr, &h->records[frame].header, sizeof(hdr), hipMemcpyDeviceToHost));
+    *n_out = hdr.n_seeds;
+    int n = hdr.n_seeds < h->cells ? hdr.n_seeds : h->cells; // the buffer keeps one entry per cell
+    n = n < capacity ? n : capacity;
+    std::vector<uint16_t> tmp((size_t)(n > 0 ? n : 0));
+    if (n > 0)
+        CAPE_HIP_TRY(hipMemcpy(tmp.data(), h->seedSeq + (size_t)frame * h->cells, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+        seeds_out[i] = (int32_t)tmp[(size_t)i];
+    return CAPE_OK;
+}
+
 int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_dev, int32_t n_frames,
                        const double* cam2_to_cam1, void* stream_)
 {
@@ -777,7 +891,10 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
         return CAPE_OK;
     if (depth_dev == rectified_dev)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "rectify_depth is not in-place");
+    CAPE_ON_DEVICE(h);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
+        return rc;
     const size_t frameSize = (size_t)h->cfg.width * h->cfg.height;
     if (h->rectKeyFrames < (size_t)n_frames)
     {
@@ -803,8 +920,7 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
     p.fy = h->cfg.fy;
     p.cx = h->cfg.cx;
     p.cy = h->cfg.cy;
-    cape::launch_rectify(p, n_frames, stream);
-    CAPE_HIP_TRY(hipGetLastError());
+    CAPE_HIP_TRY(cape::launch_rectify(p, n_frames, stream));
     return CAPE_OK;
 }
 
@@ -813,6 +929,7 @@ int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* recti
 {
     if (!h || !depth_host || !rectified_host || n_frames < 0)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or negative frame count");
+    CAPE_ON_DEVICE(h);
     const size_t bytes = (size_t)n_frames * h->cfg.width * h->cfg.height * sizeof(float);
     float *din = nullptr, *dout = nullptr;
     CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&din), bytes));
@@ -826,6 +943,8 @@ int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* recti
         rc = fail(CAPE_ERR_HIP, "H2D copy failed");
     if (rc == CAPE_OK)
         rc = cape_rectify_depth(h, din, dout, n_frames, cam2_to_cam1, nullptr);
+    if (rc == CAPE_OK && hipStreamSynchronize(nullptr) != hipSuccess)
+        rc = fail(CAPE_ERR_HIP, "rectify kernels failed");
     if (rc == CAPE_OK && hipMemcpy(rectified_host, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(CAPE_ERR_HIP, "D2H copy failed");
     (void)hipFree(din);
@@ -843,7 +962,9 @@ int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void
         return fail(CAPE_ERR_INVALID_ARGUMENT, "unknown match flag");
     if (n_frames == 0)
         return CAPE_OK;
-    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
+    CAPE_ON_DEVICE(h);
+    if (const int rc = enter_stream(h, static_cast<hipStream_t>(stream_)); rc != CAPE_OK)
+        return rc;
     if (!h->matches)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matches), (size_t)h->cfg.max_batch * sizeof(cape_frame_match)));
     cape::MatchParams p;
@@ -857,8 +978,7 @@ int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void
     p.maxDistance = 100.0;
     const double planeMinimalOverlap = static_cast<double>(0.4f);
     p.minOverlap = (flags & CAPE_MATCH_ADVANCED) ? planeMinimalOverlap / 2 : planeMinimalOverlap;
-    cape::launch_match(p, n_frames, static_cast<hipStream_t>(stream_));
-    CAPE_HIP_TRY(hipGetLastError());
+    CAPE_HIP_TRY(cape::launch_match(p, n_frames, static_cast<hipStream_t>(stream_)));
     return CAPE_OK;
 }
 
@@ -878,17 +998,263 @@ int cape_copy_matches(cape_handle h, int32_t n_frames, cape_frame_match* out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
     if (!h->matches)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_consecutive has not run");
-    CAPE_HIP_TRY(hipSetDevice(h->cfg.device));
+    CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     CAPE_HIP_TRY(hipMemcpy(out, h->matches, (size_t)n_frames * sizeof(cape_frame_match), hipMemcpyDeviceToHost));
     return CAPE_OK;
 }
 
-int cape_device_summaries(cape_handle h, void** summaries)
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU gather of the packed primitive lists (see cape_gather.hip)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+void fill_layout(const cape_handle_s* h, const cape_gather_config& c, cape_gather_layout& L)
 {
-    if (!h || !summaries)
+    L = cape_gather_layout{};
+    L.frames_capacity = c.frames_capacity;
+    L.planes_capacity = c.frames_capacity * c.planes_per_frame;
+    L.cylinders_capacity = c.frames_capacity * c.cylinders_per_frame;
+    L.cells = h->cells;
+    size_t off = align16(sizeof(cape_packed_header));
+    L.frames_offset = off;
+    off = align16(off + (size_t)L.frames_capacity * sizeof(cape_packed_frame));
+    L.planes_offset = off;
+    off = align16(off + (size_t)L.planes_capacity * sizeof(cape_packed_plane));
+    L.cylinders_offset = off;
+    off = align16(off + (size_t)L.cylinders_capacity * sizeof(cape_packed_cylinder));
+    if (c.flags & CAPE_GATHER_LABELS)
+    {
+        L.plane_labels_offset = off;
+        off = align16(off + (size_t)L.frames_capacity * h->cells);
+        L.cyl_labels_offset = off;
+        off = align16(off + (size_t)L.frames_capacity * h->cells);
+    }
+    L.bytes_per_rank = off;
+}
+
+// default capacities the first time a pack / gather is asked for without cape_gather_configure
+int ensure_gather_configured(cape_handle_s* h)
+{
+    if (h->packed[0])
+        return CAPE_OK;
+    cape_gather_config c{};
+    c.frames_capacity = h->cfg.max_batch;
+    return cape_gather_configure(h, &c, nullptr);
+}
+
+int pack_into_next_slot(cape_handle_s* h, int n_frames, int first_frame, hipStream_t stream)
+{
+    const int slot = h->packSlot ^ 1;
+    // the slot may still be read by the all-gather of two batches ago
+    if (h->packedBusy[slot])
+    {
+        CAPE_HIP_TRY(hipStreamWaitEvent(stream, h->packedFree[slot], 0));
+        h->packedBusy[slot] = false;
+    }
+    const cape_gather_layout& L = h->gatherLayout;
+    unsigned char* base = h->packed[slot];
+    cape::PackParams p{};
+    p.records = h->records;
+    p.planeLabelsIn = h->planeLabels;
+    p.cylLabelsIn = h->cylLabels;
+    p.header = reinterpret_cast<cape_packed_header*>(base);
+    p.frames = reinterpret_cast<cape_packed_frame*>(base + L.frames_offset);
+    p.planes = reinterpret_cast<cape_packed_plane*>(base + L.planes_offset);
+    p.cylinders = reinterpret_cast<cape_packed_cylinder*>(base + L.cylinders_offset);
+    p.planeLabels8 = L.plane_labels_offset ? base + L.plane_labels_offset : nullptr;
+    p.cylLabels8 = L.cyl_labels_offset ? base + L.cyl_labels_offset : nullptr;
+    p.nFrames = n_frames;
+    p.firstFrame = first_frame;
+    p.framesCapacity = L.frames_capacity;
+    p.planesCapacity = L.planes_capacity;
+    p.cylindersCapacity = L.cylinders_capacity;
+    p.cells = h->cells;
+    p.flags = h->gatherCfg.flags;
+    CAPE_HIP_TRY(cape::launch_pack(p, stream));
+    h->packSlot = slot;
+    return CAPE_OK;
+}
+} // namespace
+
+int cape_gather_configure(cape_handle h, const cape_gather_config* cfg, cape_gather_layout* layout_out)
+{
+    if (!h || !cfg)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
-    *summaries = h->summaries;
+    cape_gather_config c = *cfg;
+    if (c.planes_per_frame == 0)
+        c.planes_per_frame = 16;
+    if (c.cylinders_per_frame == 0)
+        c.cylinders_per_frame = 8;
+    if (c.frames_capacity <= 0 || c.frames_capacity > h->cfg.max_batch || c.planes_per_frame < 0 ||
+        c.planes_per_frame > CAPE_MAX_PLANES || c.cylinders_per_frame < 0 || c.cylinders_per_frame > CAPE_MAX_CYLINDERS ||
+        (c.flags & ~(uint32_t)CAPE_GATHER_LABELS))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "frames_capacity in [1, max_batch], planes/cylinders per frame in [1, 64], known flags");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old slots
+    cape_gather_layout L;
+    fill_layout(h, c, L);
+    for (int k = 0; k < 2; ++k)
+    {
+        (void)hipFree(h->packed[k]);
+        h->packed[k] = nullptr;
+        h->packedBusy[k] = false;
+    }
+    h->gatherPending = false;
+    for (int k = 0; k < 2; ++k)
+    {
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->packed[k]), L.bytes_per_rank));
+        CAPE_HIP_TRY(hipMemset(h->packed[k], 0, L.bytes_per_rank));
+        if (!h->packedFree[k])
+            CAPE_HIP_TRY(hipEventCreateWithFlags(&h->packedFree[k], hipEventDisableTiming));
+    }
+    if (!h->packReady)
+        CAPE_HIP_TRY(hipEventCreateWithFlags(&h->packReady, hipEventDisableTiming));
+    if (!h->gatherDone)
+        CAPE_HIP_TRY(hipEventCreateWithFlags(&h->gatherDone, hipEventDisableTiming));
+    h->gatherCfg = c;
+    h->gatherLayout = L;
+    if (layout_out)
+        *layout_out = L;
+    return CAPE_OK;
+}
+
+int cape_pack_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void** packed_dev, void* stream_)
+{
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
+    if (n_frames > h->lastFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
+    CAPE_ON_DEVICE(h);
+    if (const int rc = ensure_gather_configured(h); rc != CAPE_OK)
+        return rc;
+    if (n_frames > h->gatherLayout.frames_capacity)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds cape_gather_config.frames_capacity");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
+        return rc;
+    if (const int rc = pack_into_next_slot(h, n_frames, first_frame, stream); rc != CAPE_OK)
+        return rc;
+    if (packed_dev)
+        *packed_dev = h->packed[h->packSlot];
+    return CAPE_OK;
+}
+
+int cape_copy_packed(cape_handle h, void* packed_host)
+{
+    if (!h || !packed_host)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->packed[0])
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "nothing has been packed yet");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    CAPE_HIP_TRY(hipMemcpy(packed_host, h->packed[h->packSlot], h->gatherLayout.bytes_per_rank, hipMemcpyDeviceToHost));
+    return CAPE_OK;
+}
+
+int cape_comm_unique_id(void* id_out)
+{
+    if (!id_out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    if (const char* why = cape::rccl_load())
+        return fail(CAPE_ERR_UNSUPPORTED, why);
+    cape::RcclUniqueId id;
+    if (const int rc = cape::rccl_unique_id(&id); rc != 0)
+        return fail(CAPE_ERR_HIP, std::string("ncclGetUniqueId: ") + cape::rccl_error_string(rc));
+    std::memcpy(id_out, id.internal, CAPE_COMM_ID_BYTES);
+    return CAPE_OK;
+}
+
+int cape_comm_init(cape_handle h, const void* id_, int32_t rank, int32_t world)
+{
+    if (!h || !id_ || world <= 0 || rank < 0 || rank >= world)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or rank outside [0, world)");
+    if (h->comm)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "the handle already has a communicator (cape_comm_destroy first)");
+    if (const char* why = cape::rccl_load())
+        return fail(CAPE_ERR_UNSUPPORTED, why);
+    CAPE_ON_DEVICE(h);
+    cape::RcclUniqueId id;
+    std::memcpy(id.internal, id_, CAPE_COMM_ID_BYTES);
+    if (!h->commStream)
+        CAPE_HIP_TRY(hipStreamCreateWithFlags(&h->commStream, hipStreamNonBlocking));
+    if (const int rc = cape::rccl_comm_init(&h->comm, world, id, rank); rc != 0)
+    {
+        h->comm = nullptr;
+        return fail(CAPE_ERR_HIP, std::string("ncclCommInitRank: ") + cape::rccl_error_string(rc));
+    }
+    h->commRank = rank;
+    h->commWorld = world;
+    return CAPE_OK;
+}
+
+int cape_comm_destroy(cape_handle h)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->comm)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    if (h->commStream)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->commStream));
+    const int rc = cape::rccl_comm_destroy(h->comm);
+    h->comm = nullptr;
+    h->gatherPending = false;
+    if (rc != 0)
+        return fail(CAPE_ERR_HIP, std::string("ncclCommDestroy: ") + cape::rccl_error_string(rc));
+    return CAPE_OK;
+}
+
+int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void* recv_dev, void* stream_)
+{
+    if (!h || !recv_dev || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or negative frame count");
+    if (!h->comm)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "no communicator: call cape_comm_init first");
+    if (n_frames > h->lastFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
+    CAPE_ON_DEVICE(h);
+    if (const int rc = ensure_gather_configured(h); rc != CAPE_OK)
+        return rc;
+    if (n_frames > h->gatherLayout.frames_capacity)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds cape_gather_config.frames_capacity");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
+        return rc;
+    if (const int rc = pack_into_next_slot(h, n_frames, first_frame, stream); rc != CAPE_OK)
+        return rc;
+    const int slot = h->packSlot;
+    // the collective runs on the handle's own stream, behind the pack kernels: the caller's stream is free for the
+    // kernels of the next batch
+    CAPE_HIP_TRY(hipEventRecord(h->packReady, stream));
+    CAPE_HIP_TRY(hipStreamWaitEvent(h->commStream, h->packReady, 0));
+    if (const int rc = cape::rccl_all_gather_bytes(h->packed[slot], recv_dev, h->gatherLayout.bytes_per_rank, h->comm, h->commStream);
+        rc != 0)
+        return fail(CAPE_ERR_HIP, std::string("ncclAllGather: ") + cape::rccl_error_string(rc));
+    CAPE_HIP_TRY(hipEventRecord(h->packedFree[slot], h->commStream));
+    h->packedBusy[slot] = true;
+    CAPE_HIP_TRY(hipEventRecord(h->gatherDone, h->commStream));
+    h->gatherPending = true;
+    return CAPE_OK;
+}
+
+int cape_gather_wait(cape_handle h, void* stream_, int32_t host_sync)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->gatherPending)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    if (host_sync)
+    {
+        CAPE_HIP_TRY(hipEventSynchronize(h->gatherDone));
+        h->gatherPending = false;
+    }
+    else
+    {
+        CAPE_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_), h->gatherDone, 0));
+    }
     return CAPE_OK;
 }
 
@@ -896,6 +1262,7 @@ int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out)
 {
     if (!h || !out || n_frames < 0 || n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     CAPE_HIP_TRY(hipMemcpy(out, h->debugCycles, (size_t)n_frames * cape::kProfileSlots * 8, hipMemcpyDeviceToHost));
     return CAPE_OK;
@@ -913,6 +1280,7 @@ int cape_get_timings(cape_handle h, cape_timings* out)
 {
     if (!h || !out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    CAPE_ON_DEVICE(h);
     const int rc = fold_timings(h);
     if (rc != CAPE_OK)
         return rc;
@@ -924,6 +1292,7 @@ int cape_reset_timings(cape_handle h)
 {
     if (!h)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    CAPE_ON_DEVICE(h);
     const int rc = fold_timings(h);
     h->tm = cape_timings{};
     return rc;

@@ -545,19 +545,23 @@ __global__ __launch_bounds__(256, CAPE_A2_WAVES) void cape_cell_plane_kernel(Sta
                           (planar ? kFlagPlanar : 0u);
 }
 
-void launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
+// every launch helper reports its own failure: hipGetLastError() right behind the launch (a later runtime call would
+// overwrite the sticky-free error state on ROCm < 7)
+hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
 {
     const int grid = nFrames * p.pairsPerFrame;
     if (p.depth)
         hipLaunchKernelGGL(cape_cell_moments_kernel<false>, dim3(grid), dim3(kThreadsA), 0, stream, p);
     else
         hipLaunchKernelGGL(cape_cell_moments_kernel<true>, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    return hipGetLastError();
 }
 
-void launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream)
+hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream)
 {
     const size_t cellsTotal = (size_t)nFrames * p.cells;
     hipLaunchKernelGGL(cape_cell_plane_kernel, dim3((unsigned)((cellsTotal + 255) / 256)), dim3(256), 0, stream, p, nFrames);
+    return hipGetLastError();
 }
 
 } // namespace cape

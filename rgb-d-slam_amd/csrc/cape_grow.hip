@@ -530,6 +530,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         const int seed = 0x7FFFFFFF - (int)wave_max_u32(idxKey);
         if (__longlong_as_double((long long)bestAll) >= kDblMax)
             break; // "invalid seed" (:299-304)
+        if (lane == 0 && p.seed_sequence && nSeeds < C)
+            p.seed_sequence[cellBase + nSeeds] = (uint16_t)seed; // debug / parity stream: seeds in the order they were tried
         ++nSeeds;
 
         // ---- grow_plane_segment_at_seed (:312-389)
@@ -720,6 +722,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         }
     }
 
+    if (untried > 0 && nSeeds >= maxSeedIters)
+        status |= CAPE_FRAME_SEED_LIMIT; // cannot happen (see maxSeedIters); says so if it ever does
+
     CAPE_B_STOP(3);
     CAPE_TICK(9);
     // =========================================================================================
@@ -807,7 +812,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     }
     CAPE_WAVE_SYNC();
     cape_frame_record* rec = p.records + frame;
-    cape_primitive_summary* sum = p.summaries + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
     const double acolCenter = p.acol[(lane < HC ? lane : 0) * kCell + kCell / 2];
     const double browCenterOfLane = p.brow[(lane < VC ? lane : 0) * kCell + kCell / 2]; // row r's value is broadcast below
@@ -920,14 +924,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
             o->is_output = isOutput;
             o->boundary_offset = bOff;
             o->boundary_count = bCnt;
-            if (isOutput && nPlanesOut <= CAPE_SUMMARY_PLANES)
-            {
-                auto& sp = sum->planes[nPlanesOut - 1];
-                sp.normal[0] = onx; sp.normal[1] = ony; sp.normal[2] = onz;
-                sp.d = A.d;
-                sp.centroid[0] = A.cx; sp.centroid[1] = A.cy; sp.centroid[2] = A.cz;
-                sp.mse = A.mse;
-            }
         }
     }
 
@@ -961,17 +957,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         if (kept)
         {
             if (lane == 0)
-            {
                 rec->cylinders[ci].kept = 1;
-                if (nCylOut < CAPE_SUMMARY_CYLINDERS)
-                {
-                    auto& sc = sum->cylinders[nCylOut];
-                    sc.axis[0] = rec->cylinders[ci].axis[0];
-                    sc.axis[1] = rec->cylinders[ci].axis[1];
-                    sc.axis[2] = rec->cylinders[ci].axis[2];
-                    sc.radius = __builtin_nan("");
-                }
-            }
             ++nCylOut;
         }
     }
@@ -996,22 +982,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
         rec->header.n_seeds = nSeeds;
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
-        sum->n_planes = nPlanesOut;
-        sum->n_cylinders = nCylOut;
-        sum->status = status;
-        sum->n_plane_segments = nSeg;
-    }
-    // unused slots of the gather payload are zeroed, so that what travels between GPUs depends on this frame only
-    {
-        constexpr int kPlaneDoubles = sizeof(sum->planes[0]) / 8, kCylDoubles = sizeof(sum->cylinders[0]) / 8;
-        double* sp = reinterpret_cast<double*>(&sum->planes[0]);
-        const int usedP = (nPlanesOut < CAPE_SUMMARY_PLANES ? nPlanesOut : CAPE_SUMMARY_PLANES) * kPlaneDoubles;
-        for (int i = usedP + lane; i < CAPE_SUMMARY_PLANES * kPlaneDoubles; i += 64)
-            sp[i] = 0.0;
-        double* sc = reinterpret_cast<double*>(&sum->cylinders[0]);
-        const int usedC = (nCylOut < CAPE_SUMMARY_CYLINDERS ? nCylOut : CAPE_SUMMARY_CYLINDERS) * kCylDoubles;
-        for (int i = usedC + lane; i < CAPE_SUMMARY_CYLINDERS * kCylDoubles; i += 64)
-            sc[i] = 0.0;
     }
 #ifdef CAPE_B_PROFILE
     CAPE_WAVE_SYNC();
@@ -1047,7 +1017,7 @@ int grow_waves_per_cu(const StageBParams& p)
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
     const int ldsPerWave = (int)grow_lds_bytes(p.cells, cyl, kFastPlanes);
     int wpg = kWavesPerGroup;
-    while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
+    while (wpg > 1 && (size_t)ldsPerWave * wpg > (size_t)p.ldsLimitBytes)
         --wpg;
     int blocks = 0;
     hipError_t e;
@@ -1063,18 +1033,21 @@ int grow_waves_per_cu(const StageBParams& p)
 namespace {
 
 template <bool CYL, int MAXP>
-void launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
+hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 {
     const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL, MAXP);
-    int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the 160 KB of LDS admit (<= kWavesPerGroup)
-    while (wpg > 1 && (size_t)ldsPerWave * wpg > 160 * 1024)
+    int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the device's LDS admits (<= kWavesPerGroup)
+    while (wpg > 1 && (size_t)ldsPerWave * wpg > (size_t)p.ldsLimitBytes)
         --wpg;
     const size_t lds = (size_t)ldsPerWave * wpg;
+    if (lds > (size_t)p.ldsLimitBytes)
+        return hipErrorInvalidConfiguration; // cape_create refuses such grids; belt and braces
     const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
         hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     else
         hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+    return hipGetLastError();
 }
 
 } // namespace
@@ -1087,31 +1060,40 @@ void launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 // frames from the start (densely packed: a workgroup of the cylinder kernel owns 60 % of a CU's LDS, so idle waves in
 // it would cost real occupancy).  A frame that never
 // takes the branch is bit-identical in both kernels (the branch is their only difference).
-void launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
 {
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
-    // counters of the two hand-over lists ([0] = count, [1..] = frames), zeroed together: they are adjacent
+#define CAPE_LAUNCH_TRY(expr)              \
+    do                                     \
+    {                                      \
+        const hipError_t e_ = (expr);      \
+        if (e_ != hipSuccess)              \
+            return e_;                     \
+    } while (0)
+    // counters of the two hand-over lists ([0] = count, [1..] = frames)
     if (p.redoList)
-        (void)hipMemsetAsync(p.redoList, 0, sizeof(uint32_t), stream);
+        CAPE_LAUNCH_TRY(hipMemsetAsync(p.redoList, 0, sizeof(uint32_t), stream));
     if (!cyl)
     {
-        launch_grow_variant<false, kFastPlanes>(p, nFrames, stream);
+        CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
         if (p.redoList)
-            launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream); // frames with more than 32 segments (rare)
-        return;
+            CAPE_LAUNCH_TRY((launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream))); // frames with more than 32 segments (rare)
+        return hipSuccess;
     }
     if (!p.twoPass)
     {
-        launch_grow_variant<true, kFastPlanes>(p, nFrames, stream); // nearly every frame needs it anyway: skip the plane-only pass
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream))); // nearly every frame needs it anyway: skip the plane-only pass
     }
     else
     {
-        (void)hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream);
-        launch_grow_variant<false, kFastPlanes>(p, nFrames, stream);
-        launch_grow_variant<true, kFastPlanes>(p, nFrames, stream);
+        CAPE_LAUNCH_TRY(hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream));
+        CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream)));
     }
     if (p.redoList)
-        launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream);
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));
+    return hipSuccess;
+#undef CAPE_LAUNCH_TRY
 }
 
 } // namespace cape

@@ -74,7 +74,6 @@ struct StageBParams
     const CellAux* cell_aux;
     const double* cell_mse;
     cape_frame_record* records;
-    cape_primitive_summary* summaries;
     int32_t* plane_labels;
     int32_t* cyl_labels;
     double* boundary;
@@ -94,6 +93,8 @@ struct StageBParams
     uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
+    uint16_t* seed_sequence; // [frames][cells] seed cells in the order the seed loop tried them (first n_seeds entries valid)
+    int ldsLimitBytes;       // host side only: LDS one workgroup may ask for on the handle's device (queried at cape_create)
 };
 
 // N3: Depth_Map_Transformation::rectify_depth
@@ -120,6 +121,27 @@ struct MatchParams
     double minCosAngle;     // abs(cos(20 * pi / 180)), shape_primitives.cpp:72-73
     double maxDistance;     // 100 mm, shape_primitives.cpp:84
     double minOverlap;      // (double)0.4f, halved for the advanced search (map_primitive.cpp:106-107)
+};
+
+// multi-GPU gather: device-side packing of the ragged primitive lists (cape_gather.hip)
+struct PackParams
+{
+    const cape_frame_record* records;
+    const int32_t* planeLabelsIn;
+    const int32_t* cylLabelsIn;
+    cape_packed_header* header;
+    cape_packed_frame* frames;
+    cape_packed_plane* planes;
+    cape_packed_cylinder* cylinders;
+    uint8_t* planeLabels8;
+    uint8_t* cylLabels8;
+    int nFrames, firstFrame, framesCapacity, planesCapacity, cylindersCapacity, cells;
+    uint32_t flags;
+};
+
+struct RcclUniqueId
+{
+    char internal[CAPE_COMM_ID_BYTES]; // ncclUniqueId
 };
 
 } // namespace cape

@@ -149,10 +149,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void cape_match_kernel(MatchPa
         (&out.inter[0][0])[k] = (uint16_t)inter[k];
 }
 
-void launch_match(const MatchParams& p, int nFrames, hipStream_t stream)
+hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream)
 {
     const int groups = (nFrames + kWavesPerGroup - 1) / kWavesPerGroup;
     hipLaunchKernelGGL(cape_match_kernel, dim3(groups), dim3(64 * kWavesPerGroup), 0, stream, p, nFrames);
+    return hipGetLastError();
 }
 
 } // namespace cape

@@ -60,12 +60,15 @@ __global__ __launch_bounds__(256) void cape_rectify_resolve_kernel(RectifyParams
     p.keys[g] = 0ull;
 }
 
-void launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream)
+hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream)
 {
     const size_t n = (size_t)nFrames * p.W * p.H;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(cape_rectify_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, n);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
     hipLaunchKernelGGL(cape_rectify_resolve_kernel, dim3(blocks), dim3(256), 0, stream, p, n);
+    return hipGetLastError();
 }
 
 } // namespace cape

@@ -23,6 +23,7 @@ FRAME_CYL_OVERFLOW = 1 << 2
 FRAME_BIN_NEAR_EDGE = 1 << 3
 FRAME_INORDER_CELLS = 1 << 4
 FRAME_RNG_EXHAUSTED = 1 << 5
+FRAME_SEED_LIMIT = 1 << 6
 
 
 class CapeError(RuntimeError):
@@ -60,11 +61,39 @@ HEADER_DTYPE = np.dtype([
 FRAME_RECORD_DTYPE = np.dtype([
     ("header", HEADER_DTYPE), ("segments", PLANE_SEGMENT_DTYPE, CAPE_MAX_PLANES),
     ("cylinders", CYLINDER_DTYPE, CAPE_MAX_CYLINDERS)], align=True)
-SUMMARY_DTYPE = np.dtype([
-    ("n_planes", "<i4"), ("n_cylinders", "<i4"), ("status", "<u4"), ("n_plane_segments", "<i4"),
-    ("planes", np.dtype([("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8")]), 16),
-    ("cylinders", np.dtype([("axis", "<f8", 3), ("radius", "<f8")]), 8)], align=True)
-assert SUMMARY_DTYPE.itemsize == 1296
+# packed gather payload (include/cape_hip.h: cape_packed_*)
+PACKED_MAGIC = 0x43415045
+GATHER_LABELS = 1
+PACKED_PLANES_DROPPED = 1
+PACKED_CYLINDERS_DROPPED = 2
+COMM_ID_BYTES = 128
+PACKED_HEADER_DTYPE = np.dtype([
+    ("magic", "<u4"), ("n_frames", "<i4"), ("first_frame", "<i4"), ("n_planes_total", "<i4"),
+    ("n_cylinders_total", "<i4"), ("planes_capacity", "<i4"), ("cylinders_capacity", "<i4"), ("overflow", "<u4"),
+    ("status_or", "<u4"), ("cells", "<i4"), ("frames_capacity", "<i4"), ("flags", "<u4")], align=True)
+PACKED_FRAME_DTYPE = np.dtype([
+    ("plane_offset", "<i4"), ("n_planes", "<i4"), ("cylinder_offset", "<i4"), ("n_cylinders", "<i4"),
+    ("status", "<u4"), ("n_plane_segments", "<i4")], align=True)
+PACKED_PLANE_DTYPE = np.dtype([
+    ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"), ("score", "<f8"), ("sums", "<f8", 9),
+    ("point_count", "<u4"), ("segment", "<u4")], align=True)
+PACKED_CYLINDER_DTYPE = np.dtype([("axis", "<f8", 3), ("radius", "<f8")], align=True)
+assert (PACKED_HEADER_DTYPE.itemsize, PACKED_FRAME_DTYPE.itemsize, PACKED_PLANE_DTYPE.itemsize,
+        PACKED_CYLINDER_DTYPE.itemsize) == (48, 24, 152, 32)
+
+
+class cape_gather_config(C.Structure):
+    _fields_ = [("frames_capacity", C.c_int32), ("planes_per_frame", C.c_int32), ("cylinders_per_frame", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class cape_gather_layout(C.Structure):
+    _fields_ = [("bytes_per_rank", C.c_uint64), ("frames_offset", C.c_uint64), ("planes_offset", C.c_uint64),
+                ("cylinders_offset", C.c_uint64), ("plane_labels_offset", C.c_uint64), ("cyl_labels_offset", C.c_uint64),
+                ("frames_capacity", C.c_int32), ("planes_capacity", C.c_int32), ("cylinders_capacity", C.c_int32),
+                ("cells", C.c_int32)]
+
+
 MATCH_DTYPE = np.dtype([
     ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", CAPE_MAX_PLANES), ("area_prev", "<u2", CAPE_MAX_PLANES),
     ("area_cur", "<u2", CAPE_MAX_PLANES), ("inter", "<u2", (CAPE_MAX_PLANES, CAPE_MAX_PLANES))], align=True)
@@ -78,9 +107,10 @@ CELL_STATS_DTYPE = np.dtype([
 
 EXPORTED_SYMBOLS = [
     "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
-    "cape_device_summaries", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
+    "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
+    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_wait", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
-    "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles",
+    "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -118,12 +148,20 @@ def load_library():
     L.cape_enable_timing.argtypes = [vp, C.c_int32]
     L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
     L.cape_reset_timings.argtypes = [vp]
-    L.cape_device_summaries.argtypes = [vp, C.POINTER(vp)]
+    L.cape_gather_configure.argtypes = [vp, C.POINTER(cape_gather_config), C.POINTER(cape_gather_layout)]
+    L.cape_pack_primitives.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), vp]
+    L.cape_copy_packed.argtypes = [vp, vp]
+    L.cape_comm_unique_id.argtypes = [vp]
+    L.cape_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.cape_comm_destroy.argtypes = [vp]
+    L.cape_gather_primitives.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    L.cape_gather_wait.argtypes = [vp, vp, C.c_int32]
     L.cape_match_consecutive.argtypes = [vp, C.c_int32, C.c_uint32, vp]
     L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
     L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
     L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
     L.cape_debug_cycles.argtypes = [vp, C.c_int32, vp]
+    L.cape_copy_seed_sequence.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.cape_last_error.restype = C.c_char_p
     L.cape_version.restype = C.c_char_p
     _lib = L
@@ -245,6 +283,14 @@ class Extractor:
         _check(self.L, self.L.cape_copy_cell_stats(self.h, frame, out.ctypes.data_as(C.c_void_p)), "cape_copy_cell_stats")
         return out
 
+    def seed_sequence(self, frame):
+        """Seed cells of one frame in the order the seed loop tried them (parity stream)."""
+        out = np.zeros(self.cells, np.int32)
+        n = C.c_int32(0)
+        _check(self.L, self.L.cape_copy_seed_sequence(self.h, frame, out.ctypes.data_as(C.c_void_p), self.cells, C.byref(n)),
+               "cape_copy_seed_sequence")
+        return out[: min(n.value, self.cells)]
+
     def debug_cycles(self, n_frames):
         out = np.zeros((n_frames, 32), np.uint64)
         _check(self.L, self.L.cape_debug_cycles(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_debug_cycles")
@@ -257,10 +303,44 @@ class Extractor:
     def reset_timings(self):
         _check(self.L, self.L.cape_reset_timings(self.h), "cape_reset_timings")
 
-    def summaries_pointer(self):
+    # ---- multi-GPU gather of the packed primitive lists -------------------------------------------
+    def gather_configure(self, frames_capacity, planes_per_frame=0, cylinders_per_frame=0, labels=False):
+        cfg = cape_gather_config(frames_capacity, planes_per_frame, cylinders_per_frame, GATHER_LABELS if labels else 0)
+        lay = cape_gather_layout()
+        _check(self.L, self.L.cape_gather_configure(self.h, C.byref(cfg), C.byref(lay)), "cape_gather_configure")
+        self.gather_layout = {f: int(getattr(lay, f)) for f, _ in cape_gather_layout._fields_}
+        return self.gather_layout
+
+    def pack(self, n_frames, first_frame=0, stream=0):
         p = C.c_void_p()
-        _check(self.L, self.L.cape_device_summaries(self.h, C.byref(p)), "cape_device_summaries")
+        _check(self.L, self.L.cape_pack_primitives(self.h, n_frames, first_frame, C.byref(p), C.c_void_p(stream)),
+               "cape_pack_primitives")
         return p.value
+
+    def packed_host(self):
+        out = np.zeros(self.gather_layout["bytes_per_rank"], np.uint8)
+        _check(self.L, self.L.cape_copy_packed(self.h, out.ctypes.data_as(C.c_void_p)), "cape_copy_packed")
+        return out
+
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _check(self.L, self.L.cape_comm_unique_id(buf), "cape_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self.L, self.L.cape_comm_init(self.h, buf, rank, world), "cape_comm_init")
+
+    def comm_destroy(self):
+        _check(self.L, self.L.cape_comm_destroy(self.h), "cape_comm_destroy")
+
+    def gather(self, n_frames, first_frame, recv_ptr, stream=0):
+        """pack + ONE ncclAllGather (RCCL called from the C layer) of bytes_per_rank per rank into recv_ptr."""
+        _check(self.L, self.L.cape_gather_primitives(self.h, n_frames, first_frame, C.c_void_p(recv_ptr), C.c_void_p(stream)),
+               "cape_gather_primitives")
+
+    def gather_wait(self, stream=0, host_sync=True):
+        _check(self.L, self.L.cape_gather_wait(self.h, C.c_void_p(stream), 1 if host_sync else 0), "cape_gather_wait")
 
     def timings(self):
         t = cape_timings()

@@ -1,0 +1,128 @@
+"""The synthetic streams of cape_amd.synth rendered ON THE GPU with torch, a batch of frames at a time.
+
+bench.py needs thousands of distinct frames resident in HBM (a 4 096-frame room stream, 8 x 2 048 TUM-like
+frames for the sharded run); the numpy generators take 50-80 ms per frame on one host core.  Same scenes, same camera
+trajectories (the pose functions are shared with synth.py), same noise / quantisation / hole model; the random numbers
+come from torch's generator instead of Philox, so the frames are NOT byte-identical to synth.py's -- they are bench
+input, never a parity fixture (the CPU baseline and the parity spot checks of bench.py read the very frames generated
+here back from the device).  Plumbing: this module owns no part of the product path.
+"""
+import numpy as np
+
+from . import synth
+
+
+def _poses(scene, seed, start, n):
+    """(tan(yaw/2), tan(pitch/2), origin) per frame -- the trajectory formulas of synth.room / tumlike / tunnel."""
+    out = []
+    tag = {"room": 0x726F6F6D, "tumlike": 0x74756D, "tunnel": 0x74756E6E}[scene]
+    ph = synth._Rng(tag, seed).uniform((4,))
+    for i in range(n):
+        f = start + i
+        if scene == "room":
+            ty = 0.18 * synth._tri(ph[0] + f / 257.0) + 0.07
+            tp = 0.08 * synth._tri(ph[1] + f / 181.0) - 0.03
+            o = (300.0 * synth._tri(ph[2] + f / 409.0), -150.0 + 100.0 * synth._tri(ph[3] + f / 331.0), 0.0)
+        elif scene == "tumlike":
+            ty = 0.10 * synth._tri(ph[0] + f / 193.0) + 0.105
+            tp = 0.05 * synth._tri(ph[1] + f / 149.0) - 0.12
+            o = (100.0 * synth._tri(ph[2] + f / 233.0), -400.0, 0.0)
+        else:
+            ty = 0.06 * synth._tri(ph[0] + f / 211.0) + 0.02
+            tp = 0.04 * synth._tri(ph[1] + f / 173.0) - 0.01
+            o = (150.0 * synth._tri(ph[2] + f / 307.0), 100.0 * synth._tri(ph[3] + f / 263.0), 0.0)
+        out.append((synth._rotation(ty, tp), np.array(o, dtype=np.float64)))
+    return out
+
+
+def stream(scene, seed, n_frames, width=640, height=480, start=0, device="cuda", chunk=64, raw_u16=False):
+    """n_frames x H x W float32 millimetres on `device` (or the raw uint16 TUM sensor units with raw_u16=True)."""
+    import torch
+
+    if scene not in ("room", "tumlike", "tunnel"):
+        raise ValueError(scene)
+    s = width / 640.0
+    base = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+    intr = {k: v * s for k, v in base.items()}
+    f64 = torch.float64
+    u = (torch.arange(width, dtype=f64, device=device) - intr["cx"]) / intr["fx"]
+    v = (torch.arange(height, dtype=f64, device=device) - intr["cy"]) / intr["fy"]
+    Y, X = torch.meshgrid(v, u, indexing="ij")
+    rays = torch.stack([X, Y, torch.ones_like(X)], dim=-1)  # H x W x 3, camera frame
+    gen = torch.Generator(device=device)
+    gen.manual_seed((int(seed) * 1000003 + start) & 0x7FFFFFFF)
+    inf = float("inf")
+    out = torch.empty((n_frames, height, width), dtype=torch.int16 if raw_u16 else torch.float32, device=device)
+
+    def hit_plane(o, dw, n, c):
+        n = torch.tensor(n, dtype=f64, device=device)
+        den = dw @ n                                    # c x H x W
+        num = (c - o @ n)[:, None, None]
+        t = num / den
+        return torch.where((den != 0) & (t > 0), t, torch.full_like(t, inf))
+
+    for c0 in range(0, n_frames, chunk):
+        cn = min(chunk, n_frames - c0)
+        poses = _poses(scene, seed, start + c0, cn)
+        R = torch.tensor(np.stack([p[0] for p in poses]), dtype=f64, device=device)  # c x 3 x 3
+        o = torch.tensor(np.stack([p[1] for p in poses]), dtype=f64, device=device)  # c x 3
+        dw = torch.einsum("hwk,cjk->chwj", rays, R)                                  # d @ R.T per frame
+        if scene == "room":
+            lo, hi = (-2000.0, -1500.0, -1500.0), (2000.0, 1500.0, 3500.0)
+            t = torch.full(dw.shape[:3], inf, dtype=f64, device=device)
+            for ax in range(3):
+                n = [0.0, 0.0, 0.0]
+                n[ax] = 1.0
+                t = torch.minimum(t, hit_plane(o, dw, n, lo[ax]))
+                t = torch.minimum(t, hit_plane(o, dw, n, hi[ax]))
+            mode, holes = "mm", 0.02
+        elif scene == "tumlike":
+            t = hit_plane(o, dw, [0.0, 1.0, 0.0], 600.0)
+            t = torch.minimum(t, hit_plane(o, dw, [0.0, 0.0, 1.0], 2500.0))
+            t = torch.minimum(t, hit_plane(o, dw, [1.0, 0.0, 0.0], 1600.0))
+            blo = torch.tensor([-500.0, 200.0, 1300.0], dtype=f64, device=device)
+            bhi = torch.tensor([100.0, 600.0, 1700.0], dtype=f64, device=device)
+            t0 = (blo - o)[:, None, None, :] / dw
+            t1 = (bhi - o)[:, None, None, :] / dw
+            tn = torch.minimum(t0, t1).amax(dim=-1)
+            tf = torch.maximum(t0, t1).amin(dim=-1)
+            t = torch.minimum(t, torch.where((tn <= tf) & (tn > 0), tn, torch.full_like(tn, inf)))
+            mode, holes = "tum", 0.08
+        else:
+            a = np.array([0.05, 0.03, 1.0])
+            a = torch.tensor(a / np.sqrt(a @ a), dtype=f64, device=device)
+            dperp = dw - (dw @ a)[..., None] * a
+            operp = o - (o @ a)[:, None] * a                                          # c x 3
+            A = (dperp * dperp).sum(-1)
+            B = 2.0 * torch.einsum("chwk,ck->chw", dperp, operp)
+            Cc = ((operp * operp).sum(-1) - 1200.0 * 1200.0)[:, None, None]
+            disc = B * B - 4 * A * Cc
+            tt = (-B + torch.sqrt(torch.clamp(disc, min=0.0))) / (2 * A)
+            t = torch.where((disc >= 0) & (A > 0) & (tt > 0), tt, torch.full_like(tt, inf))
+            t = torch.minimum(t, hit_plane(o, dw, [0.0, 1.0, 0.0], 900.0))
+            t = torch.where(t > 8000.0, torch.full_like(t, inf), t)
+            mode, holes = "mm", 0.02
+        del dw
+        # synth._finish: sigma = 0.5 * quant(z), sensor quantisation, random holes
+        z = torch.where(torch.isfinite(t), t, torch.zeros_like(t))
+        valid = z > 0
+        quant = torch.clamp(-0.53 + 0.74e-3 * z + 2.73e-6 * z * z, min=0.5)
+        z = z + 0.5 * quant * torch.randn(z.shape, dtype=f64, device=device, generator=gen)
+        hole = torch.rand(z.shape, dtype=torch.float32, device=device, generator=gen) < holes
+        if mode == "mm":
+            raw = torch.round(z)
+            res = raw.to(torch.float32)
+        else:
+            raw = torch.clamp(torch.round(5.0 * z), 0, 65535)
+            res = raw.to(torch.float32) * np.float32(1.0 / 5.0)
+        bad = hole | ~valid | (res <= 0)
+        if scene == "tumlike":
+            bad[:, :, : int(12 * s)] = True  # Kinect shadow band
+        if raw_u16:
+            if mode == "mm":
+                raw = torch.clamp(torch.round(5.0 * z), 0, 65535)  # 1/5 mm sensor units for every scene
+            raw = torch.where(bad, torch.zeros_like(raw), raw)
+            out[c0:c0 + cn] = raw.to(torch.int32).to(torch.int16)  # bit pattern of the uint16 value
+        else:
+            out[c0:c0 + cn] = torch.where(bad, torch.zeros_like(res), res)
+    return out

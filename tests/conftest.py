@@ -9,15 +9,50 @@ for p in (os.path.join(ROOT, "rgb-d-slam_amd", "python"), os.path.join(ROOT, "or
         sys.path.insert(0, p)
 
 
+LIB_DIR = os.path.join(ROOT, "rgb-d-slam_amd", "lib")
+CSRC_DIR = os.path.join(ROOT, "rgb-d-slam_amd", "csrc")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The built libraries are git-ignored; they normally travel with the working tree, but a fresh checkout has none.
-    # Building is not a fallback for the product (which still fails loudly without its .so): it is what build() does.
-    lib = os.path.join(ROOT, "rgb-d-slam_amd", "lib")
-    if not all(os.path.exists(os.path.join(lib, f)) for f in ("libcape_hip.so", "libcape_primitives.so", "test_shim.exe", "test_polygon.exe")):
-        import subprocess
 
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "rgb-d-slam_amd", "csrc"), "all", "host"])
+
+def _make(targets, needs_hipcc):
+    """Build git-ignored products on demand (what __graft_entry__.build() does); skip -- never abort the session --
+    when the toolchain for them is absent.  Building is not a fallback for the product, which still fails loudly
+    without its .so."""
+    import shutil
+    import subprocess
+
+    if needs_hipcc and not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc is not installed: cannot build " + " ".join(targets))
+    r = subprocess.run(["make", "-C", CSRC_DIR] + targets, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.fail("make " + " ".join(targets) + " failed:\n" + r.stderr[-2000:])
+
+
+@pytest.fixture(scope="session")
+def hip_library():
+    """Path of libcape_hip.so, built if a fresh checkout has none."""
+    path = os.path.join(LIB_DIR, "libcape_hip.so")
+    if not os.path.exists(path):
+        _make(["all"], needs_hipcc=True)
+    return path
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_need_the_library(request):
+    if request.node.get_closest_marker("gpu") is not None:
+        request.getfixturevalue("hip_library")
+
+
+@pytest.fixture(scope="session")
+def host_binaries(hip_library):
+    """The C++ mirror library and its drivers (g++ only, but they link libcape_hip.so)."""
+    names = ("libcape_primitives.so", "test_shim.exe", "test_polygon.exe")
+    if not all(os.path.exists(os.path.join(LIB_DIR, f)) for f in names):
+        _make(["host"], needs_hipcc=False)
+    return LIB_DIR
 
 
 @pytest.fixture(scope="session")

@@ -13,7 +13,7 @@ def _declared_functions():
     return sorted(set(re.findall(r"\b(cape_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol(hip_library):
     import cape_amd
 
     lib = cape_amd.load_library()
@@ -24,19 +24,20 @@ def test_library_exports_every_declared_symbol():
     assert set(cape_amd.EXPORTED_SYMBOLS) == set(declared)
 
 
-def test_struct_sizes_match_header():
+def test_struct_sizes_match_header(hip_library):
     import cape_amd
 
     assert cape_amd.PLANE_SEGMENT_DTYPE.itemsize == 30 * 8 + 6 * 4
     assert cape_amd.CYLINDER_DTYPE.itemsize == 40
     assert cape_amd.HEADER_DTYPE.itemsize == 32
     assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 64 * 40
-    assert cape_amd.SUMMARY_DTYPE.itemsize == 1296
+    assert cape_amd.PACKED_HEADER_DTYPE.itemsize == 48 and cape_amd.PACKED_FRAME_DTYPE.itemsize == 24
+    assert cape_amd.PACKED_PLANE_DTYPE.itemsize == 152 and cape_amd.PACKED_CYLINDER_DTYPE.itemsize == 32
     assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4
     assert cape_amd.MATCH_DTYPE.itemsize == 8 + 64 * 4 + 2 * 64 * 2 + 64 * 64 * 2
 
 
-def test_no_cpu_fallback():
+def test_no_cpu_fallback(hip_library):
     """Without a HIP device cape_create must fail with CAPE_ERR_NO_DEVICE (-2), never compute on the CPU."""
     import pytest
     import torch

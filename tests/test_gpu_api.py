@@ -1,0 +1,101 @@
+"""Behaviour of the C ABI around the kernels: the handle's device is used whatever device the caller has current
+(and the caller gets its device back), one stream in flight per handle, seed-sequence export, error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _intr():
+    from cape_amd import synth
+
+    return dict(synth.DEFAULT_INTRINSICS)
+
+
+def test_current_device_is_preserved(oracle_mod):
+    """Every entry point selects the handle's device itself and restores the caller's."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    torch.cuda.set_device(0)
+    depth = synth.room(seed=2, frame=4)
+    ex = Extractor(640, 480, cylinders=False, device=0, max_batch=2, **_intr())
+    n = ex.extract_host(depth)
+    res = ex.results(n)
+    assert torch.cuda.current_device() == 0
+    ref = oracle_mod.Oracle(640, 480, cylinders=False, **_intr()).run(depth)
+    assert np.array_equal(res.plane_labels[0], ref.plane_labels)
+    ex.close()
+
+
+def test_handle_on_another_device_than_the_current_one(oracle_mod):
+    """a handle created for device 1 while device 0 is current must allocate, copy, launch and synchronise on
+    device 1 in every entry point (extract_host staging, rectify scratch, cell stats, timings)."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    depth = synth.tumlike(seed=1, frame=0)
+    intr = dict(synth.TUM_FR1_INTRINSICS)
+    ex = Extractor(640, 480, cylinders=True, device=1, max_batch=2, **intr)
+    ex.enable_timing(True)
+    n = ex.extract_host(depth)
+    res = ex.results(n)
+    assert torch.cuda.current_device() == 0
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    ref = orc.run(depth)
+    assert np.array_equal(res.plane_labels[0], ref.plane_labels)
+    assert np.array_equal(ex.cell_stats(0)["bin"], ref.bins)
+    assert ex.timings()["calls"] == 1
+    with torch.cuda.device(1):
+        src = torch.from_numpy(depth).cuda()
+        dst = torch.empty_like(src)
+    ex.rectify_device(src.data_ptr(), dst.data_ptr(), 1, np.eye(4))
+    with torch.cuda.device(1):
+        torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), orc.rectify(depth, np.eye(4)))
+    assert torch.cuda.current_device() == 0
+    ex.close()
+
+
+def test_stream_switch_is_ordered(oracle_mod):
+    """One stream in flight per handle: a call on a second stream first waits for the handle's work on the first one,
+    so the shared scratch (depth staging, per-cell buffers, records) is never overwritten under a running kernel."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    frames = np.stack([synth.room(seed=9, frame=i) for i in range(8)])
+    other = np.stack([synth.tumlike(seed=3, frame=i) for i in range(8)])
+    ex = Extractor(640, 480, cylinders=False, max_batch=8, **_intr())
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **_intr())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        ex.extract_host(other, s1.cuda_stream)      # long-ish work on stream 1 ...
+        ex.extract_host(frames, s2.cuda_stream)     # ... then the same handle on stream 2 right away
+    res = ex.results(8)
+    for f in (0, 3, 7):
+        assert np.array_equal(res.plane_labels[f], orc.run(frames[f]).plane_labels)
+    ex.close()
+
+
+def test_seed_sequence_entry(oracle_mod):
+    from cape_amd import Extractor, synth
+
+    depth = synth.tumlike(seed=2, frame=3)
+    intr = dict(synth.TUM_FR1_INTRINSICS)
+    ex = Extractor(640, 480, cylinders=True, max_batch=1, **intr)
+    ex.extract_host(depth)
+    ref = oracle_mod.Oracle(640, 480, cylinders=True, **intr).run(depth)
+    seeds = ex.seed_sequence(0)
+    assert len(seeds) > 0 and np.array_equal(seeds, ref.seeds)
+    # capacity smaller than the sequence: truncated copy, full length reported
+    out = np.zeros(2, np.int32)
+    n = C.c_int32(0)
+    assert ex.L.cape_copy_seed_sequence(ex.h, 0, out.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == 0
+    assert n.value == len(ref.seeds) and np.array_equal(out, ref.seeds[:2])
+    assert ex.L.cape_copy_seed_sequence(ex.h, 5, out.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == -1  # frame >= max_batch
+    ex.close()

@@ -1,0 +1,151 @@
+"""Multi-GPU exchange on the device side (BASELINE.json configs[3], [4]): the packed primitive lists
+written by cape_pack_primitives equal the ones built from ORACLE results byte for byte, and they travel unchanged
+through (a) ONE ncclAllGather issued by libcape_hip itself (cape_comm_init + cape_gather_primitives, RCCL resolved with
+dlopen) and (b) torch.distributed's nccl (= RCCL) group.  The box has one GPU, so the world is 1 here; the N-rank
+arithmetic (sharding, ragged shards, parsing in rank order) is covered by tests/test_multigpu_gloo.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _DevMem:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _stream(n, seed=2):
+    from cape_amd import synth
+
+    return np.stack([synth.tunnel(seed=seed, frame=f) if f % 4 == 3 else synth.tumlike(seed=seed, frame=f) for f in range(n)])
+
+
+def _setup(n, labels=True, planes_per_frame=0, cylinders_per_frame=0, frames_capacity=None):
+    from cape_amd import Extractor, synth
+
+    intr = dict(synth.TUM_FR1_INTRINSICS)
+    ex = Extractor(640, 480, cylinders=True, max_batch=max(n, frames_capacity or 0), **intr)
+    lay = ex.gather_configure(frames_capacity or n, planes_per_frame, cylinders_per_frame, labels=labels)
+    return ex, lay, intr
+
+
+def test_packed_lists_equal_oracle_bytes(oracle_mod):
+    from cape_amd.dist import Shard, packed_layout
+    from packing import pack_oracle
+
+    n = 10
+    frames = _stream(n)
+    ex, lay, intr = _setup(n, labels=True, frames_capacity=12)  # two unused frame slots: must come out zeroed
+    assert lay == packed_layout(12, 768, 16, 8, labels=True)
+    ex.extract_host(frames)
+    ex.pack(n, first_frame=40)
+    got = ex.packed_host()
+    res = ex.results(n, with_boundary=False)
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    refs = [orc.run(frames[f]) for f in range(n)]
+    want = pack_oracle(refs, 40, lay, labels=True, status=res.records["header"]["status"])
+    sh = Shard(got, lay)
+    assert int(sh.header["n_frames"]) == n and sh.first_frame == 40 and int(sh.header["overflow"]) == 0
+    assert int(sh.header["n_planes_total"]) == sum(len(r.planes) for r in refs) > 0
+    assert int(sh.header["n_cylinders_total"]) == sum(len(r.cylinders) for r in refs) > 0
+    assert np.array_equal(got, want), "packed bytes differ from the oracle-built payload"
+    # packing again (other staging slot) gives the same bytes: what travels depends on the frames only
+    ex.pack(n, first_frame=40)
+    assert np.array_equal(ex.packed_host(), want)
+    ex.close()
+
+
+def test_overflow_is_reported_not_silent(oracle_mod):
+    from cape_amd import PACKED_PLANES_DROPPED
+    from cape_amd.dist import Shard
+
+    n = 6
+    frames = _stream(n)
+    ex, lay, intr = _setup(n, labels=False, planes_per_frame=1, cylinders_per_frame=1)
+    ex.extract_host(frames)
+    ex.pack(n)
+    sh = Shard(ex.packed_host(), lay)
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    total = sum(len(orc.run(frames[f]).planes) for f in range(n))
+    assert total > lay["planes_capacity"] == n
+    assert int(sh.header["n_planes_total"]) == total
+    assert int(sh.header["overflow"]) & PACKED_PLANES_DROPPED
+    assert [int(f["n_planes"]) for f in sh.frames] == [len(orc.run(frames[f]).planes) for f in range(n)]
+    # a budget of CAPE_MAX_PLANES per frame can never overflow
+    lay = ex.gather_configure(n, 64, 64)
+    ex.pack(n)
+    sh = Shard(ex.packed_host(), lay)
+    assert int(sh.header["overflow"]) == 0 and int(sh.header["n_planes_total"]) == total
+    ex.close()
+
+
+def test_native_rccl_gather(oracle_mod):
+    """cape_comm_unique_id -> cape_comm_init -> cape_gather_primitives: the C layer calls librccl itself."""
+    import torch
+    from cape_amd.dist import primitives_by_frame, unpack_gathered
+
+    n = 8
+    frames = _stream(n, seed=5)
+    ex, lay, intr = _setup(n, labels=True)
+    uid = ex.comm_unique_id()
+    assert len(uid) == 128
+    ex.comm_init(uid, 0, 1)
+    recv = torch.zeros(lay["bytes_per_rank"], dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep in range(3):  # both staging slots get reused
+        ex.extract_host(frames, stream)
+        ex.gather(n, 0, recv.data_ptr(), stream)
+    ex.gather_wait(host_sync=True)
+    got = recv.cpu().numpy()
+    assert np.array_equal(got, ex.packed_host()), "gathered bytes differ from the packed staging slot"
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    by_frame = primitives_by_frame(unpack_gathered(got, 1, lay))
+    for f in range(n):
+        r = orc.run(frames[f])
+        planes, cyls = by_frame[f]
+        assert len(planes) == len(r.planes) and len(cyls) == len(r.cylinders)
+        if len(planes):
+            assert np.array_equal(planes["normal"].view(np.uint64), np.ascontiguousarray(r.planes[:, 0:3]).view(np.uint64))
+            assert np.array_equal(planes["d"].view(np.uint64), np.ascontiguousarray(r.planes[:, 3]).view(np.uint64))
+    # stream-ordered wait instead of a host wait
+    ex.extract_host(frames, stream)
+    ex.gather(n, 0, recv.data_ptr(), stream)
+    ex.gather_wait(stream, host_sync=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(recv.cpu().numpy(), got)
+    ex.comm_destroy()
+    ex.close()
+
+
+def test_torch_nccl_group_gather(oracle_mod):
+    """The same payload through torch.distributed's nccl (= RCCL) process group, zero-copy view of the library's slot."""
+    import torch
+    import torch.distributed as dist
+    from cape_amd.dist import all_gather_bytes, unpack_gathered
+
+    n = 5
+    frames = _stream(n, seed=7)
+    ex, lay, intr = _setup(n, labels=False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        ex.extract_host(frames, stream)
+        ptr = ex.pack(n, 0, stream)
+        local = torch.as_tensor(_DevMem(ptr, lay["bytes_per_rank"]), device="cuda")
+        out = all_gather_bytes(local, 1)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, ex.packed_host())
+        sh = unpack_gathered(got, 1, lay)[0]
+        orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+        assert [int(f["n_planes"]) for f in sh.frames] == [len(orc.run(frames[f]).planes) for f in range(n)]
+    finally:
+        if created:
+            dist.destroy_process_group()
+    ex.close()

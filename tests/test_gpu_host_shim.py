@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("scene,seed,frame", [("tumlike", 1, 0), ("tunnel", 0, 0)])
-def test_shim_matches_oracle(oracle_mod, tmp_path, scene, seed, frame):
+def test_shim_matches_oracle(oracle_mod, host_binaries, tmp_path, scene, seed, frame):
     from cape_amd import synth
 
     exe = os.path.join(ROOT, "rgb-d-slam_amd", "lib", "test_shim.exe")

@@ -39,6 +39,7 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert np.array_equal(cs["bin"], orc_res.bins), "histogram bins"
     hdr = res.records["header"][f]
     assert hdr["n_seeds"] == len(orc_res.seeds), "seed loop length"
+    assert np.array_equal(ex.seed_sequence(f), orc_res.seeds), "seed sequence (cells in the order they were tried)"
     assert np.array_equal(res.plane_labels[f], orc_res.plane_labels), "plane label grid (bit-exact)"
     assert np.array_equal(res.cyl_labels[f], orc_res.cyl_labels), "cylinder label grid (bit-exact)"
     segs = res.segments(f)
@@ -296,10 +297,11 @@ def test_cylinders_noisy_and_1280(oracle_mod):
     ex2.close()
 
 
-def test_summaries_visible_to_torch_without_copy():
-    """The gather payload: torch wraps libcape_hip's device buffer through __cuda_array_interface__ (bench.py)."""
+def test_packed_payload_visible_to_torch_without_copy():
+    """The gather payload: torch wraps libcape_hip's packed staging slot through __cuda_array_interface__."""
     import torch
-    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+    from cape_amd import Extractor, synth
+    from cape_amd.dist import Shard
 
     class DevMem:
         def __init__(self, ptr, n):
@@ -307,21 +309,26 @@ def test_summaries_visible_to_torch_without_copy():
 
     frames = synth.stream("tumlike", seed=1, n_frames=3)
     ex = Extractor(640, 480, cylinders=False, max_batch=3, **synth.TUM_FR1_INTRINSICS)
+    lay = ex.gather_configure(3, 64, 64)
     ex.extract_host(frames)
     res = ex.results(3)
-    t = torch.as_tensor(DevMem(ex.summaries_pointer(), 3 * SUMMARY_DTYPE.itemsize), device="cuda")
-    s = np.frombuffer(t.cpu().numpy().tobytes(), dtype=SUMMARY_DTYPE)
-    assert np.array_equal(s["n_planes"], res.records["header"]["n_planes"])
+    ptr = ex.pack(3)
+    torch.cuda.synchronize()
+    t = torch.as_tensor(DevMem(ptr, lay["bytes_per_rank"]), device="cuda")
+    sh = Shard(t.cpu().numpy(), lay)
+    assert np.array_equal(sh.frames["n_planes"], res.records["header"]["n_planes"])
     for f in range(3):
         pl = res.planes(f)
-        k = min(len(pl), 16)
-        assert np.array_equal(s["planes"]["normal"][f, :k], pl["out_normal"][:k])
-        assert np.array_equal(s["planes"]["d"][f, :k], pl["d"][:k])
+        got = sh.frame_planes(f)
+        assert len(got) == len(pl)  # nothing truncated, however many planes a frame holds
+        assert np.array_equal(got["normal"], pl["out_normal"]) and np.array_equal(got["d"], pl["d"])
+        assert np.array_equal(got["sums"], pl["sums"]) and np.array_equal(got["point_count"], pl["point_count"])
     # the payload depends on the current frames only: an empty batch after a busy one leaves nothing behind
     ex.extract_host(np.zeros_like(frames))
-    t = torch.as_tensor(DevMem(ex.summaries_pointer(), 3 * SUMMARY_DTYPE.itemsize), device="cuda")
-    raw = np.frombuffer(t.cpu().numpy().tobytes(), dtype=np.uint8).reshape(3, SUMMARY_DTYPE.itemsize)
-    assert not raw.any(), "stale primitives in the gather payload"
+    ex.pack(3)
+    ex.pack(3)  # both staging slots
+    raw = ex.packed_host()
+    assert not raw[lay["frames_offset"]:].any(), "stale primitives in the gather payload"
     ex.close()
 
 
@@ -478,8 +485,8 @@ def test_rectify_depth_parity(oracle_mod):
 
 def test_large_mixed_batch_labels(oracle_mod):
     """256 different frames in one launch (several independent frame-waves per workgroup): every label grid, plane count
-    and primitive summary equals the frame's own oracle run."""
-    from cape_amd import SUMMARY_DTYPE, Extractor, synth
+    equals the frame's own oracle run."""
+    from cape_amd import Extractor, synth
 
     names = ["room", "facets", "tunnel", "facets"]
     frames = np.stack([synth.SCENES[names[i % 4]](seed=1000 + i, frame=3 * i) for i in range(64)])
@@ -603,4 +610,32 @@ def test_more_than_32_plane_segments(oracle_mod):
         assert int(res.records["header"]["n_plane_segments"][1]) == 34
         for k in range(n):
             compare_frame(want[k], ex, res, k, check_cells=False)
+    ex.close()
+
+
+@pytest.mark.parametrize("scene,cyl", [("room", False), ("tumlike", True), ("tunnel", True)])
+def test_device_rendered_streams_parity(oracle_mod, scene, cyl):
+    """bench.py renders its streams on the GPU (cape_amd.synth_gpu, torch): those frames are fresh inputs, not fixtures --
+    the extractor must agree with the oracle on them like on any other frame, float32 and raw uint16 alike."""
+    import torch
+    from cape_amd import Extractor, synth_gpu
+
+    n = 6
+    intr = _intr(scene)
+    dev = synth_gpu.stream(scene, 77, n, start=1000, device="cuda", chunk=4)
+    frames = dev.cpu().numpy()
+    assert frames.dtype == np.float32 and (frames > 0).mean() > 0.5
+    assert len({frames[i].tobytes() for i in range(n)}) == n, "every frame of a rendered stream is distinct"
+    orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+    ex = Extractor(640, 480, cylinders=cyl, max_batch=n, **intr)
+    ex.extract_device(dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    res = ex.results(n)
+    for f in range(n):
+        compare_frame(orc.run(frames[f]), ex, res, f, check_cells=(f == 0))
+    raw = synth_gpu.stream(scene, 77, 2, start=1000, device="cuda", raw_u16=True)
+    ex.extract_device_u16(raw.data_ptr(), 0.2, 2, torch.cuda.current_stream().cuda_stream)
+    res = ex.results(2)
+    as_f32 = raw.cpu().numpy().view(np.uint16).astype(np.float32) * np.float32(0.2)
+    for f in range(2):
+        compare_frame(orc.run(as_f32[f]), ex, res, f, check_cells=False)
     ex.close()
