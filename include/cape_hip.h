@@ -246,6 +246,10 @@ typedef struct cape_layout
     int32_t grow_frames_per_cu;   /* frames (one wavefront each) the grow kernel keeps in flight per CU (occupancy API) */
 } cape_layout;
 
+/* Number of HIP devices this process sees (0 and CAPE_ERR_NO_DEVICE without a GPU): what a host-side batch API shards
+ * over (one handle per device). */
+int cape_device_count(int32_t* count_out);
+
 /* Depth_Map_Transformation / Primitive_Detection constructors (src/rgbd_slam.cpp:48-57). */
 int cape_create(const cape_config* cfg, cape_handle* out);
 void cape_destroy(cape_handle h);

@@ -436,6 +436,18 @@ extern "C" {
 const char* cape_last_error(void) { return g_lastError.c_str(); }
 const char* cape_version(void) { return "cape_hip 0.1 (gfx950)"; }
 
+int cape_device_count(int32_t* count_out)
+{
+    if (!count_out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    int ndev = 0;
+    *count_out = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CAPE_ERR_NO_DEVICE, "no HIP device: libcape_hip has no CPU fallback");
+    *count_out = ndev;
+    return CAPE_OK;
+}
+
 int cape_create(const cape_config* cfg, cape_handle* out)
 {
     if (!cfg || !out)

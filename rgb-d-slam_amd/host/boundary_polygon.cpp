@@ -455,6 +455,17 @@ double Polygon::inter_over_union(const Polygon& other) const
 
 bool Polygon::is_valid() const noexcept { return ring_is_simple(_ring); }
 
+bool Polygon::is_valid(std::string& reason) const noexcept
+{
+    if (_ring.size() < 3)
+        reason = "Geometry has too few points";
+    else if (!ring_is_simple(_ring))
+        reason = "Geometry has invalid self-intersections";
+    else
+        reason = "Geometry is valid";
+    return is_valid();
+}
+
 double Polygon::area() const noexcept { return _ring.size() < 3 ? 0.0 : std::abs(ring_area_signed(_ring)); }
 
 bool Polygon::contains(const vector2& point) const noexcept { return _ring.size() >= 3 && point_in_ring(point, _ring, false); }

@@ -13,13 +13,16 @@
 #pragma once
 #include <array>
 #include <cstddef>
+#include <string>
 #include <utility>
 #include <vector>
 
+#include "compat/types.hpp" // rgbd_slam::vector2 / vector3 (the reference's src/types.hpp names)
+
 namespace rgbd_slam::utils {
 
-using vector2 = std::array<double, 2>;
-using vector3 = std::array<double, 3>;
+using rgbd_slam::vector2;
+using rgbd_slam::vector3;
 
 // get_plane_coordinate_system (polygon.cpp:74-115): two unit vectors spanning the plane of `normal`
 std::pair<vector3, vector3> get_plane_coordinate_system(const vector3& normal);
@@ -34,6 +37,7 @@ class Polygon
     Polygon(const std::vector<vector3>& points, const vector3& normal, const vector3& center);
 
     [[nodiscard]] bool is_valid() const noexcept;               // simple (non self-intersecting) ring of >= 3 vertices
+    [[nodiscard]] bool is_valid(std::string& reason) const noexcept; // polygon.hpp:84-87: same, with the failure reason
     [[nodiscard]] size_t boundary_length() const noexcept { return _ring.size(); }
     [[nodiscard]] double area() const noexcept;                 // shoelace, >= 0
     [[nodiscard]] double get_area() const noexcept { return _area; }

@@ -1,0 +1,338 @@
+#include "primitive_detection.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <exception>
+#include <string>
+#include <thread>
+
+#include "outputs/logger.hpp"
+#include "parameters.hpp"
+
+namespace rgbd_slam::features::primitives {
+
+namespace {
+// contiguous block of `total` frames owned by shard `k` of `shards` (the first total % shards blocks get one more)
+void block_of(int total, int k, int shards, int& first, int& count)
+{
+    const int q = total / shards, r = total % shards;
+    first = k * q + (k < r ? k : r);
+    count = q + (k < r ? 1 : 0);
+}
+} // namespace
+
+Primitive_Detection::Primitive_Detection(const uint width, const uint height) : _width(width), _height(height)
+{
+    Plane_Segment::set_static_members(parameters::detection::depthMapPatchSize_px,
+                                      parameters::detection::depthMapPatchSize_px * parameters::detection::depthMapPatchSize_px);
+    if (!ensure_shards(1))
+        outputs::log_error(std::string("Primitive_Detection: ") + cape_last_error());
+}
+
+Primitive_Detection::~Primitive_Detection()
+{
+    for (Shard& s : _shards)
+        cape_destroy(s.handle);
+}
+
+// shard i lives on device i % device_count; handles are created on demand and kept
+bool Primitive_Detection::ensure_shards(int wanted) noexcept
+{
+    try
+    {
+        int devices = 0;
+        if (cape_device_count(&devices) != CAPE_OK || devices <= 0)
+            return false; // no GPU: this library has no CPU path, the detector stays "not ready"
+        if (!Parameters::is_valid())
+            Parameters::load_defaut();
+        while (static_cast<int>(_shards.size()) < wanted)
+        {
+            cape_config cfg {};
+            cfg.width = static_cast<int32_t>(_width);
+            cfg.height = static_cast<int32_t>(_height);
+            // camera intrinsics are read once, here (the reference caches them in function-local statics,
+            // point_coordinates.cpp:81)
+            cfg.fx = Parameters::get_camera_1_focal().x();
+            cfg.fy = Parameters::get_camera_1_focal().y();
+            cfg.cx = Parameters::get_camera_1_center().x();
+            cfg.cy = Parameters::get_camera_1_center().y();
+            cfg.flags = CAPE_FLAG_CYLINDERS; // the reference always runs the cylinder branch (primitive_detection.cpp:385-388)
+            cfg.device = static_cast<int>(_shards.size()) % devices;
+            cfg.max_batch = _maxBatch;
+            Shard s;
+            s.device = cfg.device;
+            if (cape_create(&cfg, &s.handle) != CAPE_OK)
+                return false;
+            cape_layout lay {};
+            cape_get_layout(s.handle, &lay);
+            _cells = lay.cells;
+            _boundaryCapacity = lay.boundary_capacity;
+            s.records.resize(_maxBatch);
+            s.boundary.resize(static_cast<size_t>(_maxBatch) * _boundaryCapacity * 3);
+            _shards.push_back(std::move(s));
+        }
+        return true;
+    }
+    catch (const std::exception&)
+    {
+        return false;
+    }
+}
+
+// add_planes_to_primitives / add_cylinders_to_primitives (primitive_detection.cpp:562-648, 705-734), from the record
+void Primitive_Detection::collect(const Shard& shard, int f, plane_container& planes, cylinder_container& cylinders) const
+{
+    planes.clear();
+    cylinders.clear();
+    const cape_frame_record& r = shard.records[f];
+    if (r.header.status & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
+        outputs::log_warning("find_primitives: per-frame capacity exceeded, primitive list truncated");
+    planes.reserve(r.header.n_planes);
+    const double* bnd = shard.boundary.data() + static_cast<size_t>(f) * _boundaryCapacity * 3;
+    std::vector<vector3> orderedBoundary;
+    for (int i = 0; i < r.header.n_plane_segments; ++i)
+    {
+        const cape_plane_segment& s = r.segments[i];
+        if (!s.is_output) // merged away, not planar, or fewer than 3 boundary points (:577-612)
+            continue;
+        const Plane_Segment planeSegment(s);
+        orderedBoundary.clear();
+        orderedBoundary.reserve(s.boundary_count);
+        const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
+        for (uint32_t k = 0; k < s.boundary_count; ++k)
+            orderedBoundary.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        try
+        {
+            // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
+            const CameraPolygon polygon(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center());
+            std::string debug;
+            if (polygon.is_valid(debug) and polygon.boundary_length() >= 3)
+                planes.emplace_back(planeSegment, polygon);
+            else
+                outputs::log_error("Polyfit error: " + debug);
+        }
+        catch (const std::exception& e)
+        {
+            outputs::log_error(std::string("Polyfit error: ") + e.what());
+        }
+    }
+    cylinders.reserve(r.header.n_cylinders);
+    for (int i = 0; i < r.header.n_cylinder_labels; ++i)
+        if (r.cylinders[i].kept)
+            cylinders.emplace_back(Cylinder_Segment(r.cylinders[i]));
+}
+
+// one chunk (<= _maxBatch frames) through the C ABI: H2D copy + kernels + D2H of records and boundary points
+bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, int m) const
+{
+    if (cape_extract_host(shard.handle, depth, m, nullptr) != CAPE_OK ||
+        cape_copy_results(shard.handle, m, shard.records.data(), nullptr, nullptr, shard.boundary.data()) != CAPE_OK)
+    {
+        shard.error = cape_last_error(); // thread-local in the library: keep it for the caller's thread
+        return false;
+    }
+    return true;
+}
+
+void Primitive_Detection::run_shard(Shard& shard, const float* depth, int firstFrame, int n, std::vector<plane_container>& planes,
+                                    std::vector<cylinder_container>& cylinders, bool& ok) const
+{
+    const size_t frameElems = static_cast<size_t>(_width) * _height;
+    ok = true;
+    for (int base = 0; base < n; base += _maxBatch)
+    {
+        const int m = (n - base < _maxBatch) ? n - base : _maxBatch;
+        if (!extract_chunk(shard, depth + static_cast<size_t>(firstFrame + base) * frameElems, m))
+        {
+            ok = false;
+            return;
+        }
+        // containers are filled in place: a Plane copy would re-normalise its parametrisation once more
+        for (int f = 0; f < m; ++f)
+            collect(shard, f, planes[firstFrame + base + f], cylinders[firstFrame + base + f]);
+    }
+}
+
+void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames, std::vector<plane_container>& planes,
+                                                std::vector<cylinder_container>& cylinders) noexcept
+{
+    try
+    {
+        // (Plane / Cylinder are copy-constructible but not assignable, like the reference's: no vector::assign here)
+        planes.clear();
+        cylinders.clear();
+        planes.resize(n_frames > 0 ? n_frames : 0);
+        cylinders.resize(n_frames > 0 ? n_frames : 0);
+        if (n_frames <= 0 || !depth)
+            return;
+        int wanted = _requestedShards;
+        if (wanted <= 0 && (cape_device_count(&wanted) != CAPE_OK || wanted <= 0))
+            wanted = 1;
+        if (wanted > n_frames)
+            wanted = n_frames;
+        if (!ensure_shards(wanted) && _shards.empty())
+        {
+            outputs::log_error("find_primitives: no device extractor (cape_create failed); returning no primitives");
+            return;
+        }
+        const int shards = static_cast<int>(_shards.size()) < wanted ? static_cast<int>(_shards.size()) : wanted;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<char> ok(shards, 1);
+        if (shards == 1)
+        {
+            bool good = true;
+            run_shard(_shards[0], depth, 0, n_frames, planes, cylinders, good);
+            ok[0] = good;
+        }
+        else
+        {
+            // one host thread per shard: the copies, kernels and polygon fits of the devices overlap; every thread writes
+            // its own block of the output vectors
+            std::vector<std::thread> workers;
+            workers.reserve(shards);
+            for (int k = 0; k < shards; ++k)
+                workers.emplace_back([&, k]() {
+                    int first = 0, count = 0;
+                    block_of(n_frames, k, shards, first, count);
+                    bool good = true;
+                    try
+                    {
+                        run_shard(_shards[k], depth, first, count, planes, cylinders, good);
+                    }
+                    catch (const std::exception&)
+                    {
+                        good = false;
+                    }
+                    ok[k] = good;
+                });
+            for (std::thread& w : workers)
+                w.join();
+        }
+        for (int k = 0; k < shards; ++k)
+            if (!ok[k])
+                outputs::log_error("find_primitives: shard " + std::to_string(k) + " failed (" + _shards[k].error +
+                                   "); its frames yield no primitives");
+        _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    catch (const std::exception& e)
+    {
+        outputs::log_error(std::string("find_primitives: ") + e.what());
+    }
+}
+
+void Primitive_Detection::find_primitives(const matrixf&, const depth_image& depthImage, plane_container& planeContainer,
+                                          cylinder_container& primitiveContainer) noexcept
+{
+    try
+    {
+        planeContainer.clear();
+        primitiveContainer.clear();
+        if (depthImage.rows != static_cast<int>(_height) || depthImage.cols != static_cast<int>(_width))
+        {
+            outputs::log_error("find_primitives: depth image size differs from the configured size");
+            return;
+        }
+        if (_shards.empty())
+        {
+            outputs::log_error("find_primitives: no device extractor (cape_create failed); returning no primitives");
+            return;
+        }
+        const depth_image d = depthImage.isContinuous() ? depthImage : depthImage.clone();
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!extract_chunk(_shards[0], d.ptr<float>(0), 1))
+        {
+            outputs::log_error("find_primitives: " + _shards[0].error);
+            return;
+        }
+        collect(_shards[0], 0, planeContainer, primitiveContainer); // in place, like emplace_back at primitive_detection.cpp:627
+        _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    catch (const std::exception& e)
+    {
+        outputs::log_error(std::string("find_primitives: ") + e.what());
+    }
+}
+
+bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame_match>& matches, bool useAdvancedSearch,
+                                            bool allowIndexZero) noexcept
+{
+    try
+    {
+        matches.clear();
+        if (_shards.empty() || n_frames < 0)
+            return false;
+        const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
+                               (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
+        matches.resize(n_frames);
+        if (cape_match_consecutive(_shards[0].handle, n_frames, flags, nullptr) != CAPE_OK ||
+            cape_copy_matches(_shards[0].handle, n_frames, matches.data()) != CAPE_OK)
+        {
+            outputs::log_error(std::string("match_consecutive: ") + cape_last_error());
+            matches.clear();
+            return false;
+        }
+        return true;
+    }
+    catch (const std::exception&)
+    {
+        return false;
+    }
+}
+
+void Primitive_Detection::show_statistics(const double meanFrameTreatmentDuration, const uint frameCount,
+                                          const bool shouldDisplayDetails) const noexcept
+{
+    // primitive_detection.cpp:69-117
+    auto percent = [](double t, double total) { return total <= 0 ? 0.0 : (t / total) * 100.0; };
+    if (frameCount == 0)
+        return;
+    const double mean = _meanPrimitiveTreatmentDuration / static_cast<double>(frameCount);
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "\tMean primitive extraction time is %.4f seconds (%.2f%%)", mean,
+                  percent(mean, meanFrameTreatmentDuration));
+    outputs::log(buf);
+    if (shouldDisplayDetails && !_shards.empty())
+    {
+        cape_timings t {};
+        if (cape_get_timings(_shards[0].handle, &t) == CAPE_OK && t.calls > 0)
+        {
+            std::snprintf(buf, sizeof buf, "\t\tMean primitive init time is %.6f seconds, grow+merge+refine %.6f seconds (device, per call)",
+                          t.cell_fit_s / t.calls, t.grow_s / t.calls);
+            outputs::log(buf);
+        }
+    }
+}
+
+int find_plane_match(const plane_container& detectedPlanes, const std::vector<bool>& isDetectedFeatureMatched,
+                     const PlaneCameraCoordinates& projectedPlane, const CameraPolygon& projectedPolygon, bool useAdvancedSearch) noexcept
+{
+    const double projectedArea = projectedPolygon.get_area();
+    const double planeMinimalOverlap = parameters::matching::minimumPlaneOverlapToConsiderMatch; // float widened, like the reference's static double
+    const double areaSimilarityThreshold = useAdvancedSearch ? planeMinimalOverlap / 2 : planeMinimalOverlap;
+    double greatestSimilarity = 0.0;
+    if (projectedArea <= 0.0)
+        return -1;
+    int selectedIndex = -1;
+    const int detectedPlaneSize = static_cast<int>(detectedPlanes.size());
+    for (int planeIndex = 0; planeIndex < detectedPlaneSize; ++planeIndex)
+    {
+        if (planeIndex < static_cast<int>(isDetectedFeatureMatched.size()) && isDetectedFeatureMatched[planeIndex])
+            continue;
+        const Plane& shapePlane = detectedPlanes[planeIndex];
+        if (not shapePlane.is_distance_similar(projectedPlane) or not shapePlane.is_normal_similar(projectedPlane))
+            continue;
+        const CameraPolygon& detectedPolygon = shapePlane.get_boundary_polygon();
+        const double newPlaneArea = detectedPolygon.get_area();
+        const double interArea = detectedPolygon.inter_area(projectedPolygon);
+        if (interArea > greatestSimilarity and interArea / newPlaneArea >= areaSimilarityThreshold)
+        {
+            selectedIndex = planeIndex;
+            greatestSimilarity = interArea;
+        }
+    }
+    if (selectedIndex <= 0) // quirk of the reference: index 0 can never be returned
+        return -1;
+    return selectedIndex;
+}
+
+} // namespace rgbd_slam::features::primitives

@@ -1,0 +1,110 @@
+// Replacement for reference src/features/primitives/primitive_detection.hpp:27-241 inside the `primitives` library:
+// same class name, constructor, find_primitives and show_statistics signatures (src/rgbd_slam.cpp:57, :293-296, :335
+// compile against it unchanged).  Everything numeric happens behind the C ABI of libcape_hip.so (include/cape_hip.h);
+// this class converts containers, builds the boundary polygons on the host (primitive_detection.cpp:622) and keeps the
+// reference's error convention (noexcept, log and skip).
+//
+// Additions (the reference extracts one frame per call on one device):
+//   find_primitives_batch : frames are independent, so a batch is cut in contiguous blocks over every visible GPU
+//                           (one handle + one host thread per device) and the lists come back in frame
+//                           order;
+//   match_consecutive     : device pre-filter for MapPlane::find_matches.
+#ifndef RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
+#define RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cape_hip.h"
+#include "depth_image.hpp"
+#include "shape_primitives.hpp"
+#include "types.hpp"
+
+namespace rgbd_slam::features::primitives {
+
+class Primitive_Detection
+{
+  public:
+    Primitive_Detection(const uint width, const uint height);
+    ~Primitive_Detection();
+
+    // primitive_detection.hpp:41-44.  depthMatrix (the organised cloud) is not read: see depth_map_transformation.hpp
+    void find_primitives(const matrixf& depthMatrix,
+                         const depth_image& depthImage,
+                         plane_container& planeContainer,
+                         cylinder_container& primitiveContainer) noexcept;
+
+    // primitive_detection.hpp:46-49
+    void show_statistics(const double meanFrameTreatmentDuration,
+                         const uint frameCount,
+                         const bool shouldDisplayDetails = false) const noexcept;
+
+    // ---- additions -------------------------------------------------------------------------------------------
+    // depth: n_frames contiguous row-major float32 images on the host.  Sharded over the visible devices (or over
+    // set_shard_count() handles); planes[f] / cylinders[f] are frame f's containers whatever device produced them.
+    void find_primitives_batch(const float* depth,
+                               int n_frames,
+                               std::vector<plane_container>& planes,
+                               std::vector<cylinder_container>& cylinders) noexcept;
+    // 0 (default): one shard per visible device.  k > 0: k shards, shard i on device i % device_count -- more shards than
+    // devices are legal (used by the tests to exercise the sharding on a one-GPU box).  Takes effect at the next batch.
+    void set_shard_count(int shards) noexcept { _requestedShards = shards; }
+    [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
+
+    // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
+    // shard (the last chunk of <= 64 frames); see cape_match_consecutive.  Plane indices count the segments flagged
+    // is_output, i.e. the planes BEFORE the polygon validity test drops any.
+    bool match_consecutive(int n_frames,
+                           std::vector<cape_frame_match>& matches,
+                           bool useAdvancedSearch = false,
+                           bool allowIndexZero = false) noexcept;
+
+    [[nodiscard]] bool is_ready() const noexcept { return !_shards.empty(); }
+
+  private:
+    struct Shard
+    {
+        cape_handle handle = nullptr;
+        int device = 0;
+        std::vector<cape_frame_record> records;
+        std::vector<double> boundary;
+        std::string error;
+    };
+    bool ensure_shards(int wanted) noexcept;
+    bool extract_chunk(Shard& shard, const float* depth, int m) const;
+    void run_shard(Shard& shard,
+                   const float* depth,
+                   int firstFrame,
+                   int n,
+                   std::vector<plane_container>& planes,
+                   std::vector<cylinder_container>& cylinders,
+                   bool& ok) const;
+    void collect(const Shard& shard, int f, plane_container& planes, cylinder_container& cylinders) const;
+
+    uint _width, _height;
+    int _cells = 0, _boundaryCapacity = 0;
+    int _maxBatch = 64;
+    int _requestedShards = 0;
+    mutable std::vector<Shard> _shards;
+    mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
+
+    // remove copy functions, like the reference (primitive_detection.hpp:228-230)
+    Primitive_Detection(const Primitive_Detection&) = delete;
+    Primitive_Detection& operator=(const Primitive_Detection&) = delete;
+};
+
+// ---- "next" row N2, host part ----------------------------------------------------------------------------------
+// The selection loop of MapPlane::find_matches (src/map_management/map_features/map_primitive.cpp:91-161) for one map
+// plane already projected into camera space: a detected plane is a candidate if is_distance_similar and
+// is_normal_similar (shape_primitives.cpp:66-86); the candidate with the greatest polygon intersection area wins if
+// inter / area(detected) >= 0.4 (0.2 with useAdvancedSearch).  Returns the selected index or -1; like the reference it
+// can never return index 0 (`if (selectedIndex <= 0)`, map_primitive.cpp:146).
+int find_plane_match(const plane_container& detectedPlanes,
+                     const std::vector<bool>& isDetectedFeatureMatched,
+                     const PlaneCameraCoordinates& projectedPlane,
+                     const CameraPolygon& projectedPolygon,
+                     bool useAdvancedSearch = false) noexcept;
+
+} // namespace rgbd_slam::features::primitives
+#endif

@@ -106,7 +106,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
+    "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_wait", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
@@ -134,6 +134,7 @@ def load_library():
         pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
+    L.cape_device_count.argtypes = [C.POINTER(C.c_int32)]
     L.cape_create.argtypes = [C.POINTER(cape_config), C.POINTER(vp)]
     L.cape_destroy.argtypes = [vp]
     L.cape_destroy.restype = None

@@ -49,7 +49,7 @@ def _gpu_tests_need_the_library(request):
 @pytest.fixture(scope="session")
 def host_binaries(hip_library):
     """The C++ mirror library and its drivers (g++ only, but they link libcape_hip.so)."""
-    names = ("libcape_primitives.so", "test_shim.exe", "test_polygon.exe")
+    names = ("libcape_primitives.so", "test_shim.exe", "test_polygon.exe", "test_consumers.exe")
     if not all(os.path.exists(os.path.join(LIB_DIR, f)) for f in names):
         _make(["host"], needs_hipcc=False)
     return LIB_DIR

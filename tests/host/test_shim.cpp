@@ -1,13 +1,30 @@
-// Drives the host-side mirror of the reference interface the way src/rgbd_slam.cpp:48-57,109-112,291-297 does and
-// prints the primitives as hex doubles; tests/test_gpu_host_shim.py compares them with the CPU oracle.
+// Drives the host-side replacement of the reference's `primitives` library the way src/rgbd_slam.cpp:48-57,109-112,
+// 291-297,335 drives the original, and prints the primitives as hex doubles; tests/test_gpu_host_shim.py compares them
+// with the CPU oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <vector>
 
-#include "../../rgb-d-slam_amd/host/primitives_shim.hpp"
+#include "primitives_shim.hpp"
 
 using namespace rgbd_slam;
 using namespace rgbd_slam::features::primitives;
+
+static void print_frame(const char* tag, const plane_container& planes, const cylinder_container& cylinders)
+{
+    std::printf("%splanes %zu cylinders %zu\n", tag, planes.size(), cylinders.size());
+    for (const Plane& p : planes)
+    {
+        const vector3 n = p.get_normal();
+        const matrix33 cov = p.get_point_cloud_covariance();
+        std::printf("%sP %a %a %a %a %zu %.3f %a %a\n", tag, n.x(), n.y(), n.z(), p.get_d(), p.get_boundary_polygon().boundary_length(),
+                    p.get_boundary_polygon().get_area(), cov(0, 0), cov(2, 1));
+    }
+    for (const Cylinder& c : cylinders)
+        std::printf("%sC %a %a %a %d\n", tag, c._normal.x(), c._normal.y(), c._normal.z(), c._radius != c._radius ? 1 : 0);
+}
 
 int main(int argc, char** argv)
 {
@@ -15,65 +32,80 @@ int main(int argc, char** argv)
         return 2;
     const uint W = std::atoi(argv[2]), H = std::atoi(argv[3]);
     Parameters::set_camera_1(W, H, std::atof(argv[4]), std::atof(argv[5]), std::atof(argv[6]), std::atof(argv[7]));
-    std::vector<float> depth(static_cast<size_t>(W) * H);
+    const int batchFrames = argc > 8 ? std::atoi(argv[8]) : 0; // extra frames appended to the file: sharded batch test
+    const int shards = argc > 9 ? std::atoi(argv[9]) : 0;
+    std::vector<float> depth(static_cast<size_t>(W) * H * (1 + batchFrames));
     FILE* f = std::fopen(argv[1], "rb");
     if (!f || std::fread(depth.data(), sizeof(float), depth.size(), f) != depth.size())
         return 3;
     std::fclose(f);
 
-    Depth_Map_Transformation depthOps(W, H, 20);
-    Primitive_Detection detector(W, H);
-    if (!detector.is_ready())
+    // src/rgbd_slam.cpp:48-57
+    auto depthOps = std::make_unique<Depth_Map_Transformation>(W, H, parameters::detection::depthMapPatchSize_px);
+    auto detector = std::make_unique<Primitive_Detection>(W, H);
+    if (!depthOps->is_ok() || !detector->is_ready())
         return 4;
-    const DepthImageView img {depth.data(), static_cast<int>(H), static_cast<int>(W), W};
-    if (!depthOps.get_organized_cloud_array(img))
+    const depth_image img(static_cast<int>(H), static_cast<int>(W), depth.data());
+    // :109-112
+    matrixf cloudArrayOrganized;
+    if (!depthOps->get_organized_cloud_array(img, cloudArrayOrganized))
         return 5;
+    // :293-296
     plane_container planes;
     cylinder_container cylinders;
-    detector.find_primitives(img, planes, cylinders);
-    std::printf("planes %zu cylinders %zu\n", planes.size(), cylinders.size());
-    for (const Plane& p : planes)
-    {
-        const auto n = p.get_normal();
-        std::printf("P %a %a %a %a %zu %zu %.3f\n", n[0], n[1], n[2], p.get_d(), p.get_boundary_points().size(),
-                    p.get_boundary_polygon().boundary_length(), p.get_boundary_polygon().get_area());
-    }
-    for (const Cylinder& c : cylinders)
-        std::printf("C %a %a %a\n", c._normal[0], c._normal[1], c._normal[2]);
+    detector->find_primitives(cloudArrayOrganized, img, planes, cylinders);
+    print_frame("", planes, cylinders);
+
     // N2: MapPlane::find_matches selection with the frame's own planes standing in for projected map planes
     for (size_t i = 0; i < planes.size(); ++i)
     {
-        const auto n = planes[i].get_normal();
-        const int m = find_plane_match(planes, std::vector<bool>(planes.size(), false), {n[0], n[1], n[2], planes[i].get_d()},
+        const int m = find_plane_match(planes, std::vector<bool>(planes.size(), false), planes[i].get_parametrization(),
                                        planes[i].get_boundary_polygon());
         std::printf("M %zu %d\n", i, m);
     }
     // N2 device part: the same frame twice -> every plane of "frame 1" overlaps its own copy in "frame 0"
     {
-        std::vector<float> two(depth);
-        two.insert(two.end(), depth.begin(), depth.end());
+        std::vector<float> two(depth.begin(), depth.begin() + static_cast<size_t>(W) * H);
+        two.insert(two.end(), depth.begin(), depth.begin() + static_cast<size_t>(W) * H);
         std::vector<plane_container> bp;
         std::vector<cylinder_container> bc;
-        detector.find_primitives_batch(two.data(), 2, bp, bc);
+        detector->set_shard_count(1);
+        detector->find_primitives_batch(two.data(), 2, bp, bc);
         std::vector<cape_frame_match> mm;
-        if (!detector.match_consecutive(2, mm) || mm.size() != 2)
+        if (!detector->match_consecutive(2, mm) || mm.size() != 2)
             return 7;
         std::printf("D %d %d", mm[1].n_prev, mm[1].n_cur);
         for (int j = 0; j < mm[1].n_prev; ++j)
             std::printf(" %d", mm[1].match[j]);
         std::printf("\n");
     }
+    // sharded batch: every frame of the file, cut in contiguous blocks over `shards` handles (device = shard % devices)
+    if (batchFrames > 0)
+    {
+        std::vector<plane_container> bp;
+        std::vector<cylinder_container> bc;
+        detector->set_shard_count(shards);
+        detector->find_primitives_batch(depth.data(), 1 + batchFrames, bp, bc);
+        std::printf("S %d %zu\n", detector->shard_count(), bp.size());
+        for (size_t k = 0; k < bp.size(); ++k)
+        {
+            char tag[16];
+            std::snprintf(tag, sizeof tag, "B%zu ", k);
+            print_frame(tag, bp[k], bc[k]);
+        }
+    }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
-    std::vector<float> rect(depth.size());
-    if (!depthOps.rectify_depth(img, rect.data()))
+    depth_image rect;
+    if (!depthOps->rectify_depth(img, rect))
         return 6;
     size_t hits = 0;
-    for (float v : rect)
-        hits += v > 0;
+    for (int r = 0; r < rect.rows; ++r)
+        for (int c = 0; c < rect.cols; ++c)
+            hits += rect(r, c) > 0;
     plane_container planes2;
     cylinder_container cylinders2;
-    detector.find_primitives(DepthImageView {rect.data(), static_cast<int>(H), static_cast<int>(W), W}, planes2, cylinders2);
+    detector->find_primitives(cloudArrayOrganized, rect, planes2, cylinders2);
     std::printf("R %zu %zu\n", hits, planes2.size());
-    detector.show_statistics(0.01, 1, true);
+    detector->show_statistics(0.01, 1, true); // :335
     return 0;
 }

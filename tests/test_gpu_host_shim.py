@@ -1,5 +1,5 @@
-"""The C++ host-side mirror of the reference interface (rgb-d-slam_amd/host) driven like src/rgbd_slam.cpp drives
-the reference's primitives library; output compared with the CPU oracle (cylinder branch on, as in the reference)."""
+"""The C++ host-side replacement of the reference's `primitives` library (rgb-d-slam_amd/host/overlay) driven like
+src/rgbd_slam.cpp drives the original; output compared with the CPU oracle (cylinder branch on, as in the reference)."""
 import os
 import subprocess
 
@@ -10,12 +10,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _bits(v):
+    return np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
+
+
+def _check_frame(lines, tag, r):
+    """lines of one frame (prefix `tag`) against an OracleResult."""
+    assert lines[0] == f"{tag}planes {len(r.planes)} cylinders {len(r.cylinders)}"
+    P = [ln[len(tag):].split()[1:] for ln in lines if ln.startswith(tag + "P ")]
+    assert len(P) == len(r.planes)
+    for k, p in enumerate(P):
+        vals = np.array([float.fromhex(v) for v in p[:4]])
+        # Plane::get_normal / get_d: the host re-normalises like Plane(planeSeg, polygon) does -- same bits as the oracle
+        assert np.array_equal(_bits(vals), _bits(r.planes[k, 0:4]))
+        # N1: the host-side boundary polygon is a valid ring spanning the candidate points (area in mm^2)
+        assert 3 <= int(p[4]) <= len(r.boundary[k]) and float(p[5]) > 1e3
+        cov = np.array([float.fromhex(p[6]), float.fromhex(p[7])])
+        assert np.array_equal(_bits(cov), _bits(r.planes[k, [10, 17]])), "get_point_cloud_covariance (0,0) and (2,1)"
+    Cc = [ln[len(tag):].split()[1:] for ln in lines if ln.startswith(tag + "C ")]
+    assert len(Cc) == len(r.cylinders)
+    for k, c in enumerate(Cc):
+        vals = np.array([float.fromhex(v) for v in c[:3]])
+        assert np.array_equal(_bits(vals), _bits(r.cylinders[k, 0:3]))
+        assert c[3] == "1", "Cylinder::_radius is NaN, as in the reference"
+
+
 @pytest.mark.parametrize("scene,seed,frame", [("tumlike", 1, 0), ("tunnel", 0, 0)])
 def test_shim_matches_oracle(oracle_mod, host_binaries, tmp_path, scene, seed, frame):
     from cape_amd import synth
 
-    exe = os.path.join(ROOT, "rgb-d-slam_amd", "lib", "test_shim.exe")
-    assert os.path.exists(exe), "build with make -C rgb-d-slam_amd/csrc host"
+    exe = os.path.join(host_binaries, "test_shim.exe")
     intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
     depth = synth.SCENES[scene](seed=seed, frame=frame)
     path = tmp_path / "depth.f32"
@@ -24,28 +48,47 @@ def test_shim_matches_oracle(oracle_mod, host_binaries, tmp_path, scene, seed, f
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    r = oracle_mod.Oracle(640, 480, cylinders=True, **intr).run(depth)
-    assert lines[0] == f"planes {len(r.planes)} cylinders {len(r.cylinders)}"
-    P = [ln.split()[1:] for ln in lines if ln.startswith("P ")]
-    for k, p in enumerate(P):
-        vals = np.array([float.fromhex(v) for v in p[:4]])
-        assert np.array_equal(vals.view(np.uint64), np.ascontiguousarray(r.planes[k, 0:4]).view(np.uint64))
-        assert int(p[4]) == len(r.boundary[k])
-        # N1: the host-side boundary polygon is a valid ring spanning the candidate points (area in mm^2)
-        assert 3 <= int(p[5]) <= len(r.boundary[k]) and float(p[6]) > 1e4
-    Cc = [ln.split()[1:] for ln in lines if ln.startswith("C ")]
-    for k, c in enumerate(Cc):
-        vals = np.array([float.fromhex(v) for v in c])
-        assert np.array_equal(vals.view(np.uint64), np.ascontiguousarray(r.cylinders[k, 0:3]).view(np.uint64))
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    r = orc.run(depth)
+    head = [ln for ln in lines if ln.startswith(("planes", "P ", "C "))]
+    _check_frame(head, "", r)
+    n_planes = len(r.planes)
     # N2: every plane matches itself, except index 0 which the reference's `selectedIndex <= 0` test can never return
     M = {int(ln.split()[1]): int(ln.split()[2]) for ln in lines if ln.startswith("M ")}
-    assert len(M) == len(P) and all(M[i] == (i if i > 0 else -1) for i in M)
+    assert len(M) == n_planes and all(M[i] == (i if i > 0 else -1) for i in M)
     # N2 device part on a duplicated frame: same verdicts from the cell masks
     D = [int(v) for v in [ln for ln in lines if ln.startswith("D ")][0].split()[1:]]
-    assert D[0] == D[1] == len(r.planes) and D[2:] == [(i if i > 0 else -1) for i in range(len(r.planes))]
-    # rectify_depth through the mirror class == oracle rectify (identity transform), and its frame still yields planes
+    assert D[0] == D[1] == n_planes and D[2:] == [(i if i > 0 else -1) for i in range(n_planes)]
+    # rectify_depth through the class == oracle rectify (identity transform), and its frame still yields planes
     R = [ln.split()[1:] for ln in lines if ln.startswith("R ")][0]
-    ref_rect = oracle_mod.Oracle(640, 480, cylinders=True, **intr).rectify(depth, np.eye(4))
+    ref_rect = orc.rectify(depth, np.eye(4))
     assert int(R[0]) == int((ref_rect > 0).sum())
-    assert int(R[1]) == len(oracle_mod.Oracle(640, 480, cylinders=True, **intr).run(ref_rect).planes)
+    assert int(R[1]) == len(orc.run(ref_rect).planes)
     assert "Mean primitive extraction time" in out.stderr
+
+
+@pytest.mark.parametrize("shards", [1, 3, 0])
+def test_sharded_batch_matches_oracle(oracle_mod, host_binaries, tmp_path, shards):
+    """find_primitives_batch cuts the batch in contiguous blocks over `shards` handles (one host thread each; shard i on
+    device i % device_count, so three shards also run on a one-GPU box; 0 = one per visible device) and returns the
+    containers in frame order."""
+    from cape_amd import synth
+
+    exe = os.path.join(host_binaries, "test_shim.exe")
+    intr = synth.DEFAULT_INTRINSICS
+    names = ["room", "tunnel", "facets", "room", "tunnel", "facets", "room"]
+    frames = np.stack([synth.SCENES[n](seed=11 + i, frame=2 * i) for i, n in enumerate(names)])
+    path = tmp_path / "batch.f32"
+    frames.tofile(path)
+    out = subprocess.run([exe, str(path), "640", "480", str(intr["fx"]), str(intr["fy"]), str(intr["cx"]), str(intr["cy"]),
+                          str(len(frames) - 1), str(shards)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    S = [ln for ln in lines if ln.startswith("S ")][0].split()
+    assert int(S[2]) == len(frames)
+    if shards:
+        assert int(S[1]) == shards
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    for k in range(len(frames)):
+        tag = f"B{k} "
+        _check_frame([ln for ln in lines if ln.startswith(tag)], tag, orc.run(frames[k]))
