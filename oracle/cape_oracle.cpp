@@ -22,9 +22,46 @@ namespace cape_oracle {
 // small helpers restating Eigen fixed-size semantics (Appendix A.2)
 // ---------------------------------------------------------------------------------------------------
 
+// ---- risk-measurement variants (oracle/variants.py): every third-party choice the restatement could not pin against
+// the real Eigen / OpenCV / glibc is a compile-time switch, default 0 = the choice argued in SURVEY.md Appendix A.  The
+// variants exist to MEASURE how much of the output depends on each choice; nothing ships them.
+#ifndef CAPE_VAR_DOT_ORDER
+#define CAPE_VAR_DOT_ORDER 0   // 1: a0 + (a1 + a2), the order without SSE2 packet vectorisation
+#endif
+#ifndef CAPE_VAR_NORMALIZE
+#define CAPE_VAR_NORMALIZE 0   // 1: v *= 1 / sqrt(z) instead of v /= sqrt(z)
+#endif
+#ifndef CAPE_VAR_EIGEN
+#define CAPE_VAR_EIGEN 0       // 1: cyclic Jacobi (another backward-stable solver), 2: closed form (computeDirect-style)
+#endif
+#ifndef CAPE_VAR_DET
+#define CAPE_VAR_DET 0         // 1: Eigen's bruteforce_det3_helper association
+#endif
+#ifndef CAPE_VAR_GEMM
+#define CAPE_VAR_GEMM 0        // cylinder covariance sum over k: 1 blocks of 256, 2 descending, 3 two interleaved accumulators
+#endif
+#ifndef CAPE_VAR_LIBM
+#define CAPE_VAR_LIBM 0        // acos / atan2 of the histogram: 1 result + 1 ulp, 2 result - 1 ulp
+#endif
+
 // Vector3d::dot / squaredNorm with SSE2 Packet2d linear vectorisation: (a0 + a1) + a2
+#if CAPE_VAR_DOT_ORDER
+static inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+static inline double sqnorm3(const double a[3]) { return a[0] * a[0] + (a[1] * a[1] + a[2] * a[2]); }
+#else
 static inline double dot3(const double a[3], const double b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 static inline double sqnorm3(const double a[3]) { return (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]; }
+#endif
+static inline double libm_variant(double v)
+{
+#if CAPE_VAR_LIBM == 1
+    return std::nextafter(v, std::numeric_limits<double>::infinity());
+#elif CAPE_VAR_LIBM == 2
+    return std::nextafter(v, -std::numeric_limits<double>::infinity());
+#else
+    return v;
+#endif
+}
 
 // Eigen::MatrixBase::normalize(): z = squaredNorm(); if (z > 0) v /= sqrt(z)
 void normalize3(double v[3])
@@ -33,9 +70,16 @@ void normalize3(double v[3])
     if (z > 0)
     {
         const double s = std::sqrt(z);
+#if CAPE_VAR_NORMALIZE
+        const double r = 1.0 / s;
+        v[0] *= r;
+        v[1] *= r;
+        v[2] *= r;
+#else
         v[0] /= s;
         v[1] /= s;
         v[2] /= s;
+#endif
     }
 }
 
@@ -174,7 +218,7 @@ static void tridiagonal_qr_step(double* diag, double* subdiag, int start, int en
     }
 }
 
-void self_adjoint_eigen3(const double lower[3][3], double evals[3], double evecs[3][3], int* iterations)
+static void self_adjoint_eigen3_iterative(const double lower[3][3], double evals[3], double evecs[3][3], int* iterations)
 {
     double m00 = lower[0][0], m10 = lower[1][0], m11 = lower[1][1];
     double m20 = lower[2][0], m21 = lower[2][1], m22 = lower[2][2];
@@ -297,9 +341,161 @@ void self_adjoint_eigen3(const double lower[3][3], double evals[3], double evecs
     }
 }
 
+#if CAPE_VAR_EIGEN == 1
+// variant: cyclic Jacobi sweeps to convergence, eigenvalues ascending.  A different backward-stable algorithm: its
+// eigenvectors agree with the QR iteration to a few ulp (times the inverse eigenvalue gap), which is the size of
+// disagreement to expect from any other correct implementation of the solver.
+static void self_adjoint_eigen3_variant(const double lower[3][3], double evals[3], double evecs[3][3])
+{
+    double a[3][3] = {{lower[0][0], lower[1][0], lower[2][0]}, {lower[1][0], lower[1][1], lower[2][1]}, {lower[2][0], lower[2][1], lower[2][2]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep)
+    {
+        const double off = std::abs(a[0][1]) + std::abs(a[0][2]) + std::abs(a[1][2]);
+        if (off == 0.0)
+            break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q)
+            {
+                if (a[p][q] == 0.0)
+                    continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k)
+                {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k)
+                {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k)
+                {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int idx[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (a[idx[j]][idx[j]] < a[idx[i]][idx[i]])
+                std::swap(idx[i], idx[j]);
+    for (int c = 0; c < 3; ++c)
+    {
+        evals[c] = a[idx[c]][idx[c]];
+        for (int r = 0; r < 3; ++r)
+            evecs[r][c] = v[r][idx[c]];
+    }
+}
+#elif CAPE_VAR_EIGEN == 2
+// variant: closed form in the manner of SelfAdjointEigenSolver::computeDirect (shift by the mean, scale, trigonometric
+// roots of the characteristic polynomial, eigenvectors from cross products of rows of A - lambda I).  Documented by Eigen
+// as less accurate than the iterative solver when eigenvalues are close: the pessimistic end of the range.
+static void self_adjoint_eigen3_variant(const double lower[3][3], double evals[3], double evecs[3][3])
+{
+    double A[3][3] = {{lower[0][0], lower[1][0], lower[2][0]}, {lower[1][0], lower[1][1], lower[2][1]}, {lower[2][0], lower[2][1], lower[2][2]}};
+    const double shift = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+    for (int i = 0; i < 3; ++i)
+        A[i][i] -= shift;
+    double scale = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            scale = std::max(scale, std::abs(A[i][j]));
+    if (scale > 0)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                A[i][j] /= scale;
+    // roots of x^3 - c2 x^2 + c1 x - c0 with c2 = trace = 0 after the shift
+    const double c0 = A[0][0] * A[1][1] * A[2][2] + 2.0 * A[1][0] * A[2][0] * A[2][1] - A[0][0] * A[2][1] * A[2][1] -
+                      A[1][1] * A[2][0] * A[2][0] - A[2][2] * A[1][0] * A[1][0];
+    const double c1 = A[0][0] * A[1][1] - A[1][0] * A[1][0] + A[0][0] * A[2][2] - A[2][0] * A[2][0] + A[1][1] * A[2][2] - A[2][1] * A[2][1];
+    const double a_over_3 = -c1 / 3.0 > 0 ? -c1 / 3.0 : 0.0;
+    const double half_b = 0.5 * c0;
+    double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    if (q < 0)
+        q = 0;
+    const double rho = std::sqrt(a_over_3);
+    const double theta = std::atan2(std::sqrt(q), half_b) / 3.0;
+    const double ct = std::cos(theta), st = std::sin(theta);
+    double roots[3] = {-rho * (ct + std::sqrt(3.0) * st), -rho * (ct - std::sqrt(3.0) * st), 2.0 * rho * ct};
+    std::sort(roots, roots + 3);
+    auto kernel = [&](double lambda, double out[3]) {
+        double B[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                B[i][j] = A[i][j] - (i == j ? lambda : 0.0);
+        double best = -1.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i + 1; j < 3; ++j)
+            {
+                double c[3];
+                cross3(B[i], B[j], c);
+                const double n2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+                if (n2 > best)
+                {
+                    best = n2;
+                    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+                }
+            }
+        const double n = std::sqrt(best);
+        if (n > 0)
+        {
+            out[0] /= n; out[1] /= n; out[2] /= n;
+        }
+        else
+        {
+            out[0] = 1; out[1] = 0; out[2] = 0;
+        }
+    };
+    double v0[3], v2[3], v1[3];
+    kernel(roots[0], v0);
+    kernel(roots[2], v2);
+    // orthogonalise v2 against v0, v1 = v2 x v0
+    const double dp = v0[0] * v2[0] + v0[1] * v2[1] + v0[2] * v2[2];
+    for (int k = 0; k < 3; ++k)
+        v2[k] -= dp * v0[k];
+    const double n2 = std::sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+    if (n2 > 0)
+        for (int k = 0; k < 3; ++k)
+            v2[k] /= n2;
+    cross3(v2, v0, v1);
+    for (int r = 0; r < 3; ++r)
+    {
+        evecs[r][0] = v0[r];
+        evecs[r][1] = v1[r];
+        evecs[r][2] = v2[r];
+    }
+    for (int c = 0; c < 3; ++c)
+        evals[c] = roots[c] * scale + shift;
+}
+#endif
+
+void self_adjoint_eigen3(const double lower[3][3], double evals[3], double evecs[3][3], int* iterations)
+{
+#if CAPE_VAR_EIGEN
+    if (iterations)
+        *iterations = 0;
+    self_adjoint_eigen3_variant(lower, evals, evecs);
+#else
+    self_adjoint_eigen3_iterative(lower, evals, evecs, iterations);
+#endif
+}
+
 // Matrix3d::determinant (first-row expansion, Appendix A.2)
 static inline double det3(const double m[3][3])
 {
+#if CAPE_VAR_DET
+    // Eigen's bruteforce_det3_helper(m,0,1,2) + (m,1,2,0) + (m,2,0,1): m(0,a) * (m(1,b) m(2,c) - m(1,c) m(2,b))
+    auto h = [&](int a, int b, int c) { return m[0][a] * (m[1][b] * m[2][c] - m[1][c] * m[2][b]); };
+    return h(0, 1, 2) + h(1, 2, 0) + h(2, 0, 1);
+#endif
     return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
@@ -391,9 +587,16 @@ void fit_plane(PlaneSeg& s)
         if (z > 0)
         {
             const double sq = std::sqrt(z);
+#if CAPE_VAR_NORMALIZE
+            const double rq = 1.0 / sq;
+            normal[0] *= rq;
+            normal[1] *= rq;
+            normal[2] *= rq;
+#else
             normal[0] /= sq;
             normal[1] /= sq;
             normal[2] /= sq;
+#endif
         }
     }
     const double d = -dot3(normal, s.centroid);
@@ -723,8 +926,31 @@ static CylinderSeg make_cylinder_segment(const std::vector<PlaneSeg>& planeGrid,
         for (int c = 0; c < 3; ++c)
         {
             double acc = 0.0;
+#if CAPE_VAR_GEMM == 1
+            for (unsigned k0 = 0; k0 < cols; k0 += 256) // depth blocking of a GEMM kernel: block sums added to C
+            {
+                double blk = 0.0;
+                for (unsigned k = k0; k < std::min(cols, k0 + 256u); ++k)
+                    blk += normals[3 * k + r] * normals[3 * k + c];
+                acc += blk;
+            }
+#elif CAPE_VAR_GEMM == 2
+            for (unsigned k = cols; k-- > 0;)
+                acc += normals[3 * k + r] * normals[3 * k + c];
+#elif CAPE_VAR_GEMM == 3
+            double even = 0.0, odd = 0.0; // a depth-vectorised inner product: two accumulators, reduced at the end
+            for (unsigned k = 0; k + 1 < cols; k += 2)
+            {
+                even += normals[3 * k + r] * normals[3 * k + c];
+                odd += normals[3 * (k + 1) + r] * normals[3 * (k + 1) + c];
+            }
+            if (cols & 1u)
+                even += normals[3 * (cols - 1) + r] * normals[3 * (cols - 1) + c];
+            acc = even + odd;
+#else
             for (unsigned k = 0; k < cols; ++k)
                 acc += normals[3 * k + r] * normals[3 * k + c];
+#endif
             cov[r][c] = acc / static_cast<double>(cols - 1);
         }
     }
@@ -1079,8 +1305,8 @@ void Oracle::find_primitives(const float* cloud, const float* depth, FrameResult
             const PlaneSeg& seg = planeGrid[cell];
             if (seg.planar)
             {
-                p0[cell] = acos(-seg.normal[2]);
-                p1[cell] = atan2(seg.normal[0], seg.normal[1]);
+                p0[cell] = libm_variant(acos(-seg.normal[2]));
+                p1[cell] = libm_variant(atan2(seg.normal[0], seg.normal[1]));
                 ++remainingPlanarCells;
                 isUnassigned[cell] = 1;
             }

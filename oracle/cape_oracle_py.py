@@ -24,14 +24,16 @@ def build(force=False):
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+def lib(path=None):
+    """The oracle library (default build), or a variant build at `path` (oracle/variants.py: risk measurement only)."""
+    key = path or _LIB_PATH
+    if key not in _libs:
+        if path is None:
+            build()
+        L = C.CDLL(key)
         L.cape_oracle_create.restype = C.c_void_p
         L.cape_oracle_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
         L.cape_oracle_destroy.argtypes = [C.c_void_p]
@@ -60,8 +62,8 @@ def lib():
         L.cape_oracle_ransac_max_iterations.restype = C.c_uint
         L.cape_oracle_cos_merge_angle.restype = C.c_double
         L.cape_oracle_sin_merge_angle.restype = C.c_float
-        _lib = L
-    return _lib
+        _libs[key] = L
+    return _libs[key]
 
 
 def _p(a):
@@ -75,8 +77,8 @@ class OracleResult:
 
 
 class Oracle:
-    def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=True):
-        self.L = lib()
+    def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=True, lib_path=None):
+        self.L = lib(lib_path)
         self.width, self.height = width, height
         self.h = self.L.cape_oracle_create(width, height, fx, fy, cx, cy, 1 if cylinders else 0)
         self.cells = self.L.cape_oracle_cells(self.h)

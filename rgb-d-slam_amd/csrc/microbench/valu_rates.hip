@@ -13,8 +13,10 @@ template <int OP> __global__ void k(double* out, float seedf, double seedd)
 {
     double d[UNROLL];
     float f[UNROLL];
+    unsigned u[UNROLL];
+    unsigned long long m[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) { d[i] = seedd + i + threadIdx.x; f[i] = seedf + i + threadIdx.x; }
+    for (int i = 0; i < UNROLL; ++i) { d[i] = seedd + i + threadIdx.x; f[i] = seedf + i + threadIdx.x; u[i] = 7u * i + threadIdx.x; }
     for (int it = 0; it < ITERS; ++it)
     {
 #pragma unroll
@@ -28,11 +30,37 @@ template <int OP> __global__ void k(double* out, float seedf, double seedd)
             if (OP == 5) f[i] = f[i] * seedf;                       // v_mul_f32
             if (OP == 6) f[i] = f[i] + seedf;                       // v_add_f32
             if (OP == 7) { asm volatile("v_max_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(seedf)); }
+            // round 2: which f32-class / integer instructions run at the doubled (SIMD-32) rate and which do not
+            if (OP == 8) { asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(f[i]) : "v"(f[i]), "v"(seedf)); }
+            if (OP == 9) { asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(f[i]), "v"(seedf) : "vcc"); }
+            if (OP == 10) { asm volatile("v_addc_co_u32 %0, vcc, %1, 0, vcc" : "=v"(u[i]) : "v"(u[i]) : "vcc"); }
+            if (OP == 11) { asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(f[i]) : "v"(f[i]), "v"(seedf), "v"(f[(i + 1) % UNROLL])); }
+            if (OP == 12) { asm volatile("v_min_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL])); }
+            if (OP == 13) { asm volatile("v_min3_u32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL]), "v"(u[(i + 2) % UNROLL])); }
+            if (OP == 14) { asm volatile("v_add_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL])); }
+            if (OP == 15) { asm volatile("v_and_b32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL])); }
+            if (OP == 16) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(f[i]) : "v"(f[i]), "v"(seedf), "v"(seedf)); }
+            if (OP == 17) { asm volatile("v_mov_b32 %0, %1" : "=v"(f[i]) : "v"(f[(i + 1) % UNROLL])); }
+            if (OP == 18) { asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(u[i])); }
+            if (OP == 19) { asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(u[i]) : "v"(u[i])); }
+            if (OP == 20) { asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL]), "v"(u[(i + 2) % UNROLL])); }
+            if (OP == 21) { asm volatile("v_sub_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(seedf)); }
+            if (OP == 22) { asm volatile("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(f[i]) : "v"(f[i]), "v"(seedf)); }
+            if (OP == 23) { asm volatile("v_max_f32_e64 %0, %1, %1" : "=v"(f[i]) : "v"(f[i])); }
+            if (OP == 24) { asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(f[i]) : "v"(f[i]), "v"(seedf), "v"(seedf)); }
+            if (OP == 25) { asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m[i % 4]) : "v"(f[i]), "v"(seedf)); }
+            if (OP == 26) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(f[i]) : "v"(seedf), "v"(seedf)); }
+            if (OP == 27) { asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d[i]) : "v"(d[i]), "v"(seedd)); }
+            if (OP == 28) { asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(f[i]) : "v"(u[i])); }
+            if (OP == 29) { asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL])); }
+            if (OP == 30) { asm volatile("v_sub_u32 %0, %1, %2" : "=v"(u[i]) : "v"(u[i]), "v"(u[(i + 1) % UNROLL])); }
+            if (OP == 31) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(f[i]) : "v"(f[i]), "v"(seedf)); }
         }
     }
     double acc = 0;
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) acc += d[i] + (double)f[i];
+    for (int i = 0; i < UNROLL; ++i) acc += d[i] + (double)f[i] + (double)u[i];
+    acc += (double)(m[0] ^ m[1] ^ m[2] ^ m[3]);
     if (acc == 12345.678) out[0] = acc;
 }
 
@@ -61,5 +89,11 @@ int main()
     run<0>("v_add_f64", out); run<1>("v_mul_f64", out); run<2>("v_fma_f64", out);
     run<3>("v_cvt_f64_f32", out); run<4>("v_cvt_f32_f64", out);
     run<5>("v_mul_f32", out); run<6>("v_add_f32", out); run<7>("v_max_f32", out);
+    run<8>("v_cndmask_b32", out); run<9>("v_cmp_gt_f32 vcc", out); run<10>("v_addc_co_u32", out); run<11>("v_min3_f32", out);
+    run<12>("v_min_u32", out); run<13>("v_min3_u32", out); run<14>("v_add_u32", out); run<15>("v_and_b32", out);
+    run<16>("v_fma_f32", out); run<17>("v_mov_b32", out); run<18>("v_cvt_f32_u32", out); run<19>("v_lshlrev_b32", out);
+    run<20>("v_add3_u32", out); run<21>("v_sub_f32", out); run<22>("v_mul_f32 clamp", out); run<23>("v_max_f32 x,x", out);
+    run<24>("v_med3_f32", out); run<25>("v_cmp_gt_f32 sgpr", out); run<26>("v_fmac_f32", out); run<27>("v_pk_mul_f32", out);
+    run<28>("v_cvt_f32_f16", out); run<29>("v_mul_u32_u24", out); run<30>("v_sub_u32", out); run<31>("v_add_f32 asm", out);
     return 0;
 }
