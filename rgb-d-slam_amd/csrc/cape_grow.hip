@@ -20,6 +20,7 @@
 
 #include "cape_cylinder.h"
 #include "cape_staged.h"
+#include "cape_wave.h"
 #include "cape_device.h"
 #include "cape_internal.h"
 
@@ -86,53 +87,6 @@ __host__ __device__ constexpr int kChunkDoubles(int) { return kChunk * kSumStrid
 // is what lets the cell-sum prefetch below stay in flight across it.
 #define CAPE_LDS_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        const unsigned w = __shfl_xor(v, o);
-        v = (w > v) ? w : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        const unsigned long long w = __shfl_xor(v, o);
-        v = (w < v) ? w : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v |= __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
-    return v;
-}
-// inclusive prefix sum over lanes
-__device__ __forceinline__ int wave_scan_i32(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-    {
-        const int w = __shfl_up(v, o);
-        if (lane >= o)
-            v += w;
-    }
-    return v;
-}
-
 template <typename MaskT> __device__ __forceinline__ int popc(MaskT m);
 template <> __device__ __forceinline__ int popc<uint32_t>(uint32_t m) { return __popc(m); }
 template <> __device__ __forceinline__ int popc<unsigned long long>(unsigned long long m) { return __popcll(m); }
@@ -150,15 +104,11 @@ template <typename MaskT> __device__ __forceinline__ MaskT row3(MaskT x, MaskT w
 
 template <typename MaskT> struct Rows
 {
-    // neighbour rows of a per-lane row mask
-    static __device__ __forceinline__ MaskT up(MaskT v, int lane) // row r-1
+    // neighbour rows of a per-lane row mask: one DPP wave shift (zero past the ends of the wave)
+    static __device__ __forceinline__ MaskT up(MaskT v, int) { return wave_from_lane_below(v); } // row r-1
+    static __device__ __forceinline__ MaskT dn(MaskT v, int lane, int vCells)                     // row r+1
     {
-        const MaskT w = (MaskT)__shfl_up((unsigned long long)v, 1);
-        return lane > 0 ? w : (MaskT)0;
-    }
-    static __device__ __forceinline__ MaskT dn(MaskT v, int lane, int vCells) // row r+1
-    {
-        const MaskT w = (MaskT)__shfl_down((unsigned long long)v, 1);
+        const MaskT w = wave_from_lane_above(v);
         return (lane + 1 < vCells) ? w : (MaskT)0;
     }
 };
@@ -251,9 +201,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     // ---- LDS carve (all offsets multiples of 16)
     // ---- LDS carve (every offset a multiple of 8; 13.4 KB for 640x480 plane-only -> 12 waves per CU)
     double* s_seg = reinterpret_cast<double*>(smem);                              // MAXP x 20 f64
-    double* s_chunk = s_seg + MAXP * kSegDoubles;                      // kChunk x 10 f64 staging of cell sums
-    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // 32 u64
-    int* s_hist = reinterpret_cast<int*>(s_adj + MAXP);                // 400 i32
+    double* s_chunk = s_seg + (MAXP + 1) * kSegDoubles;               // kChunk x 10 f64 staging of cell sums (s_seg: MAXP + 1 spare slot)
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // MAXP + 1 u64
+    int* s_hist = reinterpret_cast<int*>(s_adj + MAXP + 1);            // 400 i32
     short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
@@ -264,7 +214,8 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
-    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64
+    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64 (+ read-ahead pad)
+    double* s_pendCyl = s_dist + C + 16;                                          // 16 region records (cylinder instance)
 #ifdef CAPE_B_PROFILE
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsPerWave - 8 * kProfileSlots);
     if (lane < kProfileSlots)
@@ -277,10 +228,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
 
     for (int i = lane; i < kHistBins; i += 64)
         s_hist[i] = 0;
-    for (int i = lane; i < MAXP; i += 64)
+    for (int i = lane; i < MAXP + 1; i += 64)
     {
         s_adj[i] = 0ull;
-        s_mlab[i] = (unsigned char)i;
+        if (i < MAXP)
+            s_mlab[i] = (unsigned char)i;
     }
     CAPE_WAVE_SYNC();
 
@@ -473,254 +425,365 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     const double* sumsBase = p.cell_sums + cellBase * kSumStride;
     const int maxSeedIters = 4 * C + 1024; // the loop provably terminates (every iteration burns a histogram count)
 
-    while (untried > 0 && nSeeds < maxSeedIters)
+    // The cell MSEs never change: with up to 12 cells per lane (the 640x480 grid) they are fetched ONCE into registers
+    // in exactly the lane <-> cell pattern of the candidate scan, so picking a seed costs no memory round trip.
+    constexpr int kMseRegs = 12;
+    const bool mseInRegs = C <= 64 * kMseRegs;
+    const double* mseBase = p.cell_mse + cellBase;
+    double mreg[kMseRegs];
+#pragma unroll
+    for (int k = 0; k < kMseRegs; ++k)
     {
-        // ---- Histogram::get_points_from_most_frequent_bin (histogram.hpp:69-98): first index of the greatest count
-        unsigned key = 0;
-        for (int b = lane; b < kHistBins; b += 64)
-        {
-            const int h = s_hist[b];
-            const unsigned k = ((unsigned)h << 16) | (unsigned)(0xFFFF - b);
-            key = (h > 0 && k > key) ? k : key;
-        }
-        key = wave_max_u32(key);
-        if (key == 0)
-            break; // mostFrequentBin = -1 -> empty candidate list -> size < planeSeedCount
-        const int bin = 0xFFFF - (int)(key & 0xFFFFu);
+        const int i = lane + 64 * k;
+        mreg[k] = mseBase[i < C ? i : 0];
+    }
 
-        // ---- candidates = cells with _bins == bin ; seed = first strict minimum of MSE (:285-298)
-        int candLocal = 0;
-        unsigned long long bestLocal = ~0ull; // (mse bits) ; mse >= 0 so the bit pattern orders like the value
-        int bestIdxLocal = 0x7FFFFFFF;
-        {
-            const double* mseBase = p.cell_mse + cellBase;
-            constexpr int kBatch = 12; // 12 independent coalesced loads in flight per lane
-            for (int i0 = lane; i0 < C; i0 += 64 * kBatch)
+    // What a seed's region is (label propagation), what it costs the histogram and the unassigned mask, and hence every
+    // LATER seed, do not depend on the plane fitted to it (primitive_detection.cpp:332-389: the fit only decides whether
+    // the region becomes a plane segment, goes to cylinder fitting or is dropped).  So the loop only RECORDS a region --
+    // its ordered moment sums and its cell list -- and the fits of up to pendCap recorded regions run together, one lane
+    // per region, instead of 64 lanes computing the same eigen-decomposition once per seed; the recorded regions are then
+    // turned into segments in seed order.  Plane-only instances park the records in the free s_seg slots above nSeg (a
+    // segment is never written above the record it comes from); the cylinder instance, whose cylinder_fitting appends
+    // segments of its own, has a separate area.
+    constexpr int kPendCyl = 16;
+    double* s_pend = CYL ? s_pendCyl : s_seg;     // base of the record window (plane-only: advanced to s_seg + nSeg at each flush)
+    int pendCount = 0, pendCap = CYL ? kPendCyl : MAXP + 1;
+    int listTop = 0;                               // bump pointer in s_list: recorded regions keep their cell lists
+    bool moreSeeds = true;
+
+    for (;;)
+    {
+        if (moreSeeds && !(untried > 0 && nSeeds < maxSeedIters))
+            moreSeeds = false;
+        if (moreSeeds)
+            do
             {
-                double mv[kBatch];
-#pragma unroll
-                for (int k = 0; k < kBatch; ++k)
+                // ---- Histogram::get_points_from_most_frequent_bin (histogram.hpp:69-98): first index of the greatest count
+                unsigned key = 0;
+                for (int b = lane; b < kHistBins; b += 64)
                 {
-                    const int i = i0 + 64 * k;
-                    mv[k] = mseBase[i < C ? i : 0];
+                    const int h = s_hist[b];
+                    const unsigned k = ((unsigned)h << 16) | (unsigned)(0xFFFF - b);
+                    key = (h > 0 && k > key) ? k : key;
                 }
-#pragma unroll
-                for (int k = 0; k < kBatch; ++k)
+                key = wave_max_u32(key);
+                if (key == 0)
                 {
-                    const int i = i0 + 64 * k;
-                    if (i < C && s_bins[i] == (short)bin)
+                    moreSeeds = false; // mostFrequentBin = -1 -> empty candidate list -> size < planeSeedCount
+                    break;
+                }
+                const int bin = 0xFFFF - (int)(key & 0xFFFFu);
+
+                // ---- candidates = cells with _bins == bin ; seed = first strict minimum of MSE (:285-298)
+                int candLocal = 0;
+                unsigned long long bestLocal = ~0ull; // (mse bits) ; mse >= 0 so the bit pattern orders like the value
+                int bestIdxLocal = 0x7FFFFFFF;
+                if (mseInRegs)
+                {
+#pragma unroll
+                    for (int k = 0; k < kMseRegs; ++k)
                     {
-                        ++candLocal;
-                        const unsigned long long mb = (unsigned long long)__double_as_longlong(mv[k]);
-                        if (mb < bestLocal)
+                        const int i = lane + 64 * k;
+                        if (i < C && s_bins[i] == (short)bin)
                         {
-                            bestLocal = mb;
-                            bestIdxLocal = i;
+                            ++candLocal;
+                            const unsigned long long mb = (unsigned long long)__double_as_longlong(mreg[k]);
+                            if (mb < bestLocal)
+                            {
+                                bestLocal = mb;
+                                bestIdxLocal = i;
+                            }
                         }
                     }
                 }
-            }
-        }
-        CAPE_TICK(2); // histogram arg-max + candidate scan
-        const int cand = wave_sum_i32(candLocal);
-        if (cand < p.planeSeedCount || cand == 0)
-            break;
-        const unsigned long long bestAll = wave_min_u64(bestLocal);
-        const unsigned idxKey = (bestLocal == bestAll) ? (unsigned)(0x7FFFFFFF - bestIdxLocal) : 0u;
-        const int seed = 0x7FFFFFFF - (int)wave_max_u32(idxKey);
-        if (__longlong_as_double((long long)bestAll) >= kDblMax)
-            break; // "invalid seed" (:299-304)
-        if (lane == 0 && p.seed_sequence && nSeeds < C)
-            p.seed_sequence[cellBase + nSeeds] = (uint16_t)seed; // debug / parity stream: seeds in the order they were tried
-        ++nSeeds;
-
-        // ---- grow_plane_segment_at_seed (:312-389)
-        const int sy = seed / HC, sx = seed - sy * HC;
-        const double* spl = p.cell_plane + (cellBase + seed) * kPlaneStride;
-        const double snx = spl[0], sny = spl[1], snz = spl[2], sd = spl[3];
-        const double scx = spl[4], scy = spl[5], scz = spl[6];
-        const double stol = (double)p.cell_tol[cellBase + seed];
-        // newPlaneSegment(planeToGrow): the copy re-normalises the normal (plane_coordinates.hpp:24-27)
-        double pnx = snx, pny = sny, pnz = snz;
-        normalize3(pnx, pny, pnz);
-        const MaskT seedRowU = shfl_mask<MaskT>(U, sy);
-        const bool seedUnassigned = (seedRowU >> sx) & (MaskT)1;
-        const bool seedOK = seedUnassigned && can_be_merged(pnx, pny, pnz, sd, snx, sny, snz, scx, scy, scz, stol, p.cosMerge);
-
-        CAPE_TICK(3); // seed pick + self test
-        // ---- region_growing (:778-818) as label propagation on bit rows
-        MaskT act = 0;
-        if (seedOK)
-        {
-            if (lane == sy)
-                act = (MaskT)1 << sx;
-            for (;;)
-            {
-                MaskT a = act;
-                for (;;)
+                else
                 {
-                    const MaskT na = a | (U & (((MaskT)(a << 1) & EL) | ((MaskT)(a >> 1) & ER)));
-                    if (na == a)
-                        break;
-                    a = na;
-                }
-                const MaskT up = Rows<MaskT>::up(a, lane);
-                const MaskT dn = Rows<MaskT>::dn(a, lane, VC);
-                a |= U & ((up & EU) | (dn & ED));
-                const bool changed = (a != act);
-                act = a;
-                if (!__any(changed))
-                    break;
-            }
-        }
-
-        CAPE_TICK(4); // label propagation
-        // ---- activated cell list in ascending cell index (row-major)
-        const int rowCnt = popc<MaskT>(act);
-        const int incl = wave_scan_i32(rowCnt, lane);
-        const int total = __shfl(incl, 63);
-        {
-            int pos = incl - rowCnt;
-            MaskT m = act;
-            while (m)
-            {
-                const int c = ctz<MaskT>(m);
-                s_list[pos++] = (unsigned short)(lane * HC + c);
-                m &= m - 1;
-            }
-        }
-        CAPE_WAVE_SYNC();
-
-        // ---- expand_segment over activated cells in ascending order (:341-360): lanes 0..8 own one sum each, lane 9
-        //      the point count.  The seed's own sums are counted twice (copy :325 + expand of the seed itself).
-        CAPE_TICK(5); // list build
-        const int ql = lane < 10 ? lane : 0;
-        // element 0 is the seed itself (0.0 + x == x exactly), so its sums travel with the first staged chunk instead of
-        // costing a memory round trip of their own
-        double acc = 0.0;
-        staged_for_each<5, CAPE_STAGE_DEPTH_MAIN>(
-                total + 1, sumsBase, kSumStride, 0, [&](int e) { return e == 0 ? seed : (int)s_list[e - 1]; }, s_chunk, lane,
-                [&](int, const double* rec) { return rec[ql]; }, [&](int, double v) { acc += v; });
-
-        CAPE_TICK(6); // ordered accumulation
-        // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
-        for (int i = lane; i < total; i += 64)
-        {
-            const int cidx = s_list[i];
-            atomicSub(&s_hist[s_bins[cidx]], 1);
-            s_bins[cidx] = 1; // quirk: 1, not -1
-        }
-        CAPE_WAVE_SYNC();
-        if (lane == 0 && s_hist[1] < 0)
-            s_hist[1] = 0; // "if != 0: -= 1" saturates; only bin 1 can be over-decremented
-        U &= ~act;
-        untried -= total;
-
-        if (total == 0 || total < p.minCellActivated)
-        {
-            if (lane == 0)
-            {
-                const int b = s_bins[seed];
-                if (s_hist[b] != 0)
-                    s_hist[b] -= 1;
-                s_bins[seed] = 1;
-            }
-            CAPE_WAVE_SYNC();
-            continue;
-        }
-        CAPE_WAVE_SYNC();
-
-        CAPE_TICK(7); // histogram removal
-        SegRec ns;
+                    constexpr int kBatch = 12; // 12 independent coalesced loads in flight per lane
+                    for (int i0 = lane; i0 < C; i0 += 64 * kBatch)
+                    {
+                        double mv[kBatch];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            ns.S[k] = __shfl(acc, k);
-        ns.n = __shfl(acc, 9);
-        PlaneFit f;
-        fit_plane(ns.S, (uint32_t)ns.n, f);
-        if (!f.planar)
-            continue; // "Plane segment is not planar after merge"
+                        for (int k = 0; k < kBatch; ++k)
+                        {
+                            const int i = i0 + 64 * k;
+                            mv[k] = mseBase[i < C ? i : 0];
+                        }
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k)
+                        {
+                            const int i = i0 + 64 * k;
+                            if (i < C && s_bins[i] == (short)bin)
+                            {
+                                ++candLocal;
+                                const unsigned long long mb = (unsigned long long)__double_as_longlong(mv[k]);
+                                if (mb < bestLocal)
+                                {
+                                    bestLocal = mb;
+                                    bestIdxLocal = i;
+                                }
+                            }
+                        }
+                    }
+                }
+                CAPE_TICK(2); // histogram arg-max + candidate scan
+                const int cand = wave_sum_i32(candLocal);
+                if (cand < p.planeSeedCount || cand == 0)
+                {
+                    moreSeeds = false;
+                    break;
+                }
+                const unsigned long long bestAll = wave_min_u64(bestLocal);
+                const unsigned idxKey = (bestLocal == bestAll) ? (unsigned)(0x7FFFFFFF - bestIdxLocal) : 0u;
+                const int seed = 0x7FFFFFFF - (int)wave_max_u32(idxKey);
+                if (__longlong_as_double((long long)bestAll) >= kDblMax)
+                {
+                    moreSeeds = false; // "invalid seed" (:299-304)
+                    break;
+                }
+                if (lane == 0 && p.seed_sequence && nSeeds < C)
+                    p.seed_sequence[cellBase + nSeeds] = (uint16_t)seed; // debug / parity stream: seeds in the order they were tried
+                ++nSeeds;
 
-        CAPE_TICK(8); // region plane fit
-        if (f.score > 100)
-        {
-            // add_plane_segment_to_features (:391-411): push_back copies the segment (one more normalisation)
-            if (nSeg >= MAXP)
-            {
-                if (!kRedo && p.redoList)
+                // ---- grow_plane_segment_at_seed (:312-389).  The seed's own plane is requested now and looked at after the
+                //      propagation, which does not need it: the memory round trip hides behind the label propagation.
+                const int sy = seed / HC, sx = seed - sy * HC;
+                const double2* spl = reinterpret_cast<const double2*>(p.cell_plane + (cellBase + seed) * kPlaneStride);
+                const double2 sp0 = spl[0], sp1 = spl[1], sp2 = spl[2], sp3 = spl[3];
+                const float stolf = p.cell_tol[cellBase + seed];
+                const MaskT seedRowU = shfl_mask<MaskT>(U, sy);
+                const bool seedUnassigned = (seedRowU >> sx) & (MaskT)1;
+
+                CAPE_TICK(3); // seed pick
+                // ---- region_growing (:778-818) as label propagation on bit rows
+                MaskT act = 0;
+                if (seedUnassigned)
                 {
-                    // out of LDS segment slots: the 64-segment instance redoes this frame from the start
+                    if (lane == sy)
+                        act = (MaskT)1 << sx;
+                    for (;;)
+                    {
+                        MaskT a = act;
+                        for (;;)
+                        {
+                            const MaskT na = a | (U & (((MaskT)(a << 1) & EL) | ((MaskT)(a >> 1) & ER)));
+                            if (na == a)
+                                break;
+                            a = na;
+                        }
+                        const MaskT up = Rows<MaskT>::up(a, lane);
+                        const MaskT dn = Rows<MaskT>::dn(a, lane, VC);
+                        a |= U & ((up & EU) | (dn & ED));
+                        const bool changed = (a != act);
+                        act = a;
+                        if (!__any(changed))
+                            break;
+                    }
+                }
+                {
+                    // the seed's own test: newPlaneSegment(planeToGrow) is a copy, and the copy re-normalises the normal
+                    // (plane_coordinates.hpp:24-27) before can_be_merged compares it with the original
+                    const double snx = sp0.x, sny = sp0.y, snz = sp1.x, sd = sp1.y, scx = sp2.x, scy = sp2.y, scz = sp3.x;
+                    double pnx = snx, pny = sny, pnz = snz;
+                    normalize3(pnx, pny, pnz);
+                    const bool seedOK = can_be_merged(pnx, pny, pnz, sd, snx, sny, snz, scx, scy, scz, (double)stolf, p.cosMerge);
+                    if (!seedOK)
+                        act = 0;
+                }
+
+                CAPE_TICK(4); // label propagation + seed self test
+                // ---- activated cell list in ascending cell index (row-major), appended at listTop
+                const int rowCnt = popc<MaskT>(act);
+                const int incl = wave_scan_i32(rowCnt);
+                const int total = (int)readlane_u32((unsigned)incl, 63);
+                unsigned short* rlist = s_list + listTop;
+                {
+                    int pos = incl - rowCnt;
+                    MaskT m = act;
+                    while (m)
+                    {
+                        const int c = ctz<MaskT>(m);
+                        rlist[pos++] = (unsigned short)(lane * HC + c);
+                        m &= m - 1;
+                    }
+                }
+                CAPE_WAVE_SYNC();
+
+                // ---- expand_segment over activated cells in ascending order (:341-360): lanes 0..8 own one sum each, lane 9
+                //      the point count.  The seed's own sums are counted twice (copy :325 + expand of the seed itself).
+                CAPE_TICK(5); // list build
+                const int ql = lane < 10 ? lane : 0;
+                // element 0 is the seed itself (0.0 + x == x exactly), so its sums travel with the first staged chunk instead of
+                // costing a memory round trip of their own
+                double acc = 0.0;
+                staged_for_each<5, CAPE_STAGE_DEPTH_MAIN>(
+                        total + 1, sumsBase, kSumStride, 0, [&](int e) { return e == 0 ? seed : (int)rlist[e - 1]; }, s_chunk, lane,
+                        [&](int, const double* rec) { return rec[ql]; }, [&](int, double v) { acc += v; });
+
+                CAPE_TICK(6); // ordered accumulation
+                // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
+                for (int i = lane; i < total; i += 64)
+                {
+                    const int cidx = rlist[i];
+                    atomicSub(&s_hist[s_bins[cidx]], 1);
+                    s_bins[cidx] = 1; // quirk: 1, not -1
+                }
+                CAPE_WAVE_SYNC();
+                if (lane == 0 && s_hist[1] < 0)
+                    s_hist[1] = 0; // "if != 0: -= 1" saturates; only bin 1 can be over-decremented
+                U &= ~act;
+                untried -= total;
+
+                if (total == 0 || total < p.minCellActivated)
+                {
                     if (lane == 0)
-                        p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                    {
+                        const int b = s_bins[seed];
+                        if (s_hist[b] != 0)
+                            s_hist[b] -= 1;
+                        s_bins[seed] = 1;
+                    }
+                    CAPE_WAVE_SYNC();
+                    break; // region dropped: nothing recorded, its list slots are reused
+                }
+                // ---- record the region: sums + count into the window slot, list kept
+                if (lane < 10)
+                    s_pend[pendCount * kSegDoubles + lane] = acc;
+                if (lane == 0)
+                    s_adj[pendCount] = (unsigned long long)(unsigned)listTop | ((unsigned long long)(unsigned)total << 32);
+                listTop += total;
+                ++pendCount;
+                CAPE_WAVE_SYNC();
+                CAPE_TICK(7); // histogram removal + record
+            } while (0);
+
+        if (moreSeeds && pendCount < pendCap)
+            continue;
+        if (pendCount > 0)
+        {
+            // ---- fit_plane (plane_segment.cpp:232-284) of every recorded region, one lane per region
+            CAPE_TICK_RESTART();
+            if (lane < pendCount)
+            {
+                double* slot = s_pend + lane * kSegDoubles;
+                double S[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    S[k] = slot[k];
+                PlaneFit f;
+                fit_plane(S, (uint32_t)slot[9], f);
+                // add_plane_segment_to_features (:391-411): push_back copies the segment (one more normalisation); only a
+                // region that becomes a plane segment reads the normal, so the copy's normalisation is applied here
+                double nx = f.nx, ny = f.ny, nz = f.nz;
+                normalize3(nx, ny, nz);
+                slot[10] = nx; slot[11] = ny; slot[12] = nz; slot[13] = f.d;
+                slot[14] = f.cx; slot[15] = f.cy; slot[16] = f.cz;
+                slot[17] = f.mse; slot[18] = f.score; slot[19] = f.planar ? 1.0 : 0.0;
+            }
+            CAPE_WAVE_SYNC();
+            CAPE_TICK(8); // region plane fits (lane parallel)
+            bool stopAll = false;
+            for (int j = 0; j < pendCount && !stopAll; ++j)
+            {
+                SegRec ns;
+                seg_load(s_pend + j * kSegDoubles, ns);
+                const unsigned long long meta = s_adj[j];
+                const int roff = (int)(unsigned)meta, total = (int)(meta >> 32);
+                if (ns.planar == 0.0)
+                    continue; // "Plane segment is not planar after merge"
+                if (ns.score > 100)
+                {
+                    if (nSeg >= MAXP)
+                    {
+                        if (!kRedo && p.redoList)
+                        {
+                            // out of LDS segment slots: the 64-segment instance redoes this frame from the start
+                            if (lane == 0)
+                                p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                            return;
+                        }
+                        status |= CAPE_FRAME_PLANE_OVERFLOW;
+                        stopAll = true;
+                        break;
+                    }
+                    if (lane == 0)
+                        seg_store(s_seg + nSeg * kSegDoubles, ns); // at or below the record's own slot (plane-only window)
+                    ++nSeg;
+                    for (int i = lane; i < total; i += 64)
+                        s_lab[s_list[roff + i]] = (unsigned char)nSeg;
+                    CAPE_WAVE_SYNC();
+                }
+                else if (!CYL && !kRedo && p.twoPass && total > 5)
+                {
+                    // first pass of the two-pass schedule: this region goes to cylinder_fitting, which the plane-only kernel does
+                    // not carry -- hand the whole frame to the cylinder kernel (it starts over; nothing written so far counts)
+                    if (lane == 0)
+                        p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
                     return;
                 }
-                status |= CAPE_FRAME_PLANE_OVERFLOW;
-                break;
-            }
-            ns.nx = f.nx; ns.ny = f.ny; ns.nz = f.nz; ns.d = f.d;
-            normalize3(ns.nx, ns.ny, ns.nz);
-            ns.cx = f.cx; ns.cy = f.cy; ns.cz = f.cz;
-            ns.mse = f.mse; ns.score = f.score; ns.planar = 1.0;
-            if (lane == 0)
-                seg_store(s_seg + nSeg * kSegDoubles, ns);
-            ++nSeg;
-            for (int i = lane; i < total; i += 64)
-                s_lab[s_list[i]] = (unsigned char)nSeg;
-            CAPE_WAVE_SYNC();
-        }
-        else if (!CYL && !kRedo && p.twoPass && total > 5)
-        {
-            // first pass of the two-pass schedule: this region goes to cylinder_fitting, which the plane-only kernel does
-            // not carry -- hand the whole frame to the cylinder kernel (it starts over; nothing written so far counts)
-            if (lane == 0)
-                p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
-            return;
-        }
-        else if (CYL && total > 5)
-        {
-            // cylinder_fitting (:478-501) ; CYL == false is the "plane-only" mode (region dropped, cells stay consumed)
-            CylCtx cc;
-            cc.p = &p;
-            cc.lane = lane;
-            cc.cellBase = cellBase;
-            cc.C = C;
-            cc.s_list = s_list;
-            cc.total = total;
-            cc.s_dist = s_dist;
-            cc.s_ids = s_ids;
-            cc.s_idmask = s_idmask;
-            cc.s_cur = s_cur;
-            cc.s_best = s_best;
-            cc.scratch = p.cylScratch + cellBase * kCylStride;
-            cc.s_stage = s_chunk;
-            cc.s_seg = s_seg;
-            cc.s_lab = s_lab;
-            cc.s_cyl = s_cyl;
-            cc.rec = p.records + frame;
-            cc.maxPlanes = MAXP;
+                else if (CYL && total > 5)
+                {
+                    // cylinder_fitting (:478-501) ; CYL == false is the "plane-only" mode (region dropped, cells stay consumed)
+                    CylCtx cc;
+                    cc.p = &p;
+                    cc.lane = lane;
+                    cc.cellBase = cellBase;
+                    cc.C = C;
+                    cc.s_list = s_list + roff;
+                    cc.total = total;
+                    cc.s_dist = s_dist;
+                    cc.s_ids = s_ids;
+                    cc.s_idmask = s_idmask;
+                    cc.s_cur = s_cur;
+                    cc.s_best = s_best;
+                    cc.scratch = p.cylScratch + cellBase * kCylStride;
+                    cc.s_stage = s_chunk;
+                    cc.s_seg = s_seg;
+                    cc.s_lab = s_lab;
+                    cc.s_cyl = s_cyl;
+                    cc.rec = p.records + frame;
+                    cc.maxPlanes = MAXP;
 #ifdef CAPE_B_PROFILE
-            cc.dbg = s_prof;
+                    cc.dbg = s_prof;
 #else
-            cc.dbg = nullptr;
+                    cc.dbg = nullptr;
 #endif
-            bool planeOverflow = false;
-            cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
-            ++nCylFits;
-            CAPE_WAVE_SYNC();
-            CAPE_TICK_RESTART(); // the cylinder phases booked themselves in slots 12..15
-            if (planeOverflow)
-            {
-                if (!kRedo && p.redoList)
-                {
-                    if (lane == 0)
-                        p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
-                    return;
+                    bool planeOverflow = false;
+                    cylinder_fitting(cc, nSeg, nCylLabels, nCylFits, rngPos, status, planeOverflow);
+                    ++nCylFits;
+                    CAPE_WAVE_SYNC();
+                    if (planeOverflow)
+                    {
+                        if (!kRedo && p.redoList)
+                        {
+                            if (lane == 0)
+                                p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                            return;
+                        }
+                        status |= CAPE_FRAME_PLANE_OVERFLOW;
+                        stopAll = true;
+                        break;
+                    }
                 }
-                status |= CAPE_FRAME_PLANE_OVERFLOW;
+            }
+            CAPE_TICK_RESTART(); // the cylinder phases booked themselves in slots 12..15
+            pendCount = 0;
+            if (stopAll)
                 break;
+            if (!CYL)
+            {
+                // plane-only: the next window starts at the first free segment slot (one spare slot past MAXP keeps it non-empty)
+                s_pend = s_seg + nSeg * kSegDoubles;
+                pendCap = MAXP + 1 - nSeg;
             }
         }
+        if (!moreSeeds)
+            break;
     }
+    // the record window borrowed s_adj for (list offset, length): back to zeros for merge_planes
+    for (int i = lane; i < MAXP + 1; i += 64)
+        s_adj[i] = 0ull;
+    CAPE_WAVE_SYNC();
 
     if (untried > 0 && nSeeds >= maxSeedIters)
         status |= CAPE_FRAME_SEED_LIMIT; // cannot happen (see maxSeedIters); says so if it ever does
@@ -813,34 +876,53 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     CAPE_WAVE_SYNC();
     cape_frame_record* rec = p.records + frame;
     double* bnd = p.boundary + (size_t)frame * p.boundaryCapacity * 3;
-    const double acolCenter = p.acol[(lane < HC ? lane : 0) * kCell + kCell / 2];
-    const double browCenterOfLane = p.brow[(lane < VC ? lane : 0) * kCell + kCell / 2]; // row r's value is broadcast below
+    const double browCenterOfLane = p.brow[(lane < VC ? lane : 0) * kCell + kCell / 2]; // lane r: row r's centre ordinate
+    const double acolCenterOfLane = p.acol[(lane < HC ? lane : 0) * kCell + kCell / 2]; // lane c: column c's centre abscissa
     int nBoundary = 0;
-    int nPlanesOut = 0;
+    // lane j keeps what the loop decides for plane segment j (MAXP <= 64 = the wave width)
+    const int myMlab = lane < nSeg ? (int)s_mlab[lane] : -1;
+    uint32_t myOut = 0, myOff = 0, myCnt = 0;
+    // Boundary candidates of one plane = the cells of its ring (dilate(square) minus erode(cross)) whose centre pixel lies
+    // within 3 sigma of the plane, in row-major order.  The ring cells are enumerated with a prefix sum over the rows into a
+    // cell list (the staging chunk is free here), so that 64 lanes test 64 ring cells at a time instead of one grid row at
+    // a time; a band of rows that surely fits the list is handled per pass (the whole grid for 640x480).
+    unsigned short* s_ring = reinterpret_cast<unsigned short*>(s_chunk);     // kChunk * 10 * 8 / 2 = 1280 entries
+    constexpr int kBandRows = sizeof(MaskT) == 4 ? 32 : 16;                  // band rows x grid width <= 1024 entries
     for (int pi = 0; pi < nSeg; ++pi)
     {
-        SegRec A;
-        seg_load(s_seg + pi * kSegDoubles, A);
         const int mlabel = s_mlab[pi];
+        const double* segp = s_seg + pi * kSegDoubles;
         uint32_t isOutput = 0, bOff = (uint32_t)nBoundary, bCnt = 0;
-        double onx = 0, ony = 0, onz = 0;
-        double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (mlabel == pi && A.planar != 0.0)
+        if (mlabel == pi && segp[19] != 0.0)
         {
+            const double Anx = segp[10], Any = segp[11], Anz = segp[12], Ad = segp[13], Amse = segp[17];
             // label set of the merge group: j >= pi with planeMergeLabels[j] == pi
-            unsigned long long group = 0;
-            for (int j = pi; j < nSeg; ++j)
-                if (s_mlab[j] == mlabel)
-                    group |= 1ull << j;
-            // lane r builds row r of the mask
+            const unsigned long long group = __ballot(lane >= pi && myMlab == mlabel);
+            // row masks by ballot: the lanes take the cells of one grid row (two rows for grids up to 32 wide)
             MaskT M = 0;
-            if (lane < VC)
+            if (sizeof(MaskT) == 4)
             {
-                for (int c = 0; c < HC; ++c)
+                const int h = lane >> 5, col = lane & 31;
+                for (int t = 0; 2 * t < VC; ++t)
                 {
-                    const int l = s_lab[lane * HC + c];
-                    if (l > 0 && ((group >> (l - 1)) & 1ull))
-                        M |= (MaskT)1 << c;
+                    const int r = 2 * t + h;
+                    const bool in = col < HC && r < VC;
+                    const int l = in ? (int)s_lab[r * HC + col] : 0;
+                    const unsigned long long bm = __ballot(l > 0 && ((group >> (l - 1)) & 1ull));
+                    if (lane == 2 * t)
+                        M = (MaskT)(uint32_t)bm;
+                    if (lane == 2 * t + 1)
+                        M = (MaskT)(uint32_t)(bm >> 32);
+                }
+            }
+            else
+            {
+                for (int r = 0; r < VC; ++r)
+                {
+                    const int l = lane < HC ? (int)s_lab[r * HC + lane] : 0;
+                    const unsigned long long bm = __ballot(l > 0 && ((group >> (l - 1)) & 1ull));
+                    if (lane == r)
+                        M = (MaskT)bm;
                 }
             }
             const MaskT Mup = Rows<MaskT>::up(M, lane), Mdn = Rows<MaskT>::dn(M, lane, VC);
@@ -849,53 +931,66 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
             const MaskT dil = row3<MaskT>(M, widthMask) | row3<MaskT>(Mup, widthMask) | row3<MaskT>(Mdn, widthMask);
             const MaskT ring = dil & ~ero;
 
-            const double maxBoundaryDistance = 3 * sqrt(A.mse);
-            for (int r = 0; r < VC; ++r)
+            const double maxBoundaryDistance = 3 * sqrt(Amse);
+            for (int r0 = 0; r0 < VC; r0 += kBandRows)
             {
-                const MaskT ringRow = shfl_mask<MaskT>(ring, r);
-                if (ringRow == 0)
+                // ring cells of rows [r0, r0 + kBandRows) in row-major order -> s_ring
+                const bool mine = lane >= r0 && lane < r0 + kBandRows && lane < VC;
+                const MaskT rr = mine ? ring : (MaskT)0;
+                const int cnt = popc<MaskT>(rr);
+                const int incl = wave_scan_i32(cnt);
+                const int R = (int)readlane_u32((unsigned)incl, 63);
+                if (R == 0)
                     continue;
-                const double browCenter = __shfl(browCenterOfLane, r); // p.brow[r * kCell + kCell / 2] without a memory round trip per row
-                bool hit = false;
-                double px = 0, py = 0, pz = 0;
-                if (lane < HC && ((ringRow >> lane) & (MaskT)1))
                 {
-                    const double dpt = (double)s_zc[r * HC + lane]; // depthImage(centerY, centerX), staged by stage A
-                    if (dpt > 0)
+                    int pos = incl - cnt;
+                    MaskT m = rr;
+                    while (m)
                     {
-                        px = dpt * acolCenter;
-                        py = dpt * browCenter;
+                        const int c = ctz<MaskT>(m);
+                        s_ring[pos++] = (unsigned short)(lane * HC + c);
+                        m &= m - 1;
+                    }
+                }
+                CAPE_LDS_SYNC();
+                for (int j0 = 0; j0 < R; j0 += 64)
+                {
+                    const int j = j0 + lane;
+                    bool hit = false;
+                    double px = 0, py = 0, pz = 0;
+                    // every lane takes part in the two lane look-ups (a permute reads nothing from an inactive lane)
+                    const int cell = s_ring[j < R ? j : R - 1];
+                    const int r = cell / HC, c = cell - r * HC;
+                    const double ac = __shfl(acolCenterOfLane, c), br = __shfl(browCenterOfLane, r);
+                    const double dpt = (double)s_zc[cell]; // depthImage(centerY, centerX), staged by stage A
+                    if (j < R && dpt > 0)
+                    {
+                        px = dpt * ac;
+                        py = dpt * br;
                         pz = dpt;
-                        const double dist = dot3(A.nx, A.ny, A.nz, px, py, pz) + A.d;
+                        const double dist = dot3(Anx, Any, Anz, px, py, pz) + Ad;
                         hit = fabs(dist) < maxBoundaryDistance;
                     }
-                }
-                const unsigned long long hb = __ballot(hit);
-                if (hit)
-                {
-                    const int pos = nBoundary + __popcll(hb & ((1ull << lane) - 1ull));
-                    if (pos < p.boundaryCapacity)
+                    const unsigned long long hb = __ballot(hit);
+                    if (hit)
                     {
-                        bnd[(size_t)pos * 3 + 0] = px;
-                        bnd[(size_t)pos * 3 + 1] = py;
-                        bnd[(size_t)pos * 3 + 2] = pz;
+                        const int pos = nBoundary + __popcll(hb & ((1ull << lane) - 1ull));
+                        if (pos < p.boundaryCapacity)
+                        {
+                            bnd[(size_t)pos * 3 + 0] = px;
+                            bnd[(size_t)pos * 3 + 1] = py;
+                            bnd[(size_t)pos * 3 + 2] = pz;
+                        }
                     }
+                    nBoundary += __popcll(hb);
+                    bCnt += (uint32_t)__popcll(hb);
                 }
-                nBoundary += __popcll(hb);
-                bCnt += (uint32_t)__popcll(hb);
+                CAPE_LDS_SYNC();
             }
             if (nBoundary > p.boundaryCapacity)
-            {
                 status |= CAPE_FRAME_BOUNDARY_OVERFLOW;
-            }
             if (bCnt >= 3)
-            {
                 isOutput = 1;
-                ++nPlanesOut;
-                onx = A.nx; ony = A.ny; onz = A.nz;
-                normalize3(onx, ony, onz); // Plane::_parametrization(planeSeg.get_normal(), d), shape_primitives.cpp:49
-                inverse3_sym(A.S, cov);
-            }
             else
             {
                 // rejected plane: its candidate points are dropped (reference: `continue` before emplace_back)
@@ -903,28 +998,47 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                 bCnt = 0;
             }
         }
-        if (lane == 0)
+        if (lane == pi)
         {
-            cape_plane_segment* o = &rec->segments[pi];
-            o->normal[0] = A.nx; o->normal[1] = A.ny; o->normal[2] = A.nz;
-            o->d = A.d;
-            o->centroid[0] = A.cx; o->centroid[1] = A.cy; o->centroid[2] = A.cz;
-            o->mse = A.mse;
-            o->score = A.score;
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                o->sums[k] = A.S[k];
-            o->out_normal[0] = onx; o->out_normal[1] = ony; o->out_normal[2] = onz;
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                o->cov[k] = cov[k];
-            o->point_count = (uint32_t)A.n;
-            o->merge_label = (uint32_t)mlabel;
-            o->planar = A.planar != 0.0 ? 1u : 0u;
-            o->is_output = isOutput;
-            o->boundary_offset = bOff;
-            o->boundary_count = bCnt;
+            myOut = isOutput;
+            myOff = bOff;
+            myCnt = bCnt;
         }
+    }
+    const int nPlanesOut = __popcll(__ballot(myOut != 0));
+    // the records of all segments at once, lane j <- segment j: Plane::_parametrization's extra normalisation
+    // (shape_primitives.cpp:49) and get_point_cloud_covariance (plane_segment.cpp:192-203) run lane parallel
+    if (lane < nSeg)
+    {
+        SegRec A;
+        seg_load(s_seg + lane * kSegDoubles, A);
+        double onx = 0, ony = 0, onz = 0;
+        double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (myOut)
+        {
+            onx = A.nx; ony = A.ny; onz = A.nz;
+            normalize3(onx, ony, onz);
+            inverse3_sym(A.S, cov);
+        }
+        cape_plane_segment* o = &rec->segments[lane];
+        o->normal[0] = A.nx; o->normal[1] = A.ny; o->normal[2] = A.nz;
+        o->d = A.d;
+        o->centroid[0] = A.cx; o->centroid[1] = A.cy; o->centroid[2] = A.cz;
+        o->mse = A.mse;
+        o->score = A.score;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            o->sums[k] = A.S[k];
+        o->out_normal[0] = onx; o->out_normal[1] = ony; o->out_normal[2] = onz;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            o->cov[k] = cov[k];
+        o->point_count = (uint32_t)A.n;
+        o->merge_label = (uint32_t)myMlab;
+        o->planar = A.planar != 0.0 ? 1u : 0u;
+        o->is_output = myOut;
+        o->boundary_offset = myOff;
+        o->boundary_count = myCnt;
     }
 
     CAPE_B_STOP(5);
@@ -993,16 +1107,17 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes)
 {
     size_t b = 0;
-    b += (size_t)maxPlanes * kSegDoubles * 8; // s_seg
+    b += (size_t)(maxPlanes + 1) * kSegDoubles * 8; // s_seg (+ one spare slot for the record window)
     b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk
-    b += (size_t)maxPlanes * 8;               // s_adj
+    b += (size_t)(maxPlanes + 1) * 8;               // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins  } after the seed loop these two hold s_zc
     b += (size_t)cells * 2;                         // s_list  }
     b += (size_t)cells;                             // s_lab
     b += maxPlanes;                           // s_mlab
     if (cylinders)
-        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 128; // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
+        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 128 // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
+             + 16 * kSegDoubles * 8;                                                                // s_pendCyl
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots; // s_prof
 #endif

@@ -1,0 +1,106 @@
+// Cross-lane primitives of the one-wavefront-per-frame kernels, on the DPP data path of gfx950.
+//
+// __shfl_xor / __shfl_up compile to ds_bpermute_b32: a round trip through the LDS crossbar (~70 cycles, and the grow
+// wave is latency bound: a 6-step butterfly on a 64-bit key was ~850 cycles of pure waiting, several times per seed).
+// DPP operands move data between lanes inside the VALU (a v_mov with a lane pattern, ~8 cycles): quad permutes and row
+// mirrors reduce 16 lanes in four steps, v_readlane joins the four rows; row_shr + row_bcast give the inclusive scan;
+// wave_shr / wave_shl shift the whole wave by one lane (GFX9 DPP controls, present on gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cape {
+
+constexpr int kDppQuadXor1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowShr = 0x110;       // + n
+constexpr int kDppRowBcast15 = 0x142;
+constexpr int kDppRowBcast31 = 0x143;
+constexpr int kDppWaveShl1 = 0x130;     // lane i <- lane i + 1
+constexpr int kDppWaveShr1 = 0x138;     // lane i <- lane i - 1
+
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    const unsigned lo = dpp_u32<CTRL>((unsigned)v), hi = dpp_u32<CTRL>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// after the four steps every lane of a 16-lane row holds the row's reduction
+#define CAPE_ROW_REDUCE(T, DPP, OP)                 \
+    {                                               \
+        T w_;                                       \
+        w_ = DPP<kDppQuadXor1>(v);                  \
+        v = OP(v, w_);                              \
+        w_ = DPP<kDppQuadXor2>(v);                  \
+        v = OP(v, w_);                              \
+        w_ = DPP<kDppRowHalfMirror>(v);             \
+        v = OP(v, w_);                              \
+        w_ = DPP<kDppRowMirror>(v);                 \
+        v = OP(v, w_);                              \
+    }
+
+__device__ __forceinline__ unsigned op_max_u32(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned op_or_u32(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned op_add_u32(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned long long op_min_u64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+
+__device__ __forceinline__ unsigned readlane_u32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    return ((unsigned long long)readlane_u32((unsigned)(v >> 32), l) << 32) | readlane_u32((unsigned)v, l);
+}
+
+// wave-wide reductions; the result is uniform (it comes out of v_readlane, i.e. it lives in scalar registers)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    CAPE_ROW_REDUCE(unsigned, dpp_u32, op_max_u32)
+    return op_max_u32(op_max_u32(readlane_u32(v, 0), readlane_u32(v, 16)), op_max_u32(readlane_u32(v, 32), readlane_u32(v, 48)));
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+    CAPE_ROW_REDUCE(unsigned, dpp_u32, op_or_u32)
+    return (readlane_u32(v, 0) | readlane_u32(v, 16)) | (readlane_u32(v, 32) | readlane_u32(v, 48));
+}
+__device__ __forceinline__ int wave_sum_i32(int vi)
+{
+    unsigned v = (unsigned)vi;
+    CAPE_ROW_REDUCE(unsigned, dpp_u32, op_add_u32)
+    return (int)((readlane_u32(v, 0) + readlane_u32(v, 16)) + (readlane_u32(v, 32) + readlane_u32(v, 48)));
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    CAPE_ROW_REDUCE(unsigned long long, dpp_u64, op_min_u64)
+    return op_min_u64(op_min_u64(readlane_u64(v, 0), readlane_u64(v, 16)), op_min_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
+}
+
+// inclusive prefix sum over the 64 lanes: Kogge-Stone inside each row of 16 (row_shr shifts zeros in), then the row
+// totals travel down with row_bcast:15 (rows 1 and 3 take lane 15 of the row before) and row_bcast:31 (rows 2 and 3)
+__device__ __forceinline__ int wave_scan_i32(int vi)
+{
+    int v = vi;
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 2, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 4, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 8, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast31, 0xC, 0xF, false);
+    return v;
+}
+
+// the value of the lane below / above (zero past the ends of the wave)
+__device__ __forceinline__ unsigned wave_from_lane_below(unsigned v) { return dpp_u32<kDppWaveShr1>(v); }       // lane i <- i - 1
+__device__ __forceinline__ unsigned wave_from_lane_above(unsigned v) { return dpp_u32<kDppWaveShl1>(v); }       // lane i <- i + 1
+__device__ __forceinline__ unsigned long long wave_from_lane_below(unsigned long long v) { return dpp_u64<kDppWaveShr1>(v); }
+__device__ __forceinline__ unsigned long long wave_from_lane_above(unsigned long long v) { return dpp_u64<kDppWaveShl1>(v); }
+__device__ __forceinline__ double wave_from_lane_below(double v)
+{
+    return __longlong_as_double((long long)dpp_u64<kDppWaveShr1>((unsigned long long)__double_as_longlong(v)));
+}
+
+} // namespace cape
