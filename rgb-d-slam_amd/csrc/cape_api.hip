@@ -17,6 +17,7 @@ namespace cape {
 // every launcher returns the error of its own launch(es) (hipGetLastError right behind hipLaunchKernelGGL)
 hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
+int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
@@ -367,6 +368,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
     cape::StageBParams bb = b;
+    bb.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, frames);
     if (bb.needCylinder)
     {
         // Cost model, in rounds of the cylinder kernel (one round = cylSlots resident frames, ~0.25 ms at 640x480):
@@ -598,6 +600,11 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     a.cell_mse = h->cellMse;
     // primitive_detection.cpp:189-190 ; parameters.hpp:75 maximumPlaneAngleForMerge_d = 18.0f
     a.sinMerge = sinf(static_cast<float>(18.0f * M_PI / 180.0));
+    a.cosMergeA = std::cos(static_cast<double>(18.0f) * M_PI / 180.0); // plane_segment.cpp:324
+    {
+        hipDeviceProp_t prop;
+        a.smallBatchFrames = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
     // plane_segment.hpp:33-34 ; parameters.hpp:72 minimumZeroDepthProportion = 0.7f
     a.minZeroPointCount = static_cast<int>(std::floor(static_cast<float>(400) * 0.7f));
 
@@ -770,6 +777,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
             CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
+            b.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, f1 - f0);
             CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));

@@ -408,141 +408,191 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
 #ifndef CAPE_A2_WAVES
 #define CAPE_A2_WAVES 4
 #endif
-__global__ __launch_bounds__(256, CAPE_A2_WAVES) void cape_cell_plane_kernel(StageAParams p, int nFrames)
+// A workgroup owns a TILE of whole cell rows of one frame (THREADS cells at most, one lane per cell).  After the fit every
+// cell publishes its plane (normal, d, centroid, merge tolerance) in LDS, and each lane evaluates region_growing's merge
+// predicate for the directed edges to its left and upper neighbours -- the planes are still in registers here, whereas
+// the grow kernel had to read all of them back (64 B per cell, a dozen exposed memory round trips per frame) to do the
+// same.  Tiles are independent workgroups: the edges between the first row of a tile and the row above it (another
+// workgroup's) are left to the grow kernel, which evaluates just those rows (2 of 23 row boundaries at 640x480).
+// THREADS = 256 is the throughput instance (as many resident waves as before); THREADS = 1024 takes a 640x480 frame in a
+// single tile and is launched for small batches, where the latency of one frame is what matters.
+struct CellPub
 {
-    const size_t gcell = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gcell >= (size_t)nFrames * p.cells)
-        return;
-    const int frame = (int)(gcell / p.cells);
-    const int cell = (int)(gcell - (size_t)frame * p.cells);
-    const int cellRow = cell / p.hCells;
-    const int cellCol = cell - cellRow * p.hCells;
+    double nx, ny, nz, d, cx, cy, cz, tol;
+};
 
-    const CellAux aux = p.cell_aux[gcell];
-    uint32_t n = aux.flags & kCountMask;
-    const bool continuous = (aux.flags & kAuxContinuous) != 0;
-    const bool exact_ok = (aux.flags & kAuxExact) != 0;
-
-    double* os = p.cell_sums + gcell * kSumStride;
-    double S[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-        S[k] = os[k];
-
-    uint32_t inorder = 0;
-    bool rewrite = false;
-    if (!exact_ok && continuous && n >= (uint32_t)(kPts / 2))
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void cape_cell_plane_kernel(StageAParams p, int nFrames)
+{
+    __shared__ CellPub s_pub[THREADS];
+    const int HC = p.hCells, VC = p.vCells;
+    const int rowsPerTile = THREADS / HC > 0 ? THREADS / HC : 1;
+    const int tilesPerFrame = (VC + rowsPerTile - 1) / rowsPerTile;
+    const int frame = blockIdx.x / tilesPerFrame;
+    const int r0 = (blockIdx.x - frame * tilesPerFrame) * rowsPerTile;
+    const int tid = threadIdx.x;
+    const int tileCells = rowsPerTile * HC;
+    const int lrow = tid / HC, cellCol = tid - lrow * HC;
     {
-        // in-order path: the reference's pixel order (plane_segment.cpp:131-152)
-        inorder = 1;
-        rewrite = true;
-        const size_t cellOff = (size_t)frame * p.W * p.H + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
-        PxAcc A;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            A.S[k] = 0.0;
-        A.n = 0;
-        A.zmin = 0;
-        A.zmax = 0;
-        for (int r = 0; r < kCell; ++r)
+        const int cellRow = r0 + lrow;
+        const bool valid = tid < tileCells && cellRow < VC;
+        const int cell = cellRow * HC + cellCol;
+        const size_t gcell = (size_t)frame * p.cells + (valid ? cell : 0);
+
+        PlaneFit f;
+        f.planar = false;
+        f.nx = f.ny = f.nz = f.d = 0.0;
+        f.cx = f.cy = f.cz = 0.0;
+        f.mse = kDblMax;
+        f.score = 0.0;
+        bool planar = false;
+        float tol = 0.0f;
+        int bin = -1;
+        uint32_t nearEdge = 0, inorder = 0, n = 0;
+        if (valid)
         {
-            const double b = p.brow[cellRow * kCell + r];
-            for (int c = 0; c < kCell; ++c)
+            const CellAux aux = p.cell_aux[gcell];
+            n = aux.flags & kCountMask;
+            const bool continuous = (aux.flags & kAuxContinuous) != 0;
+            const bool exact_ok = (aux.flags & kAuxExact) != 0;
+
+            double* os = p.cell_sums + gcell * kSumStride;
+            double S[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                S[k] = os[k];
+
+            bool rewrite = false;
+            if (!exact_ok && continuous && n >= (uint32_t)(kPts / 2))
             {
-                const size_t o = cellOff + (size_t)r * p.W + c;
-                const float zr = p.depth ? p.depth[o] : (float)p.depth_u16[o] * p.u16_scale;
-                acc_px(zr, p.acol[cellCol * kCell + c], b, A);
+                // in-order path: the reference's pixel order (plane_segment.cpp:131-152)
+                inorder = 1;
+                rewrite = true;
+                const size_t cellOff = (size_t)frame * p.W * p.H + (size_t)(cellRow * kCell) * p.W + cellCol * kCell;
+                PxAcc A;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    A.S[k] = 0.0;
+                A.n = 0;
+                A.zmin = 0;
+                A.zmax = 0;
+                for (int r = 0; r < kCell; ++r)
+                {
+                    const double b = p.brow[cellRow * kCell + r];
+                    for (int c = 0; c < kCell; ++c)
+                    {
+                        const size_t o = cellOff + (size_t)r * p.W + c;
+                        const float zr = p.depth ? p.depth[o] : (float)p.depth_u16[o] * p.u16_scale;
+                        acc_px(zr, p.acol[cellCol * kCell + c], b, A);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    S[k] = A.S[k];
+                n = A.n;
+            }
+
+            if (!continuous || n < (uint32_t)(kPts / 2))
+            {
+                // plane_segment.cpp:114-123: returns right after clear_plane_parameters()
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    S[k] = 0.0;
+                n = 0;
+                rewrite = true;
+            }
+            else if (n >= (uint32_t)p.minZeroPointCount)
+            {
+                fit_plane(S, n, f);
+                const double qz = depth_quantization(f.cz);
+                planar = f.mse <= qz * qz; // plane_segment.cpp:167
+            }
+            if (rewrite)
+            {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    os[k] = S[k];
+                os[9] = (double)n;
+            }
+
+            // _cellDistanceTols (primitive_detection.cpp:201-220): first and last cloud rows of the cell (zeros if invalid)
+            if (planar)
+            {
+                const float z0 = aux.z0, z1 = aux.z399;
+                const int u0 = cellCol * kCell, v0 = cellRow * kCell;
+                float x0 = 0, y0 = 0, zz0 = 0, x1 = 0, y1 = 0, zz1 = 0;
+                if (z0 > 0)
+                {
+                    x0 = (float)((double)z0 * p.acol[u0]);
+                    y0 = (float)((double)z0 * p.brow[v0]);
+                    zz0 = z0;
+                }
+                if (z1 > 0)
+                {
+                    x1 = (float)((double)z1 * p.acol[u0 + kCell - 1]);
+                    y1 = (float)((double)z1 * p.brow[v0 + kCell - 1]);
+                    zz1 = z1;
+                }
+                const float dx = x1 - x0, dy = y1 - y0, dz = zz1 - zz0;
+                const float diam = sqrtf(dx * dx + (dy * dy + dz * dz));
+                tol = std_minf(50.0f, diam * p.sinMerge * sqrtf((float)n));
+
+                // init_histogram (primitive_detection.cpp:253-254) + Histogram::init_histogram (histogram.hpp:48-54)
+                const double theta = acos(-f.nz);
+                const double phi = atan2(f.nx, f.ny);
+                constexpr double kPi = 3.14159265358979323846;
+                const double tx = 19.0 * (theta - 0.0) / kPi;
+                const int xQ = (int)floor(tx);
+                int yQ = 0;
+                double ty = 0.5;
+                if (xQ > 0)
+                {
+                    ty = 19.0 * (phi - (-kPi)) / (kPi - (-kPi));
+                    yQ = (int)floor(ty);
+                }
+                bin = yQ * 20 + xQ;
+                // libm tie guard: ocml vs glibc acos/atan2 may differ in the last ulp
+                if (fabs(tx - rint(tx)) < 1e-9 || (xQ > 0 && fabs(ty - rint(ty)) < 1e-9))
+                    nearEdge = 1;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            S[k] = A.S[k];
-        n = A.n;
-    }
 
-    PlaneFit f;
-    f.planar = false;
-    f.nx = f.ny = f.nz = f.d = 0.0;
-    f.cx = f.cy = f.cz = 0.0;
-    f.mse = kDblMax;
-    f.score = 0.0;
-    bool planar = false;
-    if (!continuous || n < (uint32_t)(kPts / 2))
-    {
-        // plane_segment.cpp:114-123: returns right after clear_plane_parameters()
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            S[k] = 0.0;
-        n = 0;
-        rewrite = true;
-    }
-    else if (n >= (uint32_t)p.minZeroPointCount)
-    {
-        fit_plane(S, n, f);
-        const double qz = depth_quantization(f.cz);
-        planar = f.mse <= qz * qz; // plane_segment.cpp:167
-    }
-    if (rewrite)
-    {
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            os[k] = S[k];
-        os[9] = (double)n;
-    }
-
-    // _cellDistanceTols (primitive_detection.cpp:201-220): first and last cloud rows of the cell (zeros if invalid)
-    float tol = 0.0f;
-    int bin = -1;
-    uint32_t nearEdge = 0;
-    if (planar)
-    {
-        const float z0 = aux.z0, z1 = aux.z399;
-        const int u0 = cellCol * kCell, v0 = cellRow * kCell;
-        float x0 = 0, y0 = 0, zz0 = 0, x1 = 0, y1 = 0, zz1 = 0;
-        if (z0 > 0)
+        // ---- publish, then the merge predicate of the directed edges to the left and upper neighbours
+        CellPub me;
+        me.nx = f.nx; me.ny = f.ny; me.nz = f.nz; me.d = f.d;
+        me.cx = f.cx; me.cy = f.cy; me.cz = f.cz; me.tol = (double)tol;
+        s_pub[tid] = me;
+        __syncthreads();
+        uint32_t edges = 0;
+        if (valid)
         {
-            x0 = (float)((double)z0 * p.acol[u0]);
-            y0 = (float)((double)z0 * p.brow[v0]);
-            zz0 = z0;
+            if (cellCol > 0)
+            {
+                const CellPub L = s_pub[tid - 1];
+                if (can_be_merged(L.nx, L.ny, L.nz, L.d, me.nx, me.ny, me.nz, me.cx, me.cy, me.cz, me.tol, p.cosMergeA))
+                    edges |= kFlagLeftToMe;
+                if (can_be_merged(me.nx, me.ny, me.nz, me.d, L.nx, L.ny, L.nz, L.cx, L.cy, L.cz, L.tol, p.cosMergeA))
+                    edges |= kFlagMeToLeft;
+            }
+            if (lrow > 0) // the tile's first row: its upper neighbours belong to another workgroup (see above)
+            {
+                const CellPub Up = s_pub[tid - HC];
+                if (can_be_merged(Up.nx, Up.ny, Up.nz, Up.d, me.nx, me.ny, me.nz, me.cx, me.cy, me.cz, me.tol, p.cosMergeA))
+                    edges |= kFlagUpToMe;
+                if (can_be_merged(me.nx, me.ny, me.nz, me.d, Up.nx, Up.ny, Up.nz, Up.cx, Up.cy, Up.cz, Up.tol, p.cosMergeA))
+                    edges |= kFlagMeToUp;
+            }
+            double* op = p.cell_plane + gcell * kPlaneStride;
+            op[0] = f.nx; op[1] = f.ny; op[2] = f.nz; op[3] = f.d;
+            op[4] = f.cx; op[5] = f.cy; op[6] = f.cz; op[7] = f.mse;
+            p.cell_mse[gcell] = f.mse;
+            p.cell_score[gcell] = f.score;
+            p.cell_tol[gcell] = tol;
+            p.cell_bins[gcell] = bin;
+            p.cell_flags[gcell] = (n & kCountMask) | edges | (nearEdge ? kFlagNearEdge : 0u) | (inorder ? kFlagInorder : 0u) |
+                                  (planar ? kFlagPlanar : 0u);
         }
-        if (z1 > 0)
-        {
-            x1 = (float)((double)z1 * p.acol[u0 + kCell - 1]);
-            y1 = (float)((double)z1 * p.brow[v0 + kCell - 1]);
-            zz1 = z1;
-        }
-        const float dx = x1 - x0, dy = y1 - y0, dz = zz1 - zz0;
-        const float diam = sqrtf(dx * dx + (dy * dy + dz * dz));
-        tol = std_minf(50.0f, diam * p.sinMerge * sqrtf((float)n));
-
-        // init_histogram (primitive_detection.cpp:253-254) + Histogram::init_histogram (histogram.hpp:48-54)
-        const double theta = acos(-f.nz);
-        const double phi = atan2(f.nx, f.ny);
-        constexpr double kPi = 3.14159265358979323846;
-        const double tx = 19.0 * (theta - 0.0) / kPi;
-        const int xQ = (int)floor(tx);
-        int yQ = 0;
-        double ty = 0.5;
-        if (xQ > 0)
-        {
-            ty = 19.0 * (phi - (-kPi)) / (kPi - (-kPi));
-            yQ = (int)floor(ty);
-        }
-        bin = yQ * 20 + xQ;
-        // libm tie guard: ocml vs glibc acos/atan2 may differ in the last ulp
-        if (fabs(tx - rint(tx)) < 1e-9 || (xQ > 0 && fabs(ty - rint(ty)) < 1e-9))
-            nearEdge = 1;
     }
-
-    double* op = p.cell_plane + gcell * kPlaneStride;
-    op[0] = f.nx; op[1] = f.ny; op[2] = f.nz; op[3] = f.d;
-    op[4] = f.cx; op[5] = f.cy; op[6] = f.cz; op[7] = f.mse;
-    p.cell_mse[gcell] = f.mse;
-    p.cell_score[gcell] = f.score;
-    p.cell_tol[gcell] = tol;
-    p.cell_bins[gcell] = bin;
-    p.cell_flags[gcell] = (n & kCountMask) | (nearEdge ? kFlagNearEdge : 0u) | (inorder ? kFlagInorder : 0u) |
-                          (planar ? kFlagPlanar : 0u);
 }
 
 // every launch helper reports its own failure: hipGetLastError() right behind the launch (a later runtime call would
@@ -557,10 +607,26 @@ hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t s
     return hipGetLastError();
 }
 
+int cell_plane_threads(const StageAParams& p, int nFrames) { return nFrames <= p.smallBatchFrames ? 1024 : 256; }
+// cell rows per workgroup of stage A2 = rows whose vertical edge predicates it evaluates itself (the grow kernel does
+// the rows r = k * rowsPerTile, k >= 1)
+int cell_plane_rows_per_tile(const StageAParams& p, int nFrames)
+{
+    const int t = cell_plane_threads(p, nFrames) / p.hCells;
+    return t > 0 ? t : 1;
+}
+
 hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream)
 {
-    const size_t cellsTotal = (size_t)nFrames * p.cells;
-    hipLaunchKernelGGL(cape_cell_plane_kernel, dim3((unsigned)((cellsTotal + 255) / 256)), dim3(256), 0, stream, p, nFrames);
+    // a few frames: one wide workgroup per frame (a 640x480 grid is one tile: the fits of all its cells run at once);
+    // a batch: 256-thread workgroups, four resident per CU, each walking its frame tile by tile
+    const int threads = cell_plane_threads(p, nFrames);
+    const int rowsPerTile = cell_plane_rows_per_tile(p, nFrames);
+    const int tiles = (p.vCells + rowsPerTile - 1) / rowsPerTile;
+    if (threads == 1024)
+        hipLaunchKernelGGL(cape_cell_plane_kernel<1024>, dim3(nFrames * tiles), dim3(1024), 0, stream, p, nFrames);
+    else
+        hipLaunchKernelGGL(cape_cell_plane_kernel<256>, dim3(nFrames * tiles), dim3(256), 0, stream, p, nFrames);
     return hipGetLastError();
 }
 

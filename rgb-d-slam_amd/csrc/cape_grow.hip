@@ -241,175 +241,152 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     MaskT U = 0, EL = 0, ER = 0, EU = 0, ED = 0; // bit rows, lane r <- grid row r (filled below)
 
     // =========================================================================================
-    // init_histogram (primitive_detection.cpp:239-265, histogram.hpp:35-62)
+    // init_histogram (primitive_detection.cpp:239-265, histogram.hpp:35-62) and the bit rows of the cell grid, lane r <- row r:
+    // the unassigned mask and the four directed edge masks of region_growing's merge predicate (primitive_detection.cpp:802
+    // with plane_segment.cpp:322-326), which stage A2 evaluated per cell and left in cell_flags:
+    //   EL bit c : parent (r,c-1) -> child (r,c)      ER bit c : parent (r,c+1) -> child (r,c)
+    //   EU bit c : parent (r-1,c) -> child (r,c)      ED bit c : parent (r+1,c) -> child (r,c)
+    // One pass over flags + bins; the lanes take one grid row per ballot (two rows for grids up to 32 wide), and a batch of
+    // steps is requested before the first is used, so the whole prologue costs about one memory round trip.
     // =========================================================================================
     int nPlanarLocal = 0;
-    for (int i = lane; i < C; i += 64)
     {
-        const uint32_t fl = p.cell_flags[cellBase + i];
-        s_lab[i] = 0;
-        if (CYL)
-            s_cyl[i] = 0;
-        const int bin = p.cell_bins[cellBase + i]; // computed by stage A2 (acos / atan2 of the cell normal)
-        if (fl & kFlagPlanar)
+        constexpr bool kTwoRows = sizeof(MaskT) == 4;
+        const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
+        const bool colIn = col < HC;
+        const int steps = kTwoRows ? (VC + 1) / 2 : VC;
+        constexpr int kAhead = 12; // steps requested together (the 640x480 grid is 12 steps)
+        for (int t0 = 0; t0 < steps; t0 += kAhead)
         {
-            atomicAdd(&s_hist[bin], 1);
-            ++nPlanarLocal;
+            uint32_t fl[kAhead];
+            int bn[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+            {
+                const int r = kTwoRows ? 2 * (t0 + k) + h : (t0 + k);
+                const int ci = (r < VC ? r : VC - 1) * HC + (colIn ? col : 0); // clamped: unconditional loads
+                fl[k] = p.cell_flags[cellBase + ci];
+                bn[k] = p.cell_bins[cellBase + ci];
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+            {
+                const int t = t0 + k;
+                if (t < steps)
+                {
+                    const int r = kTwoRows ? 2 * t + h : t;
+                    const bool in = colIn && r < VC;
+                    const uint32_t f = in ? fl[k] : 0u;
+                    if (in)
+                    {
+                        const int ci = r * HC + col;
+                        s_lab[ci] = 0;
+                        if (CYL)
+                            s_cyl[ci] = 0;
+                        s_bins[ci] = (short)bn[k];
+                        if (f & kFlagPlanar)
+                        {
+                            atomicAdd(&s_hist[bn[k]], 1);
+                            ++nPlanarLocal;
+                        }
+                    }
+                    if (f & kFlagNearEdge)
+                        status |= CAPE_FRAME_BIN_NEAR_EDGE;
+                    if (f & kFlagInorder)
+                        status |= CAPE_FRAME_INORDER_CELLS;
+                    const unsigned long long bU = __ballot((f & kFlagPlanar) != 0);
+                    const unsigned long long bL2M = __ballot((f & kFlagLeftToMe) != 0);
+                    const unsigned long long bM2L = __ballot((f & kFlagMeToLeft) != 0);
+                    const unsigned long long bU2M = __ballot((f & kFlagUpToMe) != 0);
+                    const unsigned long long bM2U = __ballot((f & kFlagMeToUp) != 0);
+                    if (kTwoRows)
+                    {
+                        // low words: row 2t, high words: row 2t + 1 ; lane q keeps row q's masks (rows past the grid give zeros)
+                        if (lane == 2 * t)
+                        {
+                            U = (MaskT)(uint32_t)bU;
+                            EL = (MaskT)(uint32_t)bL2M;
+                            ER = (MaskT)((uint32_t)bM2L >> 1);
+                            EU = (MaskT)(uint32_t)bU2M;
+                            ED = (MaskT)(uint32_t)(bM2U >> 32); // parent row 2t + 1 -> child row 2t
+                        }
+                        if (lane == 2 * t + 1)
+                        {
+                            U = (MaskT)(uint32_t)(bU >> 32);
+                            EL = (MaskT)(uint32_t)(bL2M >> 32);
+                            ER = (MaskT)((uint32_t)(bM2L >> 32) >> 1);
+                            EU = (MaskT)(uint32_t)(bU2M >> 32);
+                        }
+                        if (lane == 2 * t - 1)
+                            ED = (MaskT)(uint32_t)bM2U; // parent row 2t -> child row 2t - 1
+                    }
+                    else
+                    {
+                        if (lane == t)
+                        {
+                            U = (MaskT)bU;
+                            EL = (MaskT)bL2M;
+                            ER = (MaskT)(bM2L >> 1);
+                            EU = (MaskT)bU2M;
+                        }
+                        if (lane == t - 1)
+                            ED = (MaskT)bM2U;
+                    }
+                }
+            }
         }
-        s_bins[i] = (short)bin;
-        if (fl & kFlagNearEdge)
-            status |= CAPE_FRAME_BIN_NEAR_EDGE;
-        if (fl & kFlagInorder)
-            status |= CAPE_FRAME_INORDER_CELLS;
+    }
+    // the vertical edges between the first cell row of a stage-A2 tile and the row above it (rows k * a2RowsPerTile):
+    // both rows' planes are read back and the predicate is evaluated here, exactly as stage A2 does inside a tile
+    {
+        constexpr bool kTwoRows = sizeof(MaskT) == 4;
+        const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
+        const bool colIn = col < HC;
+        const int RPT = p.a2RowsPerTile;
+        const int nB = (VC - 1) / RPT; // boundaries at rows RPT, 2 RPT, ... < VC
+        for (int s0 = 0; s0 < nB; s0 += (kTwoRows ? 2 : 1))
+        {
+            const int k = s0 + h + 1;
+            const int r = k * RPT;
+            const bool on = colIn && k <= nB;
+            const int rr = (k <= nB ? r : RPT);
+            const size_t ciMe = cellBase + (size_t)rr * HC + (colIn ? col : 0), ciUp = ciMe - HC;
+            const double2* pm = reinterpret_cast<const double2*>(p.cell_plane + ciMe * kPlaneStride);
+            const double2* pu = reinterpret_cast<const double2*>(p.cell_plane + ciUp * kPlaneStride);
+            const double2 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
+            const double2 u0 = pu[0], u1 = pu[1], u2 = pu[2], u3 = pu[3];
+            const double mtol = (double)p.cell_tol[ciMe], utol = (double)p.cell_tol[ciUp];
+            const bool u2m = on & can_be_merged(u0.x, u0.y, u1.x, u1.y, m0.x, m0.y, m1.x, m2.x, m2.y, m3.x, mtol, p.cosMerge);
+            const bool m2u = on & can_be_merged(m0.x, m0.y, m1.x, m1.y, u0.x, u0.y, u1.x, u2.x, u2.y, u3.x, utol, p.cosMerge);
+            const unsigned long long bU2M = __ballot(u2m), bM2U = __ballot(m2u);
+            if (kTwoRows)
+            {
+                const int ra = (s0 + 1) * RPT, rb = (s0 + 2) * RPT; // boundary rows of the even / odd half
+                if (lane == ra)
+                    EU = (MaskT)(uint32_t)bU2M;
+                if (lane == ra - 1)
+                    ED = (MaskT)(uint32_t)bM2U;
+                if (s0 + 2 <= nB)
+                {
+                    if (lane == rb)
+                        EU = (MaskT)(uint32_t)(bU2M >> 32);
+                    if (lane == rb - 1)
+                        ED = (MaskT)(uint32_t)(bM2U >> 32);
+                }
+            }
+            else
+            {
+                if (lane == r)
+                    EU = (MaskT)bU2M;
+                if (lane == r - 1)
+                    ED = (MaskT)bM2U;
+            }
+        }
     }
     const int nPlanar = wave_sum_i32(nPlanarLocal);
     CAPE_WAVE_SYNC();
     CAPE_B_STOP(1);
     CAPE_TICK(0);
-
-    // =========================================================================================
-    // bit rows: unassigned mask and the four directed edge masks (region_growing's predicate,
-    // primitive_detection.cpp:802 with plane_segment.cpp:322-326), lane r <- row r
-    //   EL bit c : parent (r,c-1) -> child (r,c)      ER bit c : parent (r,c+1) -> child (r,c)
-    //   EU bit c : parent (r-1,c) -> child (r,c)      ED bit c : parent (r+1,c) -> child (r,c)
-    // =========================================================================================
-    if (HC <= 32)
-    {
-        // Grids up to 32 cells wide: the two halves of the wave take two rows per step (lane = 32 * (row & 1) + column),
-        // which halves both the arithmetic and the number of exposed memory round trips.  The row above comes from the
-        // other half: row 2t for the odd half (same step), row 2t - 1 for the even half (the odd half's previous step).
-        const int h = lane >> 5, col = lane & 31;
-        const bool in = col < HC;
-        double pnx = 0, pny = 0, pnz = 0, pd = 0, pcx = 0, pcy = 0, pcz = 0, ptol = 0; // this lane's previous step
-        struct RowRec
-        {
-            double2 v0, v1, v2, v3; // (nx ny) (nz d) (cx cy) (cz mse)
-            float tol;
-            uint32_t fl;
-        };
-        // unconditional (row clamped): three steps are kept in flight, and a load behind a branch would make the
-        // wait-count insertion drain all of them (see cape_staged.h)
-        auto fetch_row = [&](RowRec& q, int t) {
-            const int r = 2 * t + h;
-            const int ci = (r < VC ? r : VC - 1) * HC + (in ? col : 0);
-            const double2* pl = reinterpret_cast<const double2*>(p.cell_plane + (cellBase + ci) * kPlaneStride);
-            q.v0 = pl[0];
-            q.v1 = pl[1];
-            q.v2 = pl[2];
-            q.v3 = pl[3];
-            q.tol = p.cell_tol[cellBase + ci];
-            q.fl = p.cell_flags[cellBase + ci];
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto step = [&](const RowRec& q, int t) {
-            const int r = 2 * t + h;
-            const bool rowIn = in && r < VC;
-            const double nx = q.v0.x, ny = q.v0.y, nz = q.v1.x, d = q.v1.y, cx = q.v2.x, cy = q.v2.y, cz = q.v3.x;
-            const double tol = (double)q.tol;
-            const bool planar = rowIn && (q.fl & kFlagPlanar);
-            // left neighbour (lane - 1, same half)
-            const double lnx = __shfl_up(nx, 1), lny = __shfl_up(ny, 1), lnz = __shfl_up(nz, 1), ld = __shfl_up(d, 1);
-            const double lcx = __shfl_up(cx, 1), lcy = __shfl_up(cy, 1), lcz = __shfl_up(cz, 1), ltol = __shfl_up(tol, 1);
-            const bool hasL = rowIn && col > 0;
-            const bool l2m = hasL & can_be_merged(lnx, lny, lnz, ld, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
-            const bool m2l = hasL & can_be_merged(nx, ny, nz, d, lnx, lny, lnz, lcx, lcy, lcz, ltol, p.cosMerge);
-            // row above: the even half sends this step's values, the odd half last step's
-            const int other = lane ^ 32;
-            const double unx = __shfl(h ? pnx : nx, other), uny = __shfl(h ? pny : ny, other), unz = __shfl(h ? pnz : nz, other);
-            const double ud = __shfl(h ? pd : d, other);
-            const double ucx = __shfl(h ? pcx : cx, other), ucy = __shfl(h ? pcy : cy, other), ucz = __shfl(h ? pcz : cz, other);
-            const double utol = __shfl(h ? ptol : tol, other);
-            const bool hasU = rowIn && r > 0;
-            const bool u2m = hasU & can_be_merged(unx, uny, unz, ud, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
-            const bool m2u = hasU & can_be_merged(nx, ny, nz, d, unx, uny, unz, ucx, ucy, ucz, utol, p.cosMerge);
-            const unsigned long long bU = __ballot(planar);
-            const unsigned long long bL2M = __ballot(l2m);
-            const unsigned long long bM2L = __ballot(m2l);
-            const unsigned long long bU2M = __ballot(u2m);
-            const unsigned long long bM2U = __ballot(m2u);
-            // low words: row 2t, high words: row 2t + 1 ; lane q keeps row q's masks (rows past the grid give zeros)
-            if (lane == 2 * t)
-            {
-                U = (MaskT)(uint32_t)bU;
-                EL = (MaskT)(uint32_t)bL2M;
-                ER = (MaskT)((uint32_t)bM2L >> 1);
-                EU = (MaskT)(uint32_t)bU2M;
-                ED = (MaskT)(uint32_t)(bM2U >> 32); // parent row 2t + 1 -> child row 2t, evaluated by the odd half
-            }
-            if (lane == 2 * t + 1)
-            {
-                U = (MaskT)(uint32_t)(bU >> 32);
-                EL = (MaskT)(uint32_t)(bL2M >> 32);
-                ER = (MaskT)((uint32_t)(bM2L >> 32) >> 1);
-                EU = (MaskT)(uint32_t)(bU2M >> 32);
-            }
-            if (lane == 2 * t - 1)
-                ED = (MaskT)(uint32_t)bM2U;
-            pnx = nx; pny = ny; pnz = nz; pd = d; pcx = cx; pcy = cy; pcz = cz; ptol = tol;
-        };
-        RowRec q0, q1, q2;
-        fetch_row(q0, 0);
-        fetch_row(q1, 1);
-        fetch_row(q2, 2);
-        for (int t = 0; 2 * t < VC; t += 3)
-        {
-            step(q0, t);
-            fetch_row(q0, t + 3);
-            step(q1, t + 1);
-            fetch_row(q1, t + 4);
-            step(q2, t + 2);
-            fetch_row(q2, t + 5);
-        }
-    }
-    else
-    {
-        double unx = 0, uny = 0, unz = 0, ud = 0, ucx = 0, ucy = 0, ucz = 0, utol = 0; // row above, same column
-        const bool in = lane < HC;
-        // row r+1 is fetched while row r is evaluated (the records sit in L2 / HBM: ~2k cycles per dependent load)
-        double qnx, qny, qnz, qd, qcx, qcy, qcz;
-        float qtol;
-        uint32_t qfl;
-        auto fetch_row = [&](int r) {
-            const int ci = r * HC + (in ? lane : 0);
-            const double* pl = p.cell_plane + (cellBase + ci) * kPlaneStride;
-            qnx = pl[0]; qny = pl[1]; qnz = pl[2]; qd = pl[3]; qcx = pl[4]; qcy = pl[5]; qcz = pl[6];
-            qtol = p.cell_tol[cellBase + ci];
-            qfl = p.cell_flags[cellBase + ci];
-        };
-        fetch_row(0);
-        for (int r = 0; r < VC; ++r)
-        {
-            const double nx = qnx, ny = qny, nz = qnz, d = qd, cx = qcx, cy = qcy, cz = qcz;
-            const double tol = (double)qtol;
-            const bool planar = in && (qfl & kFlagPlanar);
-            if (r + 1 < VC)
-                fetch_row(r + 1);
-            // left neighbour (lane - 1)
-            const double lnx = __shfl_up(nx, 1), lny = __shfl_up(ny, 1), lnz = __shfl_up(nz, 1), ld = __shfl_up(d, 1);
-            const double lcx = __shfl_up(cx, 1), lcy = __shfl_up(cy, 1), lcz = __shfl_up(cz, 1), ltol = __shfl_up(tol, 1);
-            const bool hasL = in && lane > 0;
-            const bool l2m = hasL && can_be_merged(lnx, lny, lnz, ld, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
-            const bool m2l = hasL && can_be_merged(nx, ny, nz, d, lnx, lny, lnz, lcx, lcy, lcz, ltol, p.cosMerge);
-            const bool hasU = in && r > 0;
-            const bool u2m = hasU && can_be_merged(unx, uny, unz, ud, nx, ny, nz, cx, cy, cz, tol, p.cosMerge);
-            const bool m2u = hasU && can_be_merged(nx, ny, nz, d, unx, uny, unz, ucx, ucy, ucz, utol, p.cosMerge);
-            const unsigned long long bU = __ballot(planar);
-            const unsigned long long bL2M = __ballot(l2m);
-            const unsigned long long bM2L = __ballot(m2l);
-            const unsigned long long bU2M = __ballot(u2m);
-            const unsigned long long bM2U = __ballot(m2u);
-            if (lane == r)
-            {
-                U = (MaskT)bU;
-                EL = (MaskT)bL2M;
-                ER = (MaskT)(bM2L >> 1);
-                EU = (MaskT)bU2M;
-            }
-            if (lane == r - 1)
-                ED = (MaskT)bM2U;
-            unx = nx; uny = ny; unz = nz; ud = d; ucx = cx; ucy = cy; ucz = cz; utol = tol;
-        }
-    }
 
     CAPE_B_STOP(2);
     CAPE_TICK(1);

@@ -12,7 +12,7 @@ namespace cape {
 //   cell_plane [cells][8]  f64 : nx ny nz d cx cy cz mse                               -- 64 B/cell
 //   cell_score [cells]     f64
 //   cell_tol   [cells]     f32 : _cellDistanceTols
-//   cell_flags [cells]     u32 : point count | near-edge << 29 | inorder << 30 | planar << 31
+//   cell_flags [cells]     u32 : point count | four directed-edge merge predicates << 24 | near-edge << 29 | inorder << 30 | planar << 31
 //   cell_bins  [cells]     i32 : histogram bin (-1 if not planar)
 //   cell_aux   [cells]   16 B  : A1 -> A2 hand-over (corner depths, count, continuity / exactness verdicts) + centre depth
 //   cell_mse   [cells]     f64 : copy of the cell MSE, compact so the seed selection reads it coalesced
@@ -24,7 +24,13 @@ constexpr int kPlaneStride = 8;
 constexpr uint32_t kFlagPlanar = 1u << 31;
 constexpr uint32_t kFlagInorder = 1u << 30;
 constexpr uint32_t kFlagNearEdge = 1u << 29;
-constexpr uint32_t kCountMask = (1u << 28) - 1;
+constexpr uint32_t kCountMask = (1u << 24) - 1;
+// region_growing's merge predicate (primitive_detection.cpp:802 with plane_segment.cpp:322-326) of the four directed cell
+// edges that end or start at this cell, evaluated by stage A2 where the cell planes are still in registers:
+constexpr uint32_t kFlagLeftToMe = 1u << 24; // parent (r, c-1) -> child (r, c), child's tolerance   = EL bit c of row r
+constexpr uint32_t kFlagMeToLeft = 1u << 25; // parent (r, c) -> child (r, c-1), left cell's tolerance = ER bit c-1 of row r
+constexpr uint32_t kFlagUpToMe = 1u << 26;   // parent (r-1, c) -> child (r, c)                        = EU bit c of row r
+constexpr uint32_t kFlagMeToUp = 1u << 27;   // parent (r, c) -> child (r-1, c)                        = ED bit c of row r-1
 constexpr uint32_t kAuxContinuous = 1u << 31;
 constexpr uint32_t kAuxExact = 1u << 30;
 
@@ -57,6 +63,8 @@ struct StageAParams
     CellAux* cell_aux;
     double* cell_mse;
     float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
+    double cosMergeA; // cos(18 * pi / 180), plane_segment.cpp:324 (the edge predicates of stage A2)
+    int smallBatchFrames; // host side: batches up to this many frames run the latency-oriented kernel instances
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
 };
 
@@ -93,6 +101,7 @@ struct StageBParams
     uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
+    int a2RowsPerTile;       // cell rows per workgroup of stage A2: the vertical edges into rows k * a2RowsPerTile are evaluated here
     uint16_t* seed_sequence; // [frames][cells] seed cells in the order the seed loop tried them (first n_seeds entries valid)
     int ldsLimitBytes;       // host side only: LDS one workgroup may ask for on the handle's device (queried at cape_create)
 };
