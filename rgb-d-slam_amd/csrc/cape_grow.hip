@@ -389,7 +389,6 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     CAPE_TICK(0);
 
     CAPE_B_STOP(2);
-    CAPE_TICK(1);
     // =========================================================================================
     // grow_planes_and_cylinders (primitive_detection.cpp:267-310)
     // =========================================================================================
@@ -451,6 +450,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                     break;
                 }
                 const int bin = 0xFFFF - (int)(key & 0xFFFFu);
+                CAPE_TICK(1); // histogram arg-max
 
                 // ---- candidates = cells with _bins == bin ; seed = first strict minimum of MSE (:285-298)
                 int candLocal = 0;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                         }
                     }
                 }
-                CAPE_TICK(2); // histogram arg-max + candidate scan
+                CAPE_TICK(2); // candidate scan
                 const int cand = wave_sum_i32(candLocal);
                 if (cand < p.planeSeedCount || cand == 0)
                 {
