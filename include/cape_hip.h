@@ -350,6 +350,22 @@ int cape_gather_wait(cape_handle h, void* stream, int32_t host_sync);
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
                       int32_t* cyl_labels, double* boundary);
 
+/* Handles created with max_batch <= 8 (the reference's call pattern: one frame per call) keep records, label grids and
+ * boundary points in pinned, device-mapped HOST memory: the kernels write them over PCIe directly and no device-to-host
+ * copy exists on the latency path.  cape_host_results waits for the handle's stream and returns pointers to that memory
+ * (valid until the next call / destroy); CAPE_ERR_UNSUPPORTED for larger handles, whose results live in HBM. */
+int cape_host_results(cape_handle h, const cape_frame_record** records, const int32_t** plane_labels,
+                      const int32_t** cyl_labels, const double** boundary);
+
+/* Pinned, device-mapped host memory for depth frames (hipHostMalloc / hipHostRegister on the handle's device).  When
+ * cape_extract_host is given such a buffer, batches of up to 8 frames are read by the streaming kernel straight from host
+ * memory (the image is read exactly once: the PCIe transfer is the kernel's input stream, no staging copy); larger
+ * batches take one DMA.  A registered range must stay allocated until it is unregistered. */
+int cape_host_alloc(cape_handle h, uint64_t bytes, void** out);
+int cape_host_free(cape_handle h, void* p);
+int cape_host_register(cape_handle h, void* p, uint64_t bytes);
+int cape_host_unregister(cape_handle h, void* p);
+
 /* Debug / parity: per-cell stats of one frame of the last batch (synchronous). */
 int cape_copy_cell_stats(cape_handle h, int32_t frame, cape_cell_stats* cells_out);
 

@@ -1,30 +1,26 @@
 #!/usr/bin/env python3
-"""Latency of the drop-in call pattern: ONE host frame in, primitives out (cape_extract_host + cape_copy_results), the
-way rgbd_slam.cpp:291-297 calls find_primitives.  Host-side wall clock, PCIe both ways included."""
+"""Latency of the drop-in call pattern: ONE host frame in, primitives out, the way rgbd_slam.cpp:291-297 calls
+find_primitives.  The measurement itself is C++ (profiles/single_frame_latency.cpp -> rgb-d-slam_amd/lib/latency_bench.exe);
+this script renders the frames and runs it per scene.  usage: single_frame_latency.py > profiles/rNN_single_frame_latency.txt"""
 import os
+import subprocess
 import sys
-import time
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rgb-d-slam_amd", "python"))
 import numpy as np
-from cape_amd import Extractor, synth
+from cape_amd import synth
 
-for scene, cyl in (("room", False), ("room", True), ("tumlike", True), ("tunnel", True)):
+exe = os.path.join(ROOT, "rgb-d-slam_amd", "lib", "latency_bench.exe")
+for scene, cyl in (("room", 0), ("room", 1), ("tumlike", 1), ("tunnel", 1)):
     intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
-    frames = [np.ascontiguousarray(getattr(synth, scene)(seed=7, frame=f)) for f in range(16)]
-    ex = Extractor(640, 480, cylinders=cyl, max_batch=1, **intr)
-    for f in frames[:4]:
-        ex.extract_host(f[None])
-        ex.results(1)
-    ts = []
-    for rep in range(20):
-        for f in frames:
-            t0 = time.perf_counter()
-            ex.extract_host(f[None])
-            ex.results(1)
-            ts.append(time.perf_counter() - t0)
-    ts = np.array(ts) * 1e6
-    print(f"{scene:8s} cylinders={int(cyl)}  single-frame latency: median {np.median(ts):7.1f} us  p90 {np.percentile(ts, 90):7.1f} us"
-          f"  => {1e6 / np.median(ts):7.0f} frames/s one at a time")
-    ex.close()
+    frames = np.stack([getattr(synth, scene)(seed=7, frame=f) for f in range(16)])
+    with tempfile.NamedTemporaryFile(suffix=".f32") as tf:
+        frames.tofile(tf.name)
+        print(f"== {scene}, cylinders={cyl} (abi rows; the overlay always runs the cylinder branch)", flush=True)
+        out = subprocess.run([exe, tf.name, str(len(frames)), "640", "480", str(intr["fx"]), str(intr["fy"]), str(intr["cx"]),
+                              str(intr["cy"]), str(cyl)], capture_output=True, text=True)
+        print(out.stdout, end="")
+        if out.returncode:
+            print("FAILED", out.returncode, out.stderr[-500:])

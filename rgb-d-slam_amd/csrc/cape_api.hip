@@ -51,6 +51,7 @@ int fail(int code, const std::string& msg)
             return fail(CAPE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                    \
     } while (0)
 
+constexpr int kHostResultFrames = 8; // see cape_handle_s::resultsOnHost
 constexpr int kRngTable = 40000; // upper bound on RANSAC draws per frame (cylinder section)
 
 // Every entry point that allocates, copies, launches or synchronises runs with the HANDLE's device current, whatever
@@ -135,6 +136,10 @@ struct cape_handle_s
     int32_t* planeLabels = nullptr;
     int32_t* cylLabels = nullptr;
     double* boundary = nullptr;
+    // handles for a few frames at a time (max_batch <= kHostResultFrames) keep records / label grids / boundary points in
+    // pinned, device-mapped HOST memory: the grow kernel's stores go straight over PCIe (posted writes), and reading the
+    // results is a stream synchronisation + a host memcpy instead of three device-to-host copies
+    bool resultsOnHost = false;
     // host staging for cape_extract_host
     float* depthStage = nullptr;
     // timing: one event triple per timed cape_extract, folded lazily by cape_get_timings
@@ -229,10 +234,20 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cellAux);
     (void)hipFree(h->cellMse);
     (void)hipFree(h->seedSeq);
-    (void)hipFree(h->records);
-    (void)hipFree(h->planeLabels);
-    (void)hipFree(h->cylLabels);
-    (void)hipFree(h->boundary);
+    if (h->resultsOnHost)
+    {
+        (void)hipHostFree(h->records);
+        (void)hipHostFree(h->planeLabels);
+        (void)hipHostFree(h->cylLabels);
+        (void)hipHostFree(h->boundary);
+    }
+    else
+    {
+        (void)hipFree(h->records);
+        (void)hipFree(h->planeLabels);
+        (void)hipFree(h->cylLabels);
+        (void)hipFree(h->boundary);
+    }
     (void)hipFree(h->depthStage);
     if (h->comm)
         (void)cape::rccl_comm_destroy(h->comm);
@@ -364,11 +379,15 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     CAPE_HIP_TRY(cape::launch_cell_moments(a, frames, st));
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
-    CAPE_HIP_TRY(cape::launch_cell_plane(a, frames, st));
+    cape::StageAParams a2 = a;
+    a2.clear0 = b.redoList;
+    a2.clear1 = b.needCylinder;
+    CAPE_HIP_TRY(cape::launch_cell_plane(a2, frames, st));
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
     cape::StageBParams bb = b;
     bb.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, frames);
+    bb.countersCleared = 1;
     if (bb.needCylinder)
     {
         // Cost model, in rounds of the cylinder kernel (one round = cylSlots resident frames, ~0.25 ms at 640x480):
@@ -519,10 +538,21 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
-    CAPE_ALLOC(dalloc(h->records, B));
-    CAPE_ALLOC(dalloc(h->planeLabels, B * C));
-    CAPE_ALLOC(dalloc(h->cylLabels, B * C));
-    CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
+    h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
+    if (h->resultsOnHost)
+    {
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->records), B * sizeof(cape_frame_record), hipHostMallocMapped));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->planeLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->cylLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), B * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped));
+    }
+    else
+    {
+        CAPE_ALLOC(dalloc(h->records, B));
+        CAPE_ALLOC(dalloc(h->planeLabels, B * C));
+        CAPE_ALLOC(dalloc(h->cylLabels, B * C));
+        CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
+    }
 
     // ---- constant tables
     double k00, k02, k11, k12;
@@ -574,7 +604,10 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(hipMemcpy(h->ratioCol, rc.data(), rc.size() * sizeof(float), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->ratioRow, rr.data(), rr.size() * sizeof(float), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
-    CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
+    if (h->resultsOnHost)
+        std::memset(h->records, 0, B * sizeof(cape_frame_record));
+    else
+        CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
 
     // ---- kernel parameter blocks
     cape::StageAParams& a = h->pa;
@@ -601,10 +634,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     // primitive_detection.cpp:189-190 ; parameters.hpp:75 maximumPlaneAngleForMerge_d = 18.0f
     a.sinMerge = sinf(static_cast<float>(18.0f * M_PI / 180.0));
     a.cosMergeA = std::cos(static_cast<double>(18.0f) * M_PI / 180.0); // plane_segment.cpp:324
-    {
-        hipDeviceProp_t prop;
-        a.smallBatchFrames = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    a.smallBatchFrames = 0; // see cell_plane_threads(); CAPE_A2_WIDE_BATCH=n selects the one-tile instance for batches <= n
+    if (const char* wide = std::getenv("CAPE_A2_WIDE_BATCH"))
+        a.smallBatchFrames = std::atoi(wide);
     // plane_segment.hpp:33-34 ; parameters.hpp:72 minimumZeroDepthProportion = 0.7f
     a.minZeroPointCount = static_cast<int>(std::floor(static_cast<float>(400) * 0.7f));
 
@@ -774,10 +806,13 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
             CAPE_HIP_TRY(hipStreamWaitEvent(h->pipeStream[1], h->pipeStage[i], 0));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e2b, h->pipeStream[1]));
+            a.clear0 = b.redoList;
+            a.clear1 = b.needCylinder;
             CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
             b.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, f1 - f0);
+            b.countersCleared = 1;
             CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));
@@ -803,11 +838,21 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
         return rc;
-    const size_t bytes = (size_t)h->cfg.max_batch * h->cfg.width * h->cfg.height * sizeof(float);
+    // Pinned input (cape_host_alloc / cape_host_register, or any hipHostMalloc'ed / registered buffer): a few frames are
+    // read by the streaming kernel straight from host memory -- the image is read exactly once, so the PCIe transfer IS the
+    // kernel's input stream and no staging copy precedes it; larger batches take one DMA from the pinned pages.  Pageable
+    // input goes through the runtime's staged copy.
+    const size_t frameBytes = (size_t)h->cfg.width * h->cfg.height * sizeof(float);
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, depth_host) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer;
+    if (!pinned)
+        (void)hipGetLastError(); // an unregistered pointer is not an error here
+    if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 16 == 0)
+        return cape_extract(h, static_cast<const float*>(attr.devicePointer), n_frames, stream_);
+    const size_t bytes = (size_t)h->cfg.max_batch * frameBytes;
     if (!h->depthStage)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), bytes));
-    CAPE_HIP_TRY(hipMemcpyAsync(h->depthStage, depth_host, (size_t)n_frames * h->cfg.width * h->cfg.height * sizeof(float),
-                                hipMemcpyHostToDevice, stream));
+    CAPE_HIP_TRY(hipMemcpyAsync(h->depthStage, depth_host, (size_t)n_frames * frameBytes, hipMemcpyHostToDevice, stream));
     return cape_extract(h, h->depthStage, n_frames, stream_);
 }
 
@@ -832,8 +877,25 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
     if (!h || n_frames < 0 || n_frames > h->cfg.max_batch)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
     CAPE_ON_DEVICE(h);
-    CAPE_HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)n_frames, C = (size_t)h->cells;
+    if (h->resultsOnHost)
+    {
+        // the kernels wrote into pinned host memory: once the handle's stream has drained the data is simply there
+        if (h->hasLastStream)
+            CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+        else
+            CAPE_HIP_TRY(hipDeviceSynchronize());
+        if (records)
+            std::memcpy(records, h->records, n * sizeof(cape_frame_record));
+        if (plane_labels)
+            std::memcpy(plane_labels, h->planeLabels, n * C * sizeof(int32_t));
+        if (cyl_labels)
+            std::memcpy(cyl_labels, h->cylLabels, n * C * sizeof(int32_t));
+        if (boundary)
+            std::memcpy(boundary, h->boundary, n * (size_t)h->boundaryCap * 3 * sizeof(double));
+        return CAPE_OK;
+    }
+    CAPE_HIP_TRY(hipDeviceSynchronize());
     if (records)
         CAPE_HIP_TRY(hipMemcpy(records, h->records, n * sizeof(cape_frame_record), hipMemcpyDeviceToHost));
     if (plane_labels)
@@ -842,6 +904,72 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
         CAPE_HIP_TRY(hipMemcpy(cyl_labels, h->cylLabels, n * C * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (boundary)
         CAPE_HIP_TRY(hipMemcpy(boundary, h->boundary, n * (size_t)h->boundaryCap * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return CAPE_OK;
+}
+
+int cape_host_results(cape_handle h, const cape_frame_record** records, const int32_t** plane_labels, const int32_t** cyl_labels,
+                      const double** boundary)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->resultsOnHost)
+        return fail(CAPE_ERR_UNSUPPORTED, "results live in device memory for this handle (max_batch > 8): use cape_copy_results");
+    CAPE_ON_DEVICE(h);
+    if (h->hasLastStream)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    else
+        CAPE_HIP_TRY(hipDeviceSynchronize());
+    if (records)
+        *records = h->records;
+    if (plane_labels)
+        *plane_labels = h->planeLabels;
+    if (cyl_labels)
+        *cyl_labels = h->cylLabels;
+    if (boundary)
+        *boundary = h->boundary;
+    return CAPE_OK;
+}
+
+int cape_host_alloc(cape_handle h, uint64_t bytes, void** out)
+{
+    if (!h || !out || bytes == 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or zero size");
+    CAPE_ON_DEVICE(h);
+    *out = nullptr;
+    CAPE_HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocMapped));
+    return CAPE_OK;
+}
+
+int cape_host_free(cape_handle h, void* p)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!p)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    if (h->hasLastStream)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream)); // a kernel of this handle may still be reading the buffer
+    CAPE_HIP_TRY(hipHostFree(p));
+    return CAPE_OK;
+}
+
+int cape_host_register(cape_handle h, void* p, uint64_t bytes)
+{
+    if (!h || !p || bytes == 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or zero size");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterMapped));
+    return CAPE_OK;
+}
+
+int cape_host_unregister(cape_handle h, void* p)
+{
+    if (!h || !p)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    CAPE_ON_DEVICE(h);
+    if (h->hasLastStream)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    CAPE_HIP_TRY(hipHostUnregister(p));
     return CAPE_OK;
 }
 

@@ -30,6 +30,9 @@ namespace cape {
 #ifndef CAPE_A_GROUP
 #define CAPE_A_GROUP 2   // image rows per prefetch group
 #endif
+#ifndef CAPE_A_DEPTH
+#define CAPE_A_DEPTH 1   // prefetch groups in flight ahead of the arithmetic (1 = the ping-pong loop)
+#endif
 #ifndef CAPE_A_WAVES
 #define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
 #endif
@@ -53,11 +56,14 @@ struct PxAcc
 {
     double S[9];
     uint32_t n;
-    float zmin, zmax;
+    // z range of the valid pixels, as bit patterns (non-negative floats order like unsigned integers): zmaxBits is the
+    // greatest pattern, zminBits1 the smallest (pattern - 1) -- the -1 wraps the +0 of an invalid pixel to 0xFFFFFFFF, the
+    // neutral element of the minimum, with one v_sub_u32 (which issues at twice the rate of the selects it replaces)
+    uint32_t zminBits1, zmaxBits;
 };
 
 // One pixel of plane_segment.cpp:131-152 on top of depth_map_transformation.cpp:123-138.
-__device__ __forceinline__ void acc_px(float zr, double a, double b, PxAcc& A)
+__device__ __forceinline__ float acc_px(float zr, double a, double b, PxAcc& A)
 {
     const bool valid = zr > 0.0f;       // `if (z > 0)` ; NaN is invalid
     const float z = valid ? zr : 0.0f;  // invalid pixels add +0 to every sum
@@ -77,6 +83,7 @@ __device__ __forceinline__ void acc_px(float zr, double a, double b, PxAcc& A)
     A.S[6] += (double)(x * y);
     A.S[7] += (double)(y * z);
     A.S[8] += (double)(x * z);
+    return z; // the clamped depth (+0 if invalid): what the exactness guard looks at
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -89,9 +96,8 @@ __device__ __forceinline__ void acc_px2(float zr0, float zr1, double a0, double 
     const bool v0 = z0 > 0.0f, v1 = z1 > 0.0f;                // == `if (z > 0)` on the raw value
     A.n += (v0 ? 1u : 0u) + (v1 ? 1u : 0u);
     // z range of the valid pixels (exactness guard)
-    const float i0 = v0 ? z0 : __builtin_huge_valf(), i1 = v1 ? z1 : __builtin_huge_valf();
-    A.zmin = fminf(A.zmin, fminf(i0, i1));
-    A.zmax = fmaxf(A.zmax, fmaxf(z0, z1));
+    A.zminBits1 = min(A.zminBits1, min(__float_as_uint(z0) - 1u, __float_as_uint(z1) - 1u));
+    A.zmaxBits = max(A.zmaxBits, max(__float_as_uint(z0), __float_as_uint(z1)));
     const double zd0 = (double)z0, zd1 = (double)z1;
     f32x2 z, x, y;
     z.x = z0;
@@ -127,18 +133,13 @@ __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, do
     acc_px2(v.x, v.y, a0, a1, b, A);
     acc_px2(v.z, v.w, a2, a3, b, A);
 #else
-    acc_px(v.x, a0, b, A);
-    acc_px(v.y, a1, b, A);
-    acc_px(v.z, a2, b, A);
-    acc_px(v.w, a3, b, A);
-    // z range of the valid pixels (exactness guard): invalid -> +inf for the min, 0 for the max
-    const float ix = v.x > 0.0f ? v.x : __builtin_huge_valf();
-    const float iy = v.y > 0.0f ? v.y : __builtin_huge_valf();
-    const float iz = v.z > 0.0f ? v.z : __builtin_huge_valf();
-    const float iw = v.w > 0.0f ? v.w : __builtin_huge_valf();
-    A.zmin = fminf(fminf(A.zmin, ix), fminf(iy, fminf(iz, iw)));
-    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); // fmaxf ignores NaN
-    A.zmax = fmaxf(A.zmax, mx);
+    const uint32_t bx = __float_as_uint(acc_px(v.x, a0, b, A));
+    const uint32_t by = __float_as_uint(acc_px(v.y, a1, b, A));
+    const uint32_t bz = __float_as_uint(acc_px(v.z, a2, b, A));
+    const uint32_t bw = __float_as_uint(acc_px(v.w, a3, b, A));
+    // z range of the valid pixels (exactness guard), on the clamped depths: v_max3_u32 / v_min3_u32 + four v_sub_u32
+    A.zmaxBits = max(max(A.zmaxBits, bx), max(by, max(bz, bw)));
+    A.zminBits1 = min(min(A.zminBits1, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
 #endif
 }
 
@@ -191,7 +192,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         s_cellsum[e] = 0.0;
     if (t < 64)
     {
-        s_zminmax[2 * t] = 0x7F800000u; // +inf
+        s_zminmax[2 * t] = 0xFFFFFFFFu; // neutral element of the (pattern - 1) minimum
         s_zminmax[2 * t + 1] = 0u;
     }
     __syncthreads();
@@ -202,14 +203,16 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     for (int k = 0; k < 9; ++k)
         A.S[k] = 0.0;
     A.n = 0;
-    A.zmin = __builtin_huge_valf();
-    A.zmax = 0.0f;
+    A.zminBits1 = 0xFFFFFFFFu;
+    A.zmaxBits = 0u;
     if (active)
     {
         const double a0 = p.acol[col0], a1 = p.acol[col0 + 1], a2 = p.acol[col0 + 2], a3 = p.acol[col0 + 3];
-        const size_t pixOff = frameOff + (size_t)(cellRow * kCell) * p.W + col0;
-        const float* base = p.depth + pixOff;                 // float32 millimetres
-        const uint16_t* base16 = p.depth_u16 + pixOff;        // raw sensor units (U16 variant)
+        // addresses = one base per FRAME (uniform: it lives in scalar registers and advances row by row with scalar adds)
+        // + one 32-bit element offset per thread (its column inside the frame): no 64-bit vector address arithmetic per load
+        const uint32_t pixOff32 = (uint32_t)(cellRow * kCell) * (uint32_t)p.W + (uint32_t)col0;
+        const float* frameBase = p.depth + frameOff;                 // float32 millimetres
+        const uint16_t* frameBase16 = p.depth_u16 + frameOff;        // raw sensor units (U16 variant)
         const float scale16 = p.u16_scale;
         const double* brow = p.brow + cellRow * kCell;
         const size_t W = (size_t)p.W;
@@ -225,10 +228,11 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
             {
+                const size_t rowOff = (size_t)(kGroup * g + i) * W; // uniform
                 if constexpr (U16)
-                    buf[i] = *reinterpret_cast<const ushort4*>(base16 + (size_t)(kGroup * g + i) * W);
+                    buf[i] = *reinterpret_cast<const ushort4*>((frameBase16 + rowOff) + pixOff32);
                 else
-                    buf[i] = *reinterpret_cast<const float4*>(base + (size_t)(kGroup * g + i) * W);
+                    buf[i] = *reinterpret_cast<const float4*>((frameBase + rowOff) + pixOff32);
             }
         };
         auto to_f4 = [&](const Raw& rw) {
@@ -275,6 +279,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                     s_corner[lcell * 3 + 2] = buf[i].z;
             }
         };
+#if CAPE_A_DEPTH == 1
         load_group(bufA, 0);
 #pragma unroll 1
         for (int g = 0; g < kGroups; g += 2)
@@ -285,6 +290,32 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                 load_group(bufA, g + 2);
             sum_group(bufB, g + 1);
         }
+#else
+        // two groups requested ahead of the one being summed: three register buffers in rotation, three groups per trip of a
+        // ROLLED loop (unrolled, the scheduler hoists every load of the band to the top and the kernel spills).  The kernel
+        // moves ~14 bytes per nanosecond per CU and a load takes a couple of microseconds under that load, so a CU needs ~30 KB
+        // in flight; with one group (2 rows x 16 B per lane) ahead and the ~11 waves a CU holds on average it had 22 KB.
+        Raw bufC[kGroup];
+        load_group(bufA, 0);
+        load_group(bufB, 1);
+        int g = 0;
+#pragma unroll 1
+        for (; g + 2 < kGroups; g += 3)
+        {
+            load_group(bufC, g + 2);
+            sum_group(bufA, g);
+            if (g + 3 < kGroups)
+                load_group(bufA, g + 3);
+            sum_group(bufB, g + 1);
+            if (g + 4 < kGroups)
+                load_group(bufB, g + 4);
+            sum_group(bufC, g + 2);
+        }
+        if (g < kGroups)
+            sum_group(bufA, g);
+        if (g + 1 < kGroups)
+            sum_group(bufB, g + 1);
+#endif
     }
 #if CAPE_A_LDS_ATOMIC
     if (active)
@@ -294,8 +325,8 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         for (int k = 0; k < 9; ++k)
             atomicAdd(dst + k, A.S[k]); // ds_add_f64; exact sums => order-free
         atomicAdd(dst + 9, (double)A.n);
-        atomicMin(&s_zminmax[2 * lcell], __float_as_uint(A.zmin));
-        atomicMax(&s_zminmax[2 * lcell + 1], __float_as_uint(A.zmax));
+        atomicMin(&s_zminmax[2 * lcell], A.zminBits1);
+        atomicMax(&s_zminmax[2 * lcell + 1], A.zmaxBits);
     }
 #else
     {
@@ -304,7 +335,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         for (int k = 0; k < 9; ++k)
             dst[k] = A.S[k];
         dst[9] = (double)A.n;
-        reinterpret_cast<float2*>(dst + 10)[0] = make_float2(A.zmin, A.zmax);
+        reinterpret_cast<uint2*>(dst + 10)[0] = make_uint2(A.zminBits1, A.zmaxBits);
     }
 #endif
     __syncthreads();
@@ -373,23 +404,25 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     }
     // exactness guard: all addends of every sum within 2^20 of each other (see header)
 #if CAPE_A_LDS_ATOMIC
-    const float zmin = __uint_as_float(s_zminmax[2 * t]), zmax = __uint_as_float(s_zminmax[2 * t + 1]);
+    const uint32_t zminBits1 = s_zminmax[2 * t], zmaxBits = s_zminmax[2 * t + 1];
     const uint32_t n = (uint32_t)s_cellsum[t * 10 + 9];
 #else
-    float zmin = __builtin_huge_valf(), zmax = 0.0f;
+    uint32_t zminBits1 = 0xFFFFFFFFu, zmaxBits = 0u;
     uint32_t n = 0;
     {
         const int pbase = fb * kBandThreads + fs * 5;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
         {
-            const float2 zr = reinterpret_cast<const float2*>(s_part + (pbase + k) * kPartStride + 10)[0];
-            zmin = fminf(zmin, zr.x);
-            zmax = fmaxf(zmax, zr.y);
+            const uint2 zr = reinterpret_cast<const uint2*>(s_part + (pbase + k) * kPartStride + 10)[0];
+            zminBits1 = min(zminBits1, zr.x);
+            zmaxBits = max(zmaxBits, zr.y);
             n += (uint32_t)s_part[(pbase + k) * kPartStride + 9];
         }
     }
 #endif
+    // back to depths: with n > 0 at least one pixel was valid, so the minimum is a real pattern - 1
+    const float zmin = __uint_as_float(zminBits1 + 1u), zmax = __uint_as_float(zmaxBits);
     const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);
     const bool exact_ok = (n == 0) || (zmax * rab <= 512.0f * zmin);
 
@@ -425,6 +458,13 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void cape_cell_plane_kernel(StageAParams p, int nFrames)
 {
     __shared__ CellPub s_pub[THREADS];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        if (p.clear0)
+            *p.clear0 = 0u;
+        if (p.clear1)
+            *p.clear1 = 0u;
+    }
     const int HC = p.hCells, VC = p.vCells;
     const int rowsPerTile = THREADS / HC > 0 ? THREADS / HC : 1;
     const int tilesPerFrame = (VC + rowsPerTile - 1) / rowsPerTile;
@@ -474,8 +514,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
                 for (int k = 0; k < 9; ++k)
                     A.S[k] = 0.0;
                 A.n = 0;
-                A.zmin = 0;
-                A.zmax = 0;
+                A.zminBits1 = 0;
+                A.zmaxBits = 0;
                 for (int r = 0; r < kCell; ++r)
                 {
                     const double b = p.brow[cellRow * kCell + r];
@@ -607,6 +647,9 @@ hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t s
     return hipGetLastError();
 }
 
+// The 1024-thread instance (a 640x480 frame in ONE tile, no tile-boundary rows left to the grow kernel) exists for
+// experiments only: its 12 busy waves share the four SIMDs of a single CU and the fits serialise (28 us per frame, measured),
+// while three 256-thread tiles run on three CUs side by side (~9 us).  smallBatchFrames is 0 by default.
 int cell_plane_threads(const StageAParams& p, int nFrames) { return nFrames <= p.smallBatchFrames ? 1024 : 256; }
 // cell rows per workgroup of stage A2 = rows whose vertical edge predicates it evaluates itself (the grow kernel does
 // the rows r = k * rowsPerTile, k >= 1)

@@ -1163,7 +1163,7 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
             return e_;                     \
     } while (0)
     // counters of the two hand-over lists ([0] = count, [1..] = frames)
-    if (p.redoList)
+    if (p.redoList && !p.countersCleared)
         CAPE_LAUNCH_TRY(hipMemsetAsync(p.redoList, 0, sizeof(uint32_t), stream));
     if (!cyl)
     {
@@ -1178,7 +1178,8 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
     }
     else
     {
-        CAPE_LAUNCH_TRY(hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream));
+        if (!p.countersCleared)
+            CAPE_LAUNCH_TRY(hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream));
         CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
         CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream)));
     }

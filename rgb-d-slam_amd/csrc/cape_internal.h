@@ -63,6 +63,8 @@ struct StageAParams
     CellAux* cell_aux;
     double* cell_mse;
     float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
+    uint32_t* clear0; // hand-over counters of the grow kernel (redo list, cylinder list): zeroed by one thread of stage A2, which
+    uint32_t* clear1; // always runs right before it on the same stream -- instead of two memset nodes per call
     double cosMergeA; // cos(18 * pi / 180), plane_segment.cpp:324 (the edge predicates of stage A2)
     int smallBatchFrames; // host side: batches up to this many frames run the latency-oriented kernel instances
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
@@ -101,6 +103,7 @@ struct StageBParams
     uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
+    int countersCleared;     // 1: stage A2 zeroed redoList[0] / needCylinder[0] (StageAParams::clear0/1); 0: launch_grow does
     int a2RowsPerTile;       // cell rows per workgroup of stage A2: the vertical edges into rows k * a2RowsPerTile are evaluated here
     uint16_t* seed_sequence; // [frames][cells] seed cells in the order the seed loop tried them (first n_seeds entries valid)
     int ldsLimitBytes;       // host side only: LDS one workgroup may ask for on the handle's device (queried at cape_create)

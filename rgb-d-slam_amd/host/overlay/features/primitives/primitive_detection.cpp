@@ -25,50 +25,73 @@ Primitive_Detection::Primitive_Detection(const uint width, const uint height) : 
 {
     Plane_Segment::set_static_members(parameters::detection::depthMapPatchSize_px,
                                       parameters::detection::depthMapPatchSize_px * parameters::detection::depthMapPatchSize_px);
-    if (!ensure_shards(1))
+    int devices = 0;
+    if (cape_device_count(&devices) != CAPE_OK || devices <= 0 || !make_shard(_single, 0, 1))
         outputs::log_error(std::string("Primitive_Detection: ") + cape_last_error());
 }
 
 Primitive_Detection::~Primitive_Detection()
 {
+    cape_destroy(_single.handle);
     for (Shard& s : _shards)
         cape_destroy(s.handle);
 }
 
-// shard i lives on device i % device_count; handles are created on demand and kept
+bool Primitive_Detection::make_shard(Shard& s, int device, int maxBatch) noexcept
+{
+    try
+    {
+        if (!Parameters::is_valid())
+            Parameters::load_defaut();
+        cape_config cfg {};
+        cfg.width = static_cast<int32_t>(_width);
+        cfg.height = static_cast<int32_t>(_height);
+        // camera intrinsics are read once, here (the reference caches them in function-local statics,
+        // point_coordinates.cpp:81)
+        cfg.fx = Parameters::get_camera_1_focal().x();
+        cfg.fy = Parameters::get_camera_1_focal().y();
+        cfg.cx = Parameters::get_camera_1_center().x();
+        cfg.cy = Parameters::get_camera_1_center().y();
+        cfg.flags = CAPE_FLAG_CYLINDERS; // the reference always runs the cylinder branch (primitive_detection.cpp:385-388)
+        cfg.device = device;
+        cfg.max_batch = maxBatch;
+        s.device = device;
+        s.maxBatch = maxBatch;
+        if (cape_create(&cfg, &s.handle) != CAPE_OK)
+        {
+            s.handle = nullptr;
+            return false;
+        }
+        cape_layout lay {};
+        cape_get_layout(s.handle, &lay);
+        _cells = lay.cells;
+        _boundaryCapacity = lay.boundary_capacity;
+        if (maxBatch > 8) // results in HBM: the shard keeps host copies
+        {
+            s.recordCopy.resize(maxBatch);
+            s.boundaryCopy.resize(static_cast<size_t>(maxBatch) * _boundaryCapacity * 3);
+        }
+        return true;
+    }
+    catch (const std::exception&)
+    {
+        return false;
+    }
+}
+
+// batch shard i lives on device i % device_count; handles are created on demand and kept
 bool Primitive_Detection::ensure_shards(int wanted) noexcept
 {
     try
     {
         int devices = 0;
         if (cape_device_count(&devices) != CAPE_OK || devices <= 0)
-            return false; // no GPU: this library has no CPU path, the detector stays "not ready"
-        if (!Parameters::is_valid())
-            Parameters::load_defaut();
+            return false; // no GPU: this library has no CPU path
         while (static_cast<int>(_shards.size()) < wanted)
         {
-            cape_config cfg {};
-            cfg.width = static_cast<int32_t>(_width);
-            cfg.height = static_cast<int32_t>(_height);
-            // camera intrinsics are read once, here (the reference caches them in function-local statics,
-            // point_coordinates.cpp:81)
-            cfg.fx = Parameters::get_camera_1_focal().x();
-            cfg.fy = Parameters::get_camera_1_focal().y();
-            cfg.cx = Parameters::get_camera_1_center().x();
-            cfg.cy = Parameters::get_camera_1_center().y();
-            cfg.flags = CAPE_FLAG_CYLINDERS; // the reference always runs the cylinder branch (primitive_detection.cpp:385-388)
-            cfg.device = static_cast<int>(_shards.size()) % devices;
-            cfg.max_batch = _maxBatch;
             Shard s;
-            s.device = cfg.device;
-            if (cape_create(&cfg, &s.handle) != CAPE_OK)
+            if (!make_shard(s, static_cast<int>(_shards.size()) % devices, _maxBatch))
                 return false;
-            cape_layout lay {};
-            cape_get_layout(s.handle, &lay);
-            _cells = lay.cells;
-            _boundaryCapacity = lay.boundary_capacity;
-            s.records.resize(_maxBatch);
-            s.boundary.resize(static_cast<size_t>(_maxBatch) * _boundaryCapacity * 3);
             _shards.push_back(std::move(s));
         }
         return true;
@@ -88,7 +111,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
     if (r.header.status & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
         outputs::log_warning("find_primitives: per-frame capacity exceeded, primitive list truncated");
     planes.reserve(r.header.n_planes);
-    const double* bnd = shard.boundary.data() + static_cast<size_t>(f) * _boundaryCapacity * 3;
+    const double* bnd = shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3;
     std::vector<vector3> orderedBoundary;
     for (int i = 0; i < r.header.n_plane_segments; ++i)
     {
@@ -125,13 +148,18 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
 // one chunk (<= _maxBatch frames) through the C ABI: H2D copy + kernels + D2H of records and boundary points
 bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, int m) const
 {
-    if (cape_extract_host(shard.handle, depth, m, nullptr) != CAPE_OK ||
-        cape_copy_results(shard.handle, m, shard.records.data(), nullptr, nullptr, shard.boundary.data()) != CAPE_OK)
+    bool ok = cape_extract_host(shard.handle, depth, m, nullptr) == CAPE_OK;
+    if (ok && shard.maxBatch <= 8)
+        ok = cape_host_results(shard.handle, &shard.records, nullptr, nullptr, &shard.boundary) == CAPE_OK; // in place
+    else if (ok)
     {
-        shard.error = cape_last_error(); // thread-local in the library: keep it for the caller's thread
-        return false;
+        ok = cape_copy_results(shard.handle, m, shard.recordCopy.data(), nullptr, nullptr, shard.boundaryCopy.data()) == CAPE_OK;
+        shard.records = shard.recordCopy.data();
+        shard.boundary = shard.boundaryCopy.data();
     }
-    return true;
+    if (!ok)
+        shard.error = cape_last_error(); // thread-local in the library: keep it for the caller's thread
+    return ok;
 }
 
 void Primitive_Detection::run_shard(Shard& shard, const float* depth, int firstFrame, int n, std::vector<plane_container>& planes,
@@ -139,9 +167,9 @@ void Primitive_Detection::run_shard(Shard& shard, const float* depth, int firstF
 {
     const size_t frameElems = static_cast<size_t>(_width) * _height;
     ok = true;
-    for (int base = 0; base < n; base += _maxBatch)
+    for (int base = 0; base < n; base += shard.maxBatch)
     {
-        const int m = (n - base < _maxBatch) ? n - base : _maxBatch;
+        const int m = (n - base < shard.maxBatch) ? n - base : shard.maxBatch;
         if (!extract_chunk(shard, depth + static_cast<size_t>(firstFrame + base) * frameElems, m))
         {
             ok = false;
@@ -232,19 +260,19 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
             outputs::log_error("find_primitives: depth image size differs from the configured size");
             return;
         }
-        if (_shards.empty())
+        if (!_single.handle)
         {
             outputs::log_error("find_primitives: no device extractor (cape_create failed); returning no primitives");
             return;
         }
         const depth_image d = depthImage.isContinuous() ? depthImage : depthImage.clone();
         const auto t0 = std::chrono::steady_clock::now();
-        if (!extract_chunk(_shards[0], d.ptr<float>(0), 1))
+        if (!extract_chunk(_single, d.ptr<float>(0), 1))
         {
-            outputs::log_error("find_primitives: " + _shards[0].error);
+            outputs::log_error("find_primitives: " + _single.error);
             return;
         }
-        collect(_shards[0], 0, planeContainer, primitiveContainer); // in place, like emplace_back at primitive_detection.cpp:627
+        collect(_single, 0, planeContainer, primitiveContainer); // in place, like emplace_back at primitive_detection.cpp:627
         _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     catch (const std::exception& e)
@@ -260,7 +288,7 @@ bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame
     {
         matches.clear();
         if (_shards.empty() || n_frames < 0)
-            return false;
+            return false; // the batch handle of shard 0 holds the frames: find_primitives_batch comes first
         const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
                                (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
         matches.resize(n_frames);
@@ -291,10 +319,10 @@ void Primitive_Detection::show_statistics(const double meanFrameTreatmentDuratio
     std::snprintf(buf, sizeof buf, "\tMean primitive extraction time is %.4f seconds (%.2f%%)", mean,
                   percent(mean, meanFrameTreatmentDuration));
     outputs::log(buf);
-    if (shouldDisplayDetails && !_shards.empty())
+    if (shouldDisplayDetails && _single.handle)
     {
         cape_timings t {};
-        if (cape_get_timings(_shards[0].handle, &t) == CAPE_OK && t.calls > 0)
+        if (cape_get_timings(_single.handle, &t) == CAPE_OK && t.calls > 0)
         {
             std::snprintf(buf, sizeof buf, "\t\tMean primitive init time is %.6f seconds, grow+merge+refine %.6f seconds (device, per call)",
                           t.cell_fit_s / t.calls, t.grow_s / t.calls);

@@ -60,17 +60,23 @@ class Primitive_Detection
                            bool useAdvancedSearch = false,
                            bool allowIndexZero = false) noexcept;
 
-    [[nodiscard]] bool is_ready() const noexcept { return !_shards.empty(); }
+    [[nodiscard]] bool is_ready() const noexcept { return _single.handle != nullptr; }
 
   private:
     struct Shard
     {
         cape_handle handle = nullptr;
         int device = 0;
-        std::vector<cape_frame_record> records;
-        std::vector<double> boundary;
+        int maxBatch = 0;
+        // where the last chunk's records / boundary points are: the shard's own copies (batch handles, results in HBM) or
+        // the library's pinned host memory (the one-frame handle: nothing is copied, see cape_host_results)
+        const cape_frame_record* records = nullptr;
+        const double* boundary = nullptr;
+        std::vector<cape_frame_record> recordCopy;
+        std::vector<double> boundaryCopy;
         std::string error;
     };
+    bool make_shard(Shard& s, int device, int maxBatch) noexcept;
     bool ensure_shards(int wanted) noexcept;
     bool extract_chunk(Shard& shard, const float* depth, int m) const;
     void run_shard(Shard& shard,
@@ -86,7 +92,8 @@ class Primitive_Detection
     int _cells = 0, _boundaryCapacity = 0;
     int _maxBatch = 64;
     int _requestedShards = 0;
-    mutable std::vector<Shard> _shards;
+    mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
+    mutable std::vector<Shard> _shards;    // batch shards (max_batch = 64 each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
 
     // remove copy functions, like the reference (primitive_detection.hpp:228-230)

@@ -108,7 +108,8 @@ CELL_STATS_DTYPE = np.dtype([
 EXPORTED_SYMBOLS = [
     "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
-    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_wait", "cape_copy_results", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
+    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_wait", "cape_copy_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
+    "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
 ]
@@ -145,6 +146,11 @@ def load_library():
     L.cape_rectify_depth.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    L.cape_host_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.cape_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.cape_host_free.argtypes = [vp, vp]
+    L.cape_host_register.argtypes = [vp, vp, C.c_uint64]
+    L.cape_host_unregister.argtypes = [vp, vp]
     L.cape_copy_cell_stats.argtypes = [vp, C.c_int32, vp]
     L.cape_enable_timing.argtypes = [vp, C.c_int32]
     L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
@@ -251,6 +257,21 @@ class Extractor:
         _check(self.L, self.L.cape_extract_host(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0], C.c_void_p(stream)),
                "cape_extract_host")
         return d.shape[0]
+
+    def host_alloc(self, shape, dtype=np.float32):
+        """numpy array over pinned, device-mapped host memory (cape_host_alloc); free with host_free(array)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(self.L, self.L.cape_host_alloc(self.h, n, C.byref(p)), "cape_host_alloc")
+        buf = (C.c_ubyte * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        _check(self.L, self.L.cape_host_free(self.h, C.c_void_p(p)), "cape_host_free")
 
     # ---- results -------------------------------------------------------------------------------
     def device_pointers(self):
