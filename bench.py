@@ -279,11 +279,12 @@ def main():
         # algorithmic bytes per launch (DESIGN.md "Measurement"):
         #   A1 cell moments : reads every depth pixel once, writes 96 B per cell (10 f64 sums + 16 B hand-over)
         #   A2 cell plane   : reads those 96 B, writes 88 B per cell (plane, score, tolerance, flags, bin)
-        #   B  grow         : reads 168 B per cell (sums + plane + tol/flags/bin), writes label grids + primitive lists
+        #   B  grow         : reads 112 B per cell (sums 80, flags 4, bin 4, MSE 8, centre-pixel record 16; the cell planes stay
+        #                     in stage A2, which hands over four edge bits per cell), writes label grids + primitive lists
         kernels = {
             "cape_cell_moments_kernel": (a1_ms, fpl * (W * H * (2 if args.u16 else 4) + cells * 96)),
             "cape_cell_plane_kernel": (a2_ms, fpl * (cells * (96 + 88))),
-            "cape_grow_kernel": (b_ms, fpl * (cells * 168 + 2 * cells * 4 + 32 * 128)),
+            "cape_grow_kernel": (b_ms, fpl * (cells * 112 + 2 * cells * 4 + 32 * 128)),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
@@ -339,7 +340,7 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
                 "kernel_ms": {"cape_cell_moments_kernel": a1_ms, "cape_cell_plane_kernel": a2_ms, "cape_grow_kernel": b_ms},
                 "stage_b": {"us_per_frame": 1e3 * b_ms / fpl, "frames_in_flight": ex.grow_frames_per_cu * ex.compute_units,
-                            "note": "one wavefront per frame, latency bound; ~0 HBM bytes beyond the 168 B/cell it reads"},
+                            "note": "one wavefront per frame, latency bound; ~0 HBM bytes beyond the 112 B/cell it reads"},
                 "end_to_end_GBps": frames_total / world * e2e_bytes_per_frame / elapsed / 1e9,
                 "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
             },
