@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     int* s_hist = reinterpret_cast<int*>(s_adj + MAXP + 1);            // 400 i32
     short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
     unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
-    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C);          // C u8  plane labels
+    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C + 4);      // C u8  plane labels (list: 1 pad + C entries, rounded to 8 B)
     unsigned char* s_mlab = s_lab + C;                                            // 32 u8 merge labels
     // cylinder variant only (see grow_lds_bytes)
     unsigned char* s_cyl = s_mlab + MAXP;                              // C u8  cylinder labels
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                 const int rowCnt = popc<MaskT>(act);
                 const int incl = wave_scan_i32(rowCnt);
                 const int total = (int)readlane_u32((unsigned)incl, 63);
-                unsigned short* rlist = s_list + listTop;
+                unsigned short* rlist = s_list + 1 + listTop; // s_list[0] is a pad: the slot before a list parks the seed (below)
                 {
                     int pos = incl - rowCnt;
                     MaskT m = act;
@@ -591,11 +591,21 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                 CAPE_TICK(5); // list build
                 const int ql = lane < 10 ? lane : 0;
                 // element 0 is the seed itself (0.0 + x == x exactly), so its sums travel with the first staged chunk instead of
-                // costing a memory round trip of their own
+                // costing a memory round trip of their own.  The seed id is parked in the list slot just before the region's
+                // cells for the duration of the pass (that slot is the last cell of the previous recorded region, or the pad):
+                // the index function is then one LDS look-up with no branch in front of the loads.
+                const unsigned short parkedOver = rlist[-1];
+                CAPE_LDS_SYNC();
+                if (lane == 0)
+                    rlist[-1] = (unsigned short)seed;
+                CAPE_LDS_SYNC();
                 double acc = 0.0;
                 staged_for_each<5, CAPE_STAGE_DEPTH_MAIN>(
-                        total + 1, sumsBase, kSumStride, 0, [&](int e) { return e == 0 ? seed : (int)rlist[e - 1]; }, s_chunk, lane,
+                        total + 1, sumsBase, kSumStride, 0, [&](int e) { return (int)rlist[e - 1]; }, s_chunk, lane,
                         [&](int, const double* rec) { return rec[ql]; }, [&](int, double v) { acc += v; });
+                if (lane == 0)
+                    rlist[-1] = parkedOver;
+                CAPE_LDS_SYNC();
 
                 CAPE_TICK(6); // ordered accumulation
                 // ---- Histogram::remove_point for every activated cell (histogram.hpp:103-113), _isUnassignedMask = false
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                         seg_store(s_seg + nSeg * kSegDoubles, ns); // at or below the record's own slot (plane-only window)
                     ++nSeg;
                     for (int i = lane; i < total; i += 64)
-                        s_lab[s_list[roff + i]] = (unsigned char)nSeg;
+                        s_lab[s_list[1 + roff + i]] = (unsigned char)nSeg;
                     CAPE_WAVE_SYNC();
                 }
                 else if (!CYL && !kRedo && p.twoPass && total > 5)
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
                     cc.lane = lane;
                     cc.cellBase = cellBase;
                     cc.C = C;
-                    cc.s_list = s_list + roff;
+                    cc.s_list = s_list + 1 + roff;
                     cc.total = total;
                     cc.s_dist = s_dist;
                     cc.s_ids = s_ids;
@@ -1089,7 +1099,7 @@ size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes)
     b += (size_t)(maxPlanes + 1) * 8;               // s_adj
     b += (size_t)kHistBins * 4;                     // s_hist
     b += (size_t)cells * 2;                         // s_bins  } after the seed loop these two hold s_zc
-    b += (size_t)cells * 2;                         // s_list  }
+    b += (size_t)cells * 2 + 8;                     // s_list  } (+ pad entry)
     b += (size_t)cells;                             // s_lab
     b += maxPlanes;                           // s_mlab
     if (cylinders)

@@ -62,11 +62,10 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
     // named registers on purpose: an array captured by the lambda is not promoted out of scratch memory.
     // DEPTH register sets (a, b, c, d) = DEPTH chunks in flight while one more is being consumed from LDS.
 #define CAPE_STAGE_PIECE(q) ((lane + 64 * (q)) < kPiecesPerChunk ? (lane + 64 * (q)) : kPiecesPerChunk - 1)
-#define CAPE_STAGE_LOAD(q, c0_)                                                                                          \
-    *reinterpret_cast<const double2*>(                                                                                   \
-            base + (size_t)index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1) * \
-                           strideDoubles +                                                                               \
-            2 * (firstPiece + CAPE_STAGE_PIECE(q) % PIECES))
+    // the record number of piece q of the chunk that starts at element c0_ (clamped to the last element), and its load
+#define CAPE_STAGE_INDEX(q, c0_) index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1)
+#define CAPE_STAGE_LOAD(q, rec_) \
+    *reinterpret_cast<const double2*>(base + (size_t)(rec_) * strideDoubles + 2 * (firstPiece + CAPE_STAGE_PIECE(q) % PIECES))
 #define CAPE_STAGE_DST(q) \
     *reinterpret_cast<double2*>(s_buf + (CAPE_STAGE_PIECE(q) / PIECES) * 2 * PIECES + 2 * (CAPE_STAGE_PIECE(q) % PIECES))
     double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
@@ -76,20 +75,28 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
     // unconditional (clamped) on purpose, see above; at most two surplus chunks are fetched at the end of a call.
     // The scheduling barriers keep the loads of one set together: the in-order vmcnt counter can only wait for "all
     // but the k youngest", so interleaving the two sets would make every hand-over wait for both.
-#define CAPE_STAGE_ISSUE(S, at_)              \
-    do                                        \
-    {                                         \
-        __builtin_amdgcn_sched_barrier(0);    \
-        S##0 = CAPE_STAGE_LOAD(0, at_);       \
-        if (kPerLane > 1)                     \
-            S##1 = CAPE_STAGE_LOAD(1, at_);   \
-        if (kPerLane > 2)                     \
-            S##2 = CAPE_STAGE_LOAD(2, at_);   \
-        if (kPerLane > 3)                     \
-            S##3 = CAPE_STAGE_LOAD(3, at_);   \
-        if (kPerLane > 4)                     \
-            S##4 = CAPE_STAGE_LOAD(4, at_);   \
-        __builtin_amdgcn_sched_barrier(0);    \
+    // index() usually reads a cell list in LDS: all look-ups of a set are requested before the first address is formed --
+    // written per piece, every load waited for its own LDS round trip (three exposed LDS latencies per chunk)
+#define CAPE_STAGE_ISSUE(S, at_)                                            \
+    do                                                                      \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const int r0_ = CAPE_STAGE_INDEX(0, at_);                           \
+        const int r1_ = kPerLane > 1 ? CAPE_STAGE_INDEX(1, at_) : 0;        \
+        const int r2_ = kPerLane > 2 ? CAPE_STAGE_INDEX(2, at_) : 0;        \
+        const int r3_ = kPerLane > 3 ? CAPE_STAGE_INDEX(3, at_) : 0;        \
+        const int r4_ = kPerLane > 4 ? CAPE_STAGE_INDEX(4, at_) : 0;        \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        S##0 = CAPE_STAGE_LOAD(0, r0_);                                     \
+        if (kPerLane > 1)                                                   \
+            S##1 = CAPE_STAGE_LOAD(1, r1_);                                 \
+        if (kPerLane > 2)                                                   \
+            S##2 = CAPE_STAGE_LOAD(2, r2_);                                 \
+        if (kPerLane > 3)                                                   \
+            S##3 = CAPE_STAGE_LOAD(3, r3_);                                 \
+        if (kPerLane > 4)                                                   \
+            S##4 = CAPE_STAGE_LOAD(4, r4_);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                  \
     } while (0)
 #define CAPE_STAGE_STORE(S)                   \
     do                                        \
@@ -216,6 +223,7 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
 #undef CAPE_STAGE_T
 #undef CAPE_STAGE_PIECE
 #undef CAPE_STAGE_LOAD
+#undef CAPE_STAGE_INDEX
 #undef CAPE_STAGE_DST
 #undef CAPE_STAGE_ISSUE
 #undef CAPE_STAGE_STORE
