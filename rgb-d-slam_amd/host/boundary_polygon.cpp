@@ -44,6 +44,11 @@ inline double cross2(const vector2& o, const vector2& a, const vector2& b)
 // proper or touching intersection of the open segments (a1,a2) and (b1,b2); shared endpoints do not count
 bool segments_intersect(const vector2& a1, const vector2& a2, const vector2& b1, const vector2& b2)
 {
+    // separated bounding boxes cannot cross or touch: settles nearly every pair of a ring's edges with four compares (the
+    // simple-ring test is quadratic in the ring size and ran ~3x per polygon)
+    if (std::max(a1[0], a2[0]) < std::min(b1[0], b2[0]) || std::max(b1[0], b2[0]) < std::min(a1[0], a2[0]) ||
+        std::max(a1[1], a2[1]) < std::min(b1[1], b2[1]) || std::max(b1[1], b2[1]) < std::min(a1[1], a2[1]))
+        return false;
     auto same = [](const vector2& p, const vector2& q) { return p[0] == q[0] && p[1] == q[1]; };
     if (same(a1, b1) || same(a1, b2) || same(a2, b1) || same(a2, b2))
         return false;
@@ -110,12 +115,15 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
     double prevAngle = M_PI; // walking direction so far: pointing west, the first turn is taken clockwise from it
     size_t step = 1;
     size_t remaining = n - 1;
+    std::vector<std::pair<double, size_t>> cand, byTurn; // reused from step to step
+    cand.reserve(n);
+    byTurn.reserve(k);
     while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
     {
         if (step == 4)
             used[first] = 0; // the start point becomes reachable again once the hull has three edges
         // k nearest unused neighbours of the current point
-        std::vector<std::pair<double, size_t>> cand;
+        cand.clear();
         for (size_t i = 0; i < n; ++i)
             if (!used[i] && i != current)
             {
@@ -128,7 +136,7 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
         std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
         cand.resize(kk);
         // order by the largest right-hand turn relative to the previous edge
-        std::vector<std::pair<double, size_t>> byTurn;
+        byTurn.clear();
         for (const auto& c : cand)
         {
             const double ang = std::atan2(pts[c.second][1] - pts[current][1], pts[c.second][0] - pts[current][0]);
