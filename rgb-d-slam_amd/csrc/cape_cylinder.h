@@ -16,6 +16,7 @@
 #include "cape_device.h"
 #include "cape_internal.h"
 #include "cape_staged.h"
+#include "cape_wave.h"
 
 namespace cape {
 
@@ -118,45 +119,46 @@ constexpr int kCylCacheRounds = 12;
         }                                                                                                    \
     }
 
-__device__ __forceinline__ int cyl_wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ int cyl_wave_sum(int v) { return wave_sum_i32(v); }
 
 // init-less ordered sum s[0] + s[1] + ... + s[n-1] (ascending, one rounding per add, like the reference's loops) of
 // NON-NEGATIVE addends parked in LDS.  The running sum of non-negative terms never decreases, so the scan may stop as
-// soon as it reaches `limit`: the caller only needs to know that the total is >= limit then.  Sixteen elements per
-// trip with the next sixteen already requested, so the LDS latency hides behind the dependent adds.  `s` is 16-byte
-// aligned and readable up to s[n + 15].
-__device__ __forceinline__ double ordered_sum_lds(const double* s, int n_, double limit)
+// soon as it reaches `limit`: the caller only needs to know that the total is >= limit then.
+// Each lane fetches ONE element of a block of 64 (a single conflict-free ds_read_b64 per block, the next block already
+// requested) and the chain takes its operands out of that register with v_readlane: two scalar moves per element in the
+// shadow of the dependent add.  Reading every element with a wave-uniform LDS load cost an LDS instruction per two
+// elements, and a wave gets one through only every ~16 cycles (profiles/r02_lds_rates.txt): 28 cycles per element.
+// `s` is readable up to s[n + 63] (the surplus lanes of the last block read whatever is there and add +0.0 instead).
+__device__ __forceinline__ double ordered_sum_lds(const double* s, int n_, double limit, int lane)
 {
     const int n = __builtin_amdgcn_readfirstlane(n_);
     double sum = 0.0;
-    int j = 0;
-    if (n >= 16)
+    double cur = (lane < n) ? s[lane] : 0.0;
+    for (int j0 = 0; j0 < n; j0 += 64)
     {
-        const double2* v = reinterpret_cast<const double2*>(s);
-        double2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
-        for (; j + 16 <= n; j += 16)
+        const int jn = j0 + 64 + lane;
+        const double nxt = (jn < n) ? s[jn] : 0.0; // x + (+0.0) == x for every x >= +0.0
+        __builtin_amdgcn_sched_barrier(0);
+        // the operand of element l + 1 is taken out while the add of element l waits for the one before it: issued right
+        // in front of its own add, the scalar moves (and their way into the VALU) sat on the chain, 26 cycles per element
+        double x = readlane_f64(cur, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
         {
-            // the next sixteen are requested before the sixteen dependent adds (the barrier keeps the scheduler from
-            // sinking the reads next to their uses, which would expose one LDS round trip per pair)
-            const double2* w = v + j / 2 + 8;
-            const double2 b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3], b4 = w[4], b5 = w[5], b6 = w[6], b7 = w[7];
-            __builtin_amdgcn_sched_barrier(0);
-            sum += a0.x; sum += a0.y; sum += a1.x; sum += a1.y; sum += a2.x; sum += a2.y; sum += a3.x; sum += a3.y;
-            sum += a4.x; sum += a4.y; sum += a5.x; sum += a5.y; sum += a6.x; sum += a6.y; sum += a7.x; sum += a7.y;
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 0; l < 16; ++l)
+            {
+                const double xn = readlane_f64(cur, (16 * q + l + 1) & 63); // (the 64th wraps to lane 0 and is not used)
+                __builtin_amdgcn_sched_barrier(0);
+                sum += x;
+                __builtin_amdgcn_sched_barrier(0);
+                x = xn;
+            }
             if (sum >= limit)
                 return sum;
-            a0 = b0, a1 = b1, a2 = b2, a3 = b3, a4 = b4, a5 = b5, a6 = b6, a7 = b7;
         }
+        cur = nxt;
     }
-    for (; j < n; ++j)
-        sum += s[j];
     return sum;
 }
 
@@ -191,8 +193,8 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         }
         cov6 = acc / (double)(2 * N - 1);
     }
-    const double m00 = __shfl(cov6, 0), m10 = __shfl(cov6, 1), m11 = __shfl(cov6, 2);
-    const double m20 = __shfl(cov6, 3), m21 = __shfl(cov6, 4), m22 = __shfl(cov6, 5);
+    const double m00 = readlane_f64(cov6, 0), m10 = readlane_f64(cov6, 1), m11 = readlane_f64(cov6, 2);
+    const double m20 = readlane_f64(cov6, 3), m21 = readlane_f64(cov6, 4), m22 = readlane_f64(cov6, 5);
     Eig3 eg;
     self_adjoint_eigen3(m00, m10, m11, m20, m21, m22, eg);
     const double score = eg.val[2] / eg.val[0];
@@ -361,9 +363,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     }
                 }
                 const int curCount = cyl_wave_sum(curLocal);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                    psum += __shfl_xor(psum, o);
+                psum = wave_sum_f64_tree(psum); // any order will do: psum only feeds the conservative test below
                 double dist = minHyp;
                 if (!(psum * (1.0 - 0x1p-40) >= minHyp))
                 {
@@ -381,7 +381,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                         }
                     }
                     CAPE_CYL_SYNC();
-                    dist = ordered_sum_lds(c.s_dist, m, minHyp);
+                    dist = ordered_sum_lds(c.s_dist, m, minHyp, lane);
                 }
                 bool stop = false;
                 if (dist < minHyp)
@@ -427,9 +427,9 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     chain += inl ? term : 0.0;
                 });
         CAPE_CYL_TICK(16); // LLS ordered pass
-        const double sNx = __shfl(chain, 0), sNy = __shfl(chain, 1), sNz = __shfl(chain, 2);
-        const double sCx = __shfl(chain, 3), sCy = __shfl(chain, 4), sCz = __shfl(chain, 5);
-        double b = __shfl(chain, 6);
+        const double sNx = readlane_f64(chain, 0), sNy = readlane_f64(chain, 1), sNz = readlane_f64(chain, 2);
+        const double sCx = readlane_f64(chain, 3), sCy = readlane_f64(chain, 4), sCz = readlane_f64(chain, 5);
+        double b = readlane_f64(chain, 6);
         // remove the inliers from the remaining ids (:161-179)
         {
             int newCount = 0;
@@ -507,7 +507,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             CAPE_CYL_SYNC();
             CAPE_CYL_TICK(18); // MSE: parallel distances
             // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach: scan all N entries
-            mse = ordered_sum_lds(c.s_dist, N, __builtin_inf());
+            mse = ordered_sum_lds(c.s_dist, N, __builtin_inf(), lane);
             CAPE_CYL_SYNC();
         }
         CAPE_CYL_TICK(19); // MSE: ordered sum
@@ -527,8 +527,8 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         double S[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            S[k] = __shfl(acc, k);
-        const double cnt = __shfl(acc, 9);
+            S[k] = readlane_f64(acc, k);
+        const double cnt = readlane_f64(acc, 9);
         PlaneFit f;
         fit_plane(S, (uint32_t)cnt, f);
         CAPE_CYL_TICK(21); // merged plane fit

@@ -29,6 +29,9 @@ namespace cape {
 constexpr int kHistBins = 400;
 constexpr int kSegDoubles = 20; // LDS plane-segment record: sums[9], n, normal[3], d, centroid[3], mse, score, planar
 constexpr int kChunk = kStageChunk; // cells staged per step of the ordered moment accumulation (cape_staged.h)
+#ifndef CAPE_B_PLANE_WAVES
+#define CAPE_B_PLANE_WAVES 2 // waves per SIMD the plane-only instances are compiled for: 256 registers, nothing spills (3 = 168 registers spills ~50)
+#endif
 #ifndef CAPE_B_WAVES_PER_GROUP
 #define CAPE_B_WAVES_PER_GROUP 4
 #endif
@@ -171,7 +174,7 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
 // LDS; a frame that needs more is handed to the MAXP = CAPE_MAX_PLANES (64) instance through p.redoList, exactly like
 // cylinder-branch frames are handed from the plane-only to the cylinder instance.
 template <typename MaskT, bool CYL, int MAXP>
-__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
+__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63;
@@ -214,7 +217,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : 3) void cape_grow_ke
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
     unsigned char* s_cur = s_idmask + C;                                          // C u8
     unsigned char* s_best = s_cur + C;                                            // C u8
-    double* s_dist = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(s_best + C) + 15) & ~(uintptr_t)15); // C f64 (+ read-ahead pad)
+    // (aligned through the OFFSET, not through an integer cast of the pointer: the cast loses the LDS address space and every
+    // access through s_dist / s_pendCyl becomes a flat_load that waits for vmcnt AND lgkmcnt)
+    double* s_dist = reinterpret_cast<double*>(smem + (((size_t)(s_best + C - smem) + 15) & ~(size_t)15)); // C f64 (+ read-ahead pad)
     double* s_pendCyl = s_dist + C + 16;                                          // 16 region records (cylinder instance)
 #ifdef CAPE_B_PROFILE
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsPerWave - 8 * kProfileSlots);

@@ -79,6 +79,29 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return op_min_u64(op_min_u64(readlane_u64(v, 0), readlane_u64(v, 16)), op_min_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
 }
 
+// sum of the 64 lanes' doubles in TREE order (not the order of any reference loop: only for quantities whose rounding is
+// not observable, e.g. a conservative bound); uniform result
+__device__ __forceinline__ double op_add_f64_bits(unsigned long long a, unsigned long long b)
+{
+    return __longlong_as_double((long long)a) + __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ double wave_sum_f64_tree(double x)
+{
+    unsigned long long v = (unsigned long long)__double_as_longlong(x);
+#define CAPE_F64_STEP(CTRL) v = (unsigned long long)__double_as_longlong(op_add_f64_bits(v, dpp_u64<CTRL>(v)));
+    CAPE_F64_STEP(kDppQuadXor1)
+    CAPE_F64_STEP(kDppQuadXor2)
+    CAPE_F64_STEP(kDppRowHalfMirror)
+    CAPE_F64_STEP(kDppRowMirror)
+#undef CAPE_F64_STEP
+    return (op_add_f64_bits(readlane_u64(v, 0), readlane_u64(v, 16))) + (op_add_f64_bits(readlane_u64(v, 32), readlane_u64(v, 48)));
+}
+// the double held by lane l (l uniform): v_readlane instead of a trip through the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), l));
+}
+
 // inclusive prefix sum over the 64 lanes: Kogge-Stone inside each row of 16 (row_shr shifts zeros in), then the row
 // totals travel down with row_bcast:15 (rows 1 and 3 take lane 15 of the row before) and row_bcast:31 (rows 2 and 3)
 __device__ __forceinline__ int wave_scan_i32(int vi)
