@@ -96,28 +96,43 @@ constexpr int kCylCacheRounds = 12;
         cqb##k = t_[1];                                                                                      \
         cqc##k = t_[2];                                                                                      \
     }
-#define CAPE_CYL_SCORE(k)                                                                                    \
-    if (j0 + 64 * (k) < m)                                                                                   \
+// One round = 64 cells.  The rounds are evaluated four at a time WITHOUT a branch between them (a cell past the end is
+// computed and masked): a lone wave issues in order and stalls on every dependent f64 result (~9 cycles), so the only
+// latency hiding there is comes from independent work in the same basic block -- the three other rounds of the group.
+#define CAPE_CYL_SCORE1(k)                                                                                   \
     {                                                                                                        \
         bool inl_;                                                                                           \
         const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
-        if (j0 + lane + 64 * (k) < m)                                                                        \
-        {                                                                                                    \
-            psum += d_;                                                                                      \
-            curLocal += inl_ ? 1 : 0;                                                                        \
-        }                                                                                                    \
+        const bool in_ = j0 + lane + 64 * (k) < m;                                                           \
+        psum += in_ ? d_ : 0.0;                                                                              \
+        curLocal += (in_ && inl_) ? 1 : 0;                                                                   \
+        inlBits |= (in_ && inl_) ? (1u << (k)) : 0u;                                                         \
     }
-#define CAPE_CYL_PARK(k)                                                                                     \
+#define CAPE_CYL_SCORE4(a, b, c_, d)                                                                         \
+    if (j0 + 64 * (a) < m)                                                                                   \
+    {                                                                                                        \
+        CAPE_CYL_SCORE1(a) CAPE_CYL_SCORE1(b) CAPE_CYL_SCORE1(c_) CAPE_CYL_SCORE1(d)                         \
+    }
+#define CAPE_CYL_SCORE_ALL CAPE_CYL_SCORE4(0, 1, 2, 3) CAPE_CYL_SCORE4(4, 5, 6, 7) CAPE_CYL_SCORE4(8, 9, 10, 11)
+// the distances of a hypothesis into LDS, for the ordered sum (only when the tree-order sum cannot decide, see below)
+#define CAPE_CYL_DIST(k)                                                                                     \
     if (j0 + 64 * (k) < m)                                                                                   \
     {                                                                                                        \
         bool inl_;                                                                                           \
         const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
         if (j0 + lane + 64 * (k) < m)                                                                        \
-        {                                                                                                    \
             c.s_dist[j0 + lane + 64 * (k)] = d_;                                                             \
-            c.s_cur[cqi##k] = inl_ ? 1 : 0;                                                                  \
-        }                                                                                                    \
     }
+// the inlier flags of the winning hypothesis, from the bits the scoring pass left in inlBits (bit k = round k)
+#define CAPE_CYL_FLAGS(k)                                                                                    \
+    if (j0 + lane + 64 * (k) < m)                                                                            \
+        c.s_best[cqi##k] = (unsigned char)((inlBits >> (k)) & 1u);
+
+// relative distance between the tree-order sum and the ordered sum of m <= 4096 non-negative doubles: each is within
+// (m - 1) * 2^-53 <= 2^-41 of the exact sum.  A test build widens it (-DCAPE_CYL_EPS=0.25) to drive the exact path.
+#ifndef CAPE_CYL_EPS
+#define CAPE_CYL_EPS 0x1p-40
+#endif
 
 __device__ __forceinline__ int cyl_wave_sum(int v) { return wave_sum_i32(v); }
 
@@ -260,7 +275,14 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         {
             const int m = idsLeftCount;
             const unsigned inliersAccepted = (unsigned)floor(0.9 * (double)m);
-            double minHyp = (double)(maxSqrtDistF * (float)m);
+            // The reference keeps minHypothesisDist, the ORDERED sum of the MSAC costs of the best hypothesis so far, and only
+            // ever compares against it (dist < minHypothesisDist, :296); nothing else of it is observable.  An ordered sum is
+            // a serial chain over m cells, so the wave keeps an INTERVAL [minLo, minHi] that contains the best's ordered sum
+            // (exact, lo == hi, until a hypothesis wins) and decides with the tree-order sum psum, whose distance to the
+            // ordered sum is bounded (CAPE_CYL_EPS).  Only when the intervals overlap are the ordered sums computed -- of the
+            // new hypothesis and, if it is still an interval, of the best (its parameters are kept for that).
+            double minLo = (double)(maxSqrtDistF * (float)m), minHi = minLo;
+            double bR = 0.0, bInvR2 = 0.0, bCx = 0.0, bCy = 0.0, bCz = 0.0; // the best hypothesis, for a late exact sum
             int prevBestCount = 0; // size of the vector swapped out of finalInlierIndexes
             for (int j = lane; j < N; j += 64)
                 c.s_best[j] = 0;
@@ -271,24 +293,27 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 constexpr int j0 = 0;
                 CAPE_CYL_ROUNDS(CAPE_CYL_FETCH)
             }
-            // The draws of this loop (3 per hypothesis, <= 192) are fetched once, one per lane, and handed out by lane
-            // index; the three sample cells of hypothesis it + 1 are requested while hypothesis it is evaluated.  Both
-            // take a dependent memory round trip per hypothesis off the critical path of this one-wave-per-SIMD kernel.
+            // The draws of this loop (3 per hypothesis, <= 192) are turned into sample cells once, one draw per lane and
+            // register (idsLeft does not change during one run_ransac_loop), and handed out with v_readlane; the three
+            // sample cells of hypothesis it + 1 are requested while hypothesis it is evaluated.  Both take dependent
+            // round trips (memory, LDS crossbar) per hypothesis off the critical path of this one-wave-per-SIMD kernel.
             const int rngBase = rngPos;
-            double rr0, rr1, rr2;
+            int sc0, sc1, sc2; // sample cell of draw lane, lane + 64, lane + 128
             {
                 const int last = p.rngCount - 1;
                 const int i0 = rngBase + lane, i1 = i0 + 64, i2 = i0 + 128;
-                rr0 = p.rngTable[i0 < last ? i0 : last];
-                rr1 = p.rngTable[i1 < last ? i1 : last];
-                rr2 = p.rngTable[i2 < last ? i2 : last];
+                // table exhausted: U = 0, flagged when (if) the hypothesis is actually evaluated
+                const double u0 = i0 < p.rngCount ? p.rngTable[i0 < last ? i0 : last] : 0.0;
+                const double u1 = i1 < p.rngCount ? p.rngTable[i1 < last ? i1 : last] : 0.0;
+                const double u2 = i2 < p.rngCount ? p.rngTable[i2 < last ? i2 : last] : 0.0;
+                sc0 = (int)c.s_ids[(unsigned)floor(u0 * (double)(unsigned)m)];
+                sc1 = (int)c.s_ids[(unsigned)floor(u1 * (double)(unsigned)m)];
+                sc2 = (int)c.s_ids[(unsigned)floor(u2 * (double)(unsigned)m)];
             }
             auto sample_of = [&](int drawIndex) { // drawIndex = 3 * it + q, uniform
-                const double v0 = __shfl(rr0, drawIndex & 63), v1 = __shfl(rr1, drawIndex & 63), v2 = __shfl(rr2, drawIndex & 63);
-                double U = drawIndex < 64 ? v0 : (drawIndex < 128 ? v1 : v2);
-                if (rngBase + drawIndex >= p.rngCount)
-                    U = 0.0; // table exhausted: flagged when (if) the hypothesis is actually evaluated
-                return (int)c.s_ids[(unsigned)floor(U * (double)(unsigned)m)];
+                const int dl = drawIndex & 63;
+                const int r0 = __builtin_amdgcn_readlane(sc0, dl), r1 = __builtin_amdgcn_readlane(sc1, dl), r2 = __builtin_amdgcn_readlane(sc2, dl);
+                return drawIndex < 64 ? r0 : (drawIndex < 128 ? r1 : r2);
             };
             struct Triplet
             {
@@ -306,6 +331,36 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             };
             if (p.ransacMaxIterations * 3 > 192)
                 status |= CAPE_FRAME_RNG_EXHAUSTED; // cannot happen with the reference's constants (43 iterations)
+            // the hypothesis the distance macros evaluate (uniform)
+            double radius = 0.0, invR2 = 0.0, ctx = 0.0, cty = 0.0, ctz = 0.0;
+            auto msac = [&](double t0, double t1, double t2, double t3, double t4, double t5, bool& inl) {
+                const double vx = (t3 - radius * t0) - ctx;
+                const double vy = (t4 - radius * t1) - cty;
+                const double vz = (t5 - radius * t2) - ctz;
+                const double distance = ((vx * vx + vy * vy) + vz * vz) * invR2;
+                inl = distance < maxSqrtDist;
+                return inl ? distance : maxSqrtDist;
+            };
+            // ordered sum of the MSAC costs of the hypothesis in (radius, invR2, ctx, cty, ctz); may stop at `limit`
+            auto ordered_cost = [&](double limit) {
+                if (cached)
+                {
+                    constexpr int j0 = 0;
+                    CAPE_CYL_ROUNDS(CAPE_CYL_DIST)
+                }
+                else
+                {
+                    for (int j0 = 0; j0 < m; j0 += 256)
+                    {
+                        CAPE_CYL_TRIP(CAPE_CYL_FETCH)
+                        CAPE_CYL_TRIP(CAPE_CYL_DIST)
+                    }
+                }
+                CAPE_CYL_SYNC();
+                const double d = ordered_sum_lds(c.s_dist, m, limit, lane);
+                CAPE_CYL_SYNC(); // s_dist is rewritten by the next call
+                return d;
+            };
             Triplet cur;
             fetch_triplet(cur, 0);
             for (int it = 0; it < p.ransacMaxIterations; ++it)
@@ -327,77 +382,81 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 const double pry = (n1y * c1y + n2y * c2y) + n3y * c3y;
                 const double prz = (n1z * c1z + n2z * c2z) + n3z * c3z;
                 const double b = ((prx + pry) + prz) / 3.0 - (dot3(sNx, sNy, sNz, sCx, sCy, sCz) / 9.0);
-                const double radius = b / a;
-                const double invR2 = 1.0 / (radius * radius);
-                const double ctx = (sCx - radius * sNx) / 3.0;
-                const double cty = (sCy - radius * sNy) / 3.0;
-                const double ctz = (sCz - radius * sNz) / 3.0;
+                const double hR = b / a;
+                const double hInvR2 = 1.0 / (hR * hR);
+                const double hCx = (sCx - hR * sNx) / 3.0;
+                const double hCy = (sCy - hR * sNy) / 3.0;
+                const double hCz = (sCz - hR * sNz) / 3.0;
+                radius = hR, invR2 = hInvR2, ctx = hCx, cty = hCy, ctz = hCz;
 
-                // MSAC truncated distances of all remaining cells, in parallel.  The cost the reference compares is their
-                // ORDERED sum, a serial chain over m cells, so a cheap decision comes first: psum is the same sum in
-                // tree order.  Both roundings of a sum of m <= 4096 non-negative terms stay within 2^-41 (relative)
-                // of the exact value, so psum * (1 - 2^-40) >= minHyp proves that the ordered sum cannot be < minHyp:
-                // the hypothesis loses and nothing else of it is observable.  Otherwise the distances are parked in
-                // LDS and summed in order (stopping early once the running sum reaches minHyp).
-                auto msac = [&](double t0, double t1, double t2, double t3, double t4, double t5, bool& inl) {
-                    const double vx = (t3 - radius * t0) - ctx;
-                    const double vy = (t4 - radius * t1) - cty;
-                    const double vz = (t5 - radius * t2) - ctz;
-                    const double distance = ((vx * vx + vy * vy) + vz * vz) * invR2;
-                    inl = distance < maxSqrtDist;
-                    return inl ? distance : maxSqrtDist;
-                };
+                // MSAC truncated distances of all remaining cells, in parallel, summed in tree order
                 int curLocal = 0;
                 double psum = 0.0;
+                unsigned inlBits = 0; // cached path: bit k = the lane's cell of round k is an inlier of this hypothesis
                 if (cached)
                 {
                     constexpr int j0 = 0;
-                    CAPE_CYL_ROUNDS(CAPE_CYL_SCORE)
+                    CAPE_CYL_SCORE_ALL
                 }
                 else
                 {
                     for (int j0 = 0; j0 < m; j0 += 256)
                     {
                         CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                        CAPE_CYL_TRIP(CAPE_CYL_SCORE)
+                        CAPE_CYL_SCORE4(0, 1, 2, 3)
                     }
                 }
                 const int curCount = cyl_wave_sum(curLocal);
-                psum = wave_sum_f64_tree(psum); // any order will do: psum only feeds the conservative test below
-                double dist = minHyp;
-                if (!(psum * (1.0 - 0x1p-40) >= minHyp))
+                psum = wave_sum_f64_tree(psum);
+                double lo = psum * (1.0 - CAPE_CYL_EPS), hi = psum * (1.0 + CAPE_CYL_EPS);
+                bool wins;
+                if (lo >= minHi)
+                    wins = false; // ordered sum >= lo >= the best's
+                else if (hi < minLo)
+                    wins = true; // ordered sum <= hi < the best's
+                else
                 {
+                    // cannot be told apart in tree order (never seen with the default bound outside the test build)
+                    if (minLo != minHi)
+                    {
+                        radius = bR, invR2 = bInvR2, ctx = bCx, cty = bCy, ctz = bCz;
+                        minLo = minHi = ordered_cost(__builtin_inf());
+                        radius = hR, invR2 = hInvR2, ctx = hCx, cty = hCy, ctz = hCz;
+                    }
+                    lo = hi = ordered_cost(minHi); // stops once it reaches minHi: >= the best's, loses
+                    wins = lo < minHi;
+                }
+                bool stop = false;
+                if (wins)
+                {
+                    minLo = lo, minHi = hi;
+                    bR = hR, bInvR2 = hInvR2, bCx = hCx, bCy = hCy, bCz = hCz;
                     if (cached)
                     {
                         constexpr int j0 = 0;
-                        CAPE_CYL_ROUNDS(CAPE_CYL_PARK)
+                        CAPE_CYL_ROUNDS(CAPE_CYL_FLAGS)
                     }
                     else
                     {
                         for (int j0 = 0; j0 < m; j0 += 256)
                         {
                             CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                            CAPE_CYL_TRIP(CAPE_CYL_PARK)
+                            inlBits = 0;
+                            {
+                                int curLocal = 0;
+                                double psum = 0.0;
+                                CAPE_CYL_SCORE4(0, 1, 2, 3)
+                                (void)curLocal, (void)psum;
+                            }
+                            CAPE_CYL_TRIP(CAPE_CYL_FLAGS)
                         }
-                    }
-                    CAPE_CYL_SYNC();
-                    dist = ordered_sum_lds(c.s_dist, m, minHyp, lane);
-                }
-                bool stop = false;
-                if (dist < minHyp)
-                {
-                    minHyp = dist;
-                    for (int jj = lane; jj < m; jj += 64)
-                    {
-                        const int i = c.s_ids[jj];
-                        c.s_best[i] = c.s_cur[i];
                     }
                     prevBestCount = bestCount; // inlierIndexes now holds the previous best (swap)
                     bestCount = curCount;
                     // early-stop quirk (:308-312): tests the swapped-out vector
                     stop = (unsigned)prevBestCount > inliersAccepted;
+                    CAPE_CYL_SYNC();
                 }
-                CAPE_CYL_SYNC();
                 CAPE_CYL_COUNT(27, 1); // hypotheses evaluated
                 if (stop)
                     break;
@@ -409,7 +468,12 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             break;
         const int maxInliers = bestCount;
 
-        // ===== LLS over all inliers, ascending i (:157-186): lanes 0-2 sumN, 3-5 sumC, 6 b
+        // ===== LLS over all inliers, ascending i (:157-186), and -- in the same chain -- the sums of cylinder_fitting's
+        // merged plane of the inlier cells (primitive_detection.cpp:488-500).  Both walk the region's cells in order under
+        // the same inlier mask and neither needs the other's result, so ONE traversal stages both records of a cell
+        // (4 pieces of the projected scratch + 5 pieces of cell_sums) and one dependent add per cell serves both:
+        //   lanes 0-2 sumN, 3-5 sumC, 6 b (the precomputed n.c product);  lanes 16-25 the merged plane's ten sums.
+        // The 18-double records are staged in s_dist, idle between the RANSAC loop and the (rare) ordered MSE sum.
         double chain = 0.0;
         static_assert(kStageChunk <= 32, "inlMask holds one bit per element of a chunk");
         unsigned inlMask = 0; // bit ci: element c0 + ci of the chunk being consumed is an inlier (uniform)
@@ -417,15 +481,22 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             const int ci = lane & (kStageChunk - 1);
             inlMask = (unsigned)__ballot(lane < kStageChunk && ci < cn && c.s_best[c0 + ci] != 0);
         };
-        staged_for_each<4, CAPE_STAGE_DEPTH_CYL>(
-                N, c.scratch, kCylStride, 0, [&](int e) { return e; }, c.s_stage, lane, ballotInliers,
-                // lanes 0..5 take component `lane`, lane 6 the precomputed n.c product; a non-inlier adds +0.0, which leaves
-                // the running sum unchanged bit for bit (the sum is never -0.0)
-                [&](int, const double* t) { return t[lane < 7 ? lane : 0]; },
-                [&](int i, double term) {
-                    const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
-                    chain += inl ? term : 0.0;
-                });
+        {
+            const int slot = lane < 7 ? lane : ((lane >= 16 && lane < 26) ? 8 + (lane - 16) : 0); // the lane's double of a record
+            staged_for_each_src<9, CAPE_STAGE_DEPTH_CYL>(
+                    N, [&](int e, int sub) { return sub < 4 ? e : (int)c.s_list[e]; },
+                    [&](int rec, int sub) {
+                        return sub < 4 ? reinterpret_cast<const double2*>(c.scratch + (size_t)rec * kCylStride + 2 * sub)
+                                       : reinterpret_cast<const double2*>(sumsBase + (size_t)rec * kSumStride + 2 * (sub - 4));
+                    },
+                    c.s_dist, lane, ballotInliers,
+                    // a non-inlier adds +0.0, which leaves the running sum unchanged bit for bit (the sums are never -0.0)
+                    [&](int, const double* t) { return t[slot]; },
+                    [&](int i, double term) {
+                        const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
+                        chain += inl ? term : 0.0;
+                    });
+        }
         CAPE_CYL_TICK(16); // LLS ordered pass
         const double sNx = readlane_f64(chain, 0), sNy = readlane_f64(chain, 1), sNz = readlane_f64(chain, 2);
         const double sCx = readlane_f64(chain, 3), sCy = readlane_f64(chain, 4), sCz = readlane_f64(chain, 5);
@@ -468,10 +539,12 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double P2x = ctx + ax, P2y = cty + ay, P2z = ctz + az;
         const double dx = P2x - ctx, dy = P2y - cty, dz = P2z - ctz;
         const double P1P2d = sqrt((dx * dx + dy * dy) + dz * dz);
-        double mse = 0.0;
-        {
-            // the per-cell squared distances are independent: all lanes compute them (cx, cy, cz straight from
-            // cell_plane) into LDS, then they are added in ascending order like the reference's loop
+        // The MSE only ever meets the merged plane's MSE in one comparison (primitive_detection.cpp:437-476), so -- like
+        // the RANSAC costs above -- its ordered sum is bracketed by the tree-order sum of the same addends, and the serial
+        // chain over N cells runs only if the bracket cannot decide.
+        // The per-cell squared distances are independent: all lanes compute them (cx, cy, cz straight from cell_plane).
+        auto mse_addends = [&](bool park) {
+            double ps = 0.0;
             for (int i0 = 0; i0 < N; i0 += 256)
             {
                 double2 w0[4], w1[4]; // (cx cy) (cz mse) of cell_plane
@@ -500,35 +573,25 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                             const double t = sqrt((crx * crx + cry * cry) + crz * crz) / P1P2d - radius;
                             t2 = t * t;
                         }
-                        c.s_dist[i] = t2;
+                        if (park)
+                            c.s_dist[i] = t2; // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach
+                        ps += t2;
                     }
                 }
             }
-            CAPE_CYL_SYNC();
-            CAPE_CYL_TICK(18); // MSE: parallel distances
-            // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach: scan all N entries
-            mse = ordered_sum_lds(c.s_dist, N, __builtin_inf(), lane);
-            CAPE_CYL_SYNC();
-        }
-        CAPE_CYL_TICK(19); // MSE: ordered sum
-        mse /= (double)maxInliers;
+            return wave_sum_f64_tree(ps);
+        };
+        const double mseTree = mse_addends(false);
+        CAPE_CYL_TICK(18); // MSE: parallel distances
 
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
-        const int ql = lane < 10 ? lane : 0;
-        double acc = 0.0; // Plane_Segment newMergedPlane: cleared sums
-        staged_for_each<5, CAPE_STAGE_DEPTH_CYL>(
-                N, sumsBase, kSumStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, ballotInliers,
-                [&](int, const double* rec) { return rec[ql]; },
-                [&](int i, double v) {
-                    const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
-                    acc += inl ? v : 0.0;
-                });
+        //       (its sums came out of the LLS traversal above, lanes 16-25)
         CAPE_CYL_TICK(20); // merged plane sums, ordered pass
         double S[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
-            S[k] = readlane_f64(acc, k);
-        const double cnt = readlane_f64(acc, 9);
+            S[k] = readlane_f64(chain, 16 + k);
+        const double cnt = readlane_f64(chain, 25);
         PlaneFit f;
         fit_plane(S, (uint32_t)cnt, f);
         CAPE_CYL_TICK(21); // merged plane fit
@@ -537,7 +600,25 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         CAPE_CYL_COUNT(26, maxInliers); // inliers removed
 
         // ===== add_cylinder_to_features (:437-476): model selection on MSE
-        if (f.mse < mse)
+        bool planeWins;
+        {
+            const double kInl = (double)maxInliers;
+            const double mseLo = (mseTree * (1.0 - CAPE_CYL_EPS)) / kInl, mseHi = (mseTree * (1.0 + CAPE_CYL_EPS)) / kInl;
+            if (f.mse < mseLo)
+                planeWins = true;
+            else if (!(f.mse < mseHi))
+                planeWins = false;
+            else
+            {
+                (void)mse_addends(true);
+                CAPE_CYL_SYNC();
+                const double mse = ordered_sum_lds(c.s_dist, N, __builtin_inf(), lane) / kInl;
+                CAPE_CYL_SYNC();
+                planeWins = f.mse < mse;
+            }
+        }
+        CAPE_CYL_TICK(19); // MSE: decision (ordered sum only when the bracket is not enough)
+        if (planeWins)
         {
             if (nSeg >= c.maxPlanes)
             {

@@ -37,6 +37,9 @@ constexpr int kChunk = kStageChunk; // cells staged per step of the ordered mome
 #endif
 constexpr int kWavesPerGroup = CAPE_B_WAVES_PER_GROUP; // independent frames (waves) per workgroup
 __host__ __device__ constexpr int kChunkDoubles(int) { return kChunk * kSumStride; }
+// s_dist of the cylinder instance: one f64 per cell (+ read-ahead pad); it also stages the 18-double records of the
+// combined LLS / merged-plane traversal (cape_cylinder.h), which small grids would not leave room for
+__host__ __device__ constexpr int cyl_dist_doubles(int cells) { return cells + 16 > kChunk * 18 ? cells + 16 : kChunk * 18; }
 
 // kernel-phase ablation for profiling experiments: -DCAPE_B_STOP_AT=k makes the wave leave after phase k
 #ifdef CAPE_B_STOP_AT
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
     // (aligned through the OFFSET, not through an integer cast of the pointer: the cast loses the LDS address space and every
     // access through s_dist / s_pendCyl becomes a flat_load that waits for vmcnt AND lgkmcnt)
     double* s_dist = reinterpret_cast<double*>(smem + (((size_t)(s_best + C - smem) + 15) & ~(size_t)15)); // C f64 (+ read-ahead pad)
-    double* s_pendCyl = s_dist + C + 16;                                          // 16 region records (cylinder instance)
+    double* s_pendCyl = s_dist + cyl_dist_doubles(C);                             // 16 region records (cylinder instance)
 #ifdef CAPE_B_PROFILE
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsPerWave - 8 * kProfileSlots);
     if (lane < kProfileSlots)
@@ -1108,7 +1111,7 @@ size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes)
     b += (size_t)cells;                             // s_lab
     b += maxPlanes;                           // s_mlab
     if (cylinders)
-        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cells * 8 + 128 // s_cyl, s_ids, masks, s_dist (+ read-ahead pad)
+        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cyl_dist_doubles(cells) * 8 // s_cyl, s_ids, masks, s_dist
              + 16 * kSegDoubles * 8;                                                                // s_pendCyl
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots; // s_prof

@@ -45,14 +45,17 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 // prep(c0, cn): called by all lanes right before the cn bodies of the chunk that starts at element c0 (e.g. to ballot a
 // per-element flag into a uniform mask, so that the bodies stay free of LDS look-ups and branches)
 // DEPTH (2..4): chunks requested ahead of the one being consumed; each costs ceil(32 * PIECES / 64) double2 registers.
-template <int PIECES, int DEPTH, typename IndexFn, typename Prep, typename Load, typename Fold>
-__device__ __forceinline__ void staged_for_each(int N_, const double* base, int strideDoubles, int firstPiece, IndexFn index,
-                                                double* s_buf, int lane, Prep prep, Load load, Fold fold,
-                                                unsigned long long* prof = nullptr)
+//
+// staged_for_each_src is the general form: the pieces of a record may come from more than one array (two traversals over
+// the same elements folded into one chain, e.g. different quantities in different lanes):
+// index(e, sub) -> record number that holds piece `sub` of element e;  addr(rec, sub) -> its 16 bytes.
+template <int PIECES, int DEPTH, typename IndexFn, typename AddrFn, typename Prep, typename Load, typename Fold>
+__device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrFn addr, double* s_buf, int lane, Prep prep, Load load,
+                                                    Fold fold, unsigned long long* prof = nullptr)
 {
     constexpr int kPiecesPerChunk = kStageChunk * PIECES;
     constexpr int kPerLane = (kPiecesPerChunk + 63) / 64; // pieces each lane moves per chunk
-    static_assert(PIECES >= 1 && PIECES <= 5 && kPerLane <= 5, "record / chunk too large for the staging registers");
+    static_assert(PIECES >= 1 && PIECES <= 10 && kPerLane <= 5, "record / chunk too large for the staging registers");
     static_assert(DEPTH >= 2 && DEPTH <= 4, "two to four chunks in flight");
     // the element count is wave-uniform by contract; telling the compiler makes the loop control scalar, so the two
     // exits below are real branches instead of exec-mask updates that funnel through one latch block
@@ -63,9 +66,9 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
     // DEPTH register sets (a, b, c, d) = DEPTH chunks in flight while one more is being consumed from LDS.
 #define CAPE_STAGE_PIECE(q) ((lane + 64 * (q)) < kPiecesPerChunk ? (lane + 64 * (q)) : kPiecesPerChunk - 1)
     // the record number of piece q of the chunk that starts at element c0_ (clamped to the last element), and its load
-#define CAPE_STAGE_INDEX(q, c0_) index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1)
-#define CAPE_STAGE_LOAD(q, rec_) \
-    *reinterpret_cast<const double2*>(base + (size_t)(rec_) * strideDoubles + 2 * (firstPiece + CAPE_STAGE_PIECE(q) % PIECES))
+#define CAPE_STAGE_INDEX(q, c0_) \
+    index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1, CAPE_STAGE_PIECE(q) % PIECES)
+#define CAPE_STAGE_LOAD(q, rec_) (*addr((rec_), CAPE_STAGE_PIECE(q) % PIECES))
 #define CAPE_STAGE_DST(q) \
     *reinterpret_cast<double2*>(s_buf + (CAPE_STAGE_PIECE(q) / PIECES) * 2 * PIECES + 2 * (CAPE_STAGE_PIECE(q) % PIECES))
     double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
@@ -227,6 +230,18 @@ __device__ __forceinline__ void staged_for_each(int N_, const double* base, int 
 #undef CAPE_STAGE_DST
 #undef CAPE_STAGE_ISSUE
 #undef CAPE_STAGE_STORE
+}
+
+// all pieces of a record from one array: piece `sub` of record r = base + r * strideDoubles + 2 * (firstPiece + sub)
+template <int PIECES, int DEPTH, typename IndexFn, typename Prep, typename Load, typename Fold>
+__device__ __forceinline__ void staged_for_each(int N, const double* base, int strideDoubles, int firstPiece, IndexFn index,
+                                                double* s_buf, int lane, Prep prep, Load load, Fold fold,
+                                                unsigned long long* prof = nullptr)
+{
+    staged_for_each_src<PIECES, DEPTH>(
+            N, [&](int e, int) { return index(e); },
+            [&](int rec, int sub) { return reinterpret_cast<const double2*>(base + (size_t)rec * strideDoubles + 2 * (firstPiece + sub)); },
+            s_buf, lane, prep, load, fold, prof);
 }
 
 template <int PIECES, int DEPTH, typename IndexFn, typename Load, typename Fold>
