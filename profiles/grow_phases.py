@@ -11,7 +11,7 @@ from cape_amd import Extractor, synth
 
 NAMES = ["hist + edge-mask prologue", "hist argmax", "candidate scan", "seed pick", "propagation", "list build", "ordered accum",
          "hist removal + record", "region fits (lane parallel)", "seed-loop tail", "merge", "boundary+records", "cyl: cov+eigen", "cyl: projection", "cyl: RANSAC", "",
-         "cyl: LLS ordered pass", "cyl: ids compaction", "cyl: MSE distances", "cyl: MSE ordered sum", "cyl: plane sums pass",
+         "cyl: LLS + merged-plane sums (one ordered pass)", "cyl: ids compaction", "cyl: MSE addends (parallel)", "cyl: MSE decision", "",
          "cyl: plane fit", "cyl: select+labels", "cov staged: consume + other sets", "#RANSAC rounds", "#cells in region", "#inliers", "#hypotheses", "cyl: cov pass 1", "cyl: cov pass 2", "cov staged: hand-over of set a (vmcnt wait)", "cov staged: request of set a"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 scene = sys.argv[2] if len(sys.argv) > 2 else "room"
