@@ -439,29 +439,77 @@ Polygon Polygon::project(const vector3& nextXAxis, const vector3& nextYAxis, con
     for (const vector2& p : _ring)
         ring.push_back(get_projected_plan_coordinates(get_point_from_plane_coordinates(p, _center, _xAxis, _yAxis), nextCenter,
                                                       nextXAxis, nextYAxis));
-    return Polygon(OpenRing {}, ring, nextXAxis, nextYAxis, nextCenter);
+    Polygon out(OpenRing {}, ring, nextXAxis, nextYAxis, nextCenter);
+    for (const std::vector<vector2>& hole : _inners)
+    {
+        std::vector<vector2> h;
+        h.reserve(hole.size());
+        for (const vector2& p : hole)
+            h.push_back(get_projected_plan_coordinates(get_point_from_plane_coordinates(p, _center, _xAxis, _yAxis), nextCenter,
+                                                       nextXAxis, nextYAxis));
+        out.add_hole(h);
+    }
+    return out;
 }
+
+// interior ring, stored counter-clockwise; the cached area follows
+void Polygon::add_hole(std::vector<vector2> hole)
+{
+    if (hole.size() < 3)
+        return;
+    if (ring_area_signed(hole) < 0)
+        std::reverse(hole.begin(), hole.end());
+    _inners.push_back(std::move(hole));
+    _area = area();
+}
+
+namespace {
+// area of (A minus its holes) n (B minus its holes): the holes lie inside their outer rings, so inclusion-exclusion over
+// the rings is exact
+double polygons_inter_area(const std::vector<vector2>& A, const std::vector<std::vector<vector2>>& holesA,
+                           const std::vector<vector2>& B, const std::vector<std::vector<vector2>>& holesB)
+{
+    double a = rings_inter_area(A, B);
+    for (const auto& h : holesA)
+        a -= rings_inter_area(h, B);
+    for (const auto& h : holesB)
+        a -= rings_inter_area(A, h);
+    for (const auto& ha : holesA)
+        for (const auto& hb : holesB)
+            a += rings_inter_area(ha, hb);
+    return a < 0 ? 0.0 : a;
+}
+} // namespace
 
 double Polygon::inter_area(const Polygon& other) const
 {
-    return rings_inter_area(_ring, other.project(_xAxis, _yAxis, _center)._ring);
+    const Polygon o = other.project(_xAxis, _yAxis, _center);
+    return polygons_inter_area(_ring, _inners, o._ring, o._inners);
 }
 
 double Polygon::union_area(const Polygon& other) const
 {
     const Polygon o = other.project(_xAxis, _yAxis, _center);
-    return area() + o.area() - rings_inter_area(_ring, o._ring);
+    return area() + o.area() - polygons_inter_area(_ring, _inners, o._ring, o._inners);
 }
 
 double Polygon::inter_over_union(const Polygon& other) const
 {
     const Polygon o = other.project(_xAxis, _yAxis, _center);
-    const double inter = rings_inter_area(_ring, o._ring);
+    const double inter = polygons_inter_area(_ring, _inners, o._ring, o._inners);
     const double uni = area() + o.area() - inter;
     return (uni <= 0 || inter <= 0) ? 0.0 : inter / uni;
 }
 
-bool Polygon::is_valid() const noexcept { return ring_is_simple(_ring); }
+bool Polygon::is_valid() const noexcept
+{
+    if (!ring_is_simple(_ring))
+        return false;
+    for (const auto& h : _inners)
+        if (!ring_is_simple(h) || !point_in_ring(h.front(), _ring, true))
+            return false;
+    return true;
+}
 
 bool Polygon::is_valid(std::string& reason) const noexcept
 {
@@ -469,14 +517,32 @@ bool Polygon::is_valid(std::string& reason) const noexcept
         reason = "Geometry has too few points";
     else if (!ring_is_simple(_ring))
         reason = "Geometry has invalid self-intersections";
+    else if (!is_valid())
+        reason = "Geometry has interior rings defined outside the outer boundary";
     else
         reason = "Geometry is valid";
     return is_valid();
 }
 
-double Polygon::area() const noexcept { return _ring.size() < 3 ? 0.0 : std::abs(ring_area_signed(_ring)); }
+double Polygon::area() const noexcept
+{
+    if (_ring.size() < 3)
+        return 0.0;
+    double a = std::abs(ring_area_signed(_ring));
+    for (const auto& h : _inners)
+        a -= std::abs(ring_area_signed(h));
+    return a < 0 ? 0.0 : a;
+}
 
-bool Polygon::contains(const vector2& point) const noexcept { return _ring.size() >= 3 && point_in_ring(point, _ring, false); }
+bool Polygon::contains(const vector2& point) const noexcept
+{
+    if (_ring.size() < 3 || !point_in_ring(point, _ring, false))
+        return false;
+    for (const auto& h : _inners)
+        if (point_in_ring(point, h, true)) // in a hole or on its edge: not within
+            return false;
+    return true;
+}
 
 vector3 Polygon::get_normal() const noexcept { return cross(_xAxis, _yAxis); }
 
@@ -494,27 +560,36 @@ Polygon Polygon::transform(const vector3& nextXAxis, const vector3& nextYAxis, c
     // R_from = [x y x^y] (orthonormal: inverse = transpose), R_to likewise: R = R_to R_from^T
     const vector3 zF = cross(_xAxis, _yAxis), zT = cross(nextXAxis, nextYAxis);
     const vector3 from[3] = {_xAxis, _yAxis, zF}, to[3] = {nextXAxis, nextYAxis, zT};
-    std::vector<vector2> ring;
-    ring.reserve(_ring.size());
-    for (const vector2& q : _ring)
-    {
-        const vector3 p3 = get_point_from_plane_coordinates(q, _center, _xAxis, _yAxis);
-        vector3 moved {nextCenter[0] - _center[0], nextCenter[1] - _center[1], nextCenter[2] - _center[2]};
-        for (int k = 0; k < 3; ++k)
+    auto move_ring = [&](const std::vector<vector2>& in) {
+        std::vector<vector2> ring;
+        ring.reserve(in.size());
+        for (const vector2& q : in)
         {
-            const double coord = from[k][0] * p3[0] + from[k][1] * p3[1] + from[k][2] * p3[2]; // (R_from^T p)_k
-            for (int i = 0; i < 3; ++i)
-                moved[i] += to[k][i] * coord;
+            const vector3 p3 = get_point_from_plane_coordinates(q, _center, _xAxis, _yAxis);
+            vector3 moved {nextCenter[0] - _center[0], nextCenter[1] - _center[1], nextCenter[2] - _center[2]};
+            for (int k = 0; k < 3; ++k)
+            {
+                const double coord = from[k][0] * p3[0] + from[k][1] * p3[1] + from[k][2] * p3[2]; // (R_from^T p)_k
+                for (int i = 0; i < 3; ++i)
+                    moved[i] += to[k][i] * coord;
+            }
+            ring.push_back(get_projected_plan_coordinates(moved, nextCenter, nextXAxis, nextYAxis));
         }
-        ring.push_back(get_projected_plan_coordinates(moved, nextCenter, nextXAxis, nextYAxis));
-    }
-    return Polygon(OpenRing {}, ring, nextXAxis, nextYAxis, nextCenter);
+        return ring;
+    };
+    Polygon out(OpenRing {}, move_ring(_ring), nextXAxis, nextYAxis, nextCenter);
+    for (const auto& h : _inners)
+        out.add_hole(move_ring(h));
+    return out;
 }
 
 namespace {
 
 // Outer boundary of the union of two simple rings (any orientation), counter-clockwise; empty if degenerate.
-std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std::vector<vector2>& B)
+// holes (optional): the bounded faces of the arrangement that lie in neither ring, i.e. the regions the two outlines
+// enclose without covering them (what boost::geometry::union_ returns as interior rings).
+std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std::vector<vector2>& B,
+                                       std::vector<std::vector<vector2>>* holes = nullptr)
 {
     double scale = 1.0;
     for (const auto* r : {&A, &B})
@@ -640,25 +715,65 @@ std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std:
         }
         return best;
     };
-    std::vector<vector2> ring;
-    size_t v = start;
-    vector2 back {0.0, 1.0}; // we reach the leftmost node heading south
-    const size_t first = next_of(start, back);
+    // the face that the directed edge (from -> to) has on its right, walked until it closes; empty if it does not
+    auto walk_face = [&](size_t from, size_t to, std::vector<std::pair<size_t, size_t>>* edges) {
+        std::vector<vector2> ring;
+        size_t cur = from, nxt = to;
+        for (size_t guard = 0; guard < 4 * nodes.size() + 8; ++guard)
+        {
+            ring.push_back(nodes[cur]);
+            if (edges)
+                edges->emplace_back(cur, nxt);
+            const vector2 back {nodes[cur][0] - nodes[nxt][0], nodes[cur][1] - nodes[nxt][1]};
+            const size_t after = next_of(nxt, back);
+            cur = nxt;
+            nxt = after;
+            if (cur == from && nxt == to)
+                return ring;
+        }
+        return std::vector<vector2> {}; // did not close: degenerate input
+    };
+    const size_t first = next_of(start, vector2 {0.0, 1.0}); // we reach the leftmost node heading south
     if (first == start)
         return {};
-    size_t cur = start, nxt = first;
-    for (size_t guard = 0; guard < 4 * nodes.size() + 8; ++guard)
+    std::vector<std::pair<size_t, size_t>> outerEdges;
+    const std::vector<vector2> ring = walk_face(start, first, &outerEdges);
+    if (holes && !ring.empty())
     {
-        ring.push_back(nodes[cur]);
-        back = {nodes[cur][0] - nodes[nxt][0], nodes[cur][1] - nodes[nxt][1]};
-        const size_t after = next_of(nxt, back);
-        cur = nxt;
-        nxt = after;
-        if (cur == start && nxt == first)
-            return ring;
+        // every other face of the arrangement: bounded, walked clockwise; a hole of the union is one whose inside belongs to
+        // neither operand
+        std::vector<std::pair<size_t, size_t>> seen = outerEdges;
+        auto was_seen = [&](size_t a, size_t b) { return std::find(seen.begin(), seen.end(), std::make_pair(a, b)) != seen.end(); };
+        for (size_t a = 0; a < nodes.size(); ++a)
+            for (const size_t b : adj[a])
+            {
+                if (was_seen(a, b))
+                    continue;
+                std::vector<std::pair<size_t, size_t>> faceEdges;
+                std::vector<vector2> face = walk_face(a, b, &faceEdges);
+                seen.insert(seen.end(), faceEdges.begin(), faceEdges.end());
+                if (face.size() < 3 || ring_area_signed(face) >= 0) // not a bounded face (or a degenerate spur)
+                    continue;
+                // a point strictly inside the face: just right of the middle of one of its edges
+                bool found = false;
+                vector2 probe {0, 0};
+                for (size_t i = 0; i < face.size() && !found; ++i)
+                {
+                    const vector2 &p = face[i], &q = face[(i + 1) % face.size()];
+                    const double dx = q[0] - p[0], dy = q[1] - p[1], len = std::hypot(dx, dy);
+                    if (len <= eps)
+                        continue;
+                    for (double off = 1e-3; off >= 1e-7 && !found; off *= 0.1)
+                    {
+                        probe = {0.5 * (p[0] + q[0]) + off * len * (dy / len), 0.5 * (p[1] + q[1]) - off * len * (dx / len)};
+                        found = point_in_ring(probe, face, false);
+                    }
+                }
+                if (found && !point_in_ring(probe, A, true) && !point_in_ring(probe, B, true))
+                    holes->push_back(face);
+            }
     }
-    (void)v;
-    return {}; // did not close: degenerate input
+    return ring;
 }
 
 // drop vertices that lie on the segment joining their neighbours (repeated until stable)
@@ -690,16 +805,46 @@ bool Polygon::merge_union(const Polygon& other)
     const Polygon o = other.project(_xAxis, _yAxis, _center);
     if (_ring.size() < 3 || o._ring.size() < 3)
         return false;
-    std::vector<vector2> outer = rings_union_outer(_ring, o._ring);
+    std::vector<std::vector<vector2>> holes;
+    std::vector<vector2> outer = rings_union_outer(_ring, o._ring, &holes);
     drop_collinear(outer);
     const double outerArea = outer.size() >= 3 ? std::abs(ring_area_signed(outer)) : 0.0;
     // two disjoint pieces: union_one keeps the biggest one of the multi-polygon (polygon.cpp:474-492)
-    const double areaA = area(), areaB = o.area();
+    const double areaA = std::abs(ring_area_signed(_ring)), areaB = std::abs(ring_area_signed(o._ring));
+    bool disjoint = false;
     if (outerArea + 1e-9 * std::max(areaA, areaB) < std::max(areaA, areaB))
-        outer = areaA >= areaB ? _ring : o._ring;
+    {
+        disjoint = true;
+        if (area() >= o.area())
+            return true; // this polygon is the biggest piece: unchanged (holes included)
+        outer = o._ring;
+    }
     if (outer.size() < 3 || !ring_is_simple(outer))
         return false; // "Merge of two polygons produces no overlaps, returning without merge operation"
-    *this = Polygon(outer, _xAxis, _yAxis, _center);
+    Polygon merged(outer, _xAxis, _yAxis, _center);
+    if (disjoint)
+    {
+        for (const auto& h : o._inners)
+            merged.add_hole(h);
+    }
+    else
+    {
+        for (auto& h : holes)
+        {
+            drop_collinear(h);
+            if (h.size() >= 3 && ring_is_simple(h))
+                merged.add_hole(h);
+        }
+        // a hole an operand already had: kept if the other operand stays clear of it
+        const double tiny = 1e-12 * std::max(areaA, areaB);
+        for (const auto& h : _inners)
+            if (polygons_inter_area(h, {}, o._ring, o._inners) <= tiny)
+                merged.add_hole(h);
+        for (const auto& h : o._inners)
+            if (polygons_inter_area(h, {}, _ring, _inners) <= tiny)
+                merged.add_hole(h);
+    }
+    *this = merged;
     simplify();
     return true;
 }
@@ -732,12 +877,30 @@ void Polygon::simplify(const double distanceThreshold) noexcept
     if (ring_is_simple(out))
     {
         const double newArea = std::abs(ring_area_signed(out));
-        if (newArea > _area * 0.75) // "check that the area is not too reduced" (polygon.cpp:592-598)
-        {
-            _area = newArea;
+        if (newArea > std::abs(ring_area_signed(_ring)) * 0.75) // "check that the area is not too reduced" (polygon.cpp:592-598)
             _ring = out;
-        }
     }
+    // interior rings with the same tolerance; one that degenerates or leaves the outer ring keeps its vertices
+    for (auto& h : _inners)
+    {
+        if (h.size() < 4)
+            continue;
+        std::vector<vector2> hc = h;
+        hc.push_back(h.front());
+        std::vector<char> hk(hc.size(), 0);
+        hk.front() = hk.back() = 1;
+        douglas_peucker(hc, 0, hc.size() - 1, eps, hk);
+        std::vector<vector2> ho;
+        for (size_t i = 0; i + 1 < hc.size(); ++i)
+            if (hk[i])
+                ho.push_back(hc[i]);
+        bool inside = ho.size() >= 3 && ring_is_simple(ho);
+        for (size_t i = 0; inside && i < ho.size(); ++i)
+            inside = point_in_ring(ho[i], _ring, true);
+        if (inside)
+            h = ho;
+    }
+    _area = area();
 }
 
 } // namespace rgbd_slam::utils

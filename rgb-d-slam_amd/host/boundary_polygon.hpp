@@ -36,17 +36,19 @@ class Polygon
     // throws std::invalid_argument like the reference (normal not unit / fewer than 3 points)
     Polygon(const std::vector<vector3>& points, const vector3& normal, const vector3& center);
 
-    [[nodiscard]] bool is_valid() const noexcept;               // simple (non self-intersecting) ring of >= 3 vertices
+    [[nodiscard]] bool is_valid() const noexcept;               // simple (non self-intersecting) rings, outer of >= 3 vertices
     [[nodiscard]] bool is_valid(std::string& reason) const noexcept; // polygon.hpp:84-87: same, with the failure reason
     [[nodiscard]] size_t boundary_length() const noexcept { return _ring.size(); }
-    [[nodiscard]] double area() const noexcept;                 // shoelace, >= 0
+    [[nodiscard]] double area() const noexcept;                 // shoelace of the outer ring minus the interior rings, >= 0
     [[nodiscard]] double get_area() const noexcept { return _area; }
-    [[nodiscard]] bool contains(const vector2& point) const noexcept; // strictly inside (boost::geometry::within)
+    [[nodiscard]] bool contains(const vector2& point) const noexcept; // strictly inside (boost::geometry::within): not in a hole
     [[nodiscard]] vector3 get_center() const noexcept { return _center; }
     [[nodiscard]] vector3 get_x_axis() const noexcept { return _xAxis; }
     [[nodiscard]] vector3 get_y_axis() const noexcept { return _yAxis; }
     [[nodiscard]] vector3 get_normal() const noexcept;          // xAxis x yAxis
     [[nodiscard]] const std::vector<vector2>& boundary() const noexcept { return _ring; }
+    // interior rings (holes): only a merge_union can create them, like the reference's polygon::inners()
+    [[nodiscard]] const std::vector<std::vector<vector2>>& interior_rings() const noexcept { return _inners; }
     [[nodiscard]] std::vector<vector3> get_unprojected_boundary() const;
 
     void simplify(double distanceThreshold = 10) noexcept;      // Douglas-Peucker, threshold max(area/1e5, distanceThreshold)
@@ -65,12 +67,14 @@ class Polygon
     // the rotation being about the origin like the reference) and re-expressed in the new frame
     [[nodiscard]] Polygon transform(const vector3& nextNormal, const vector3& nextCenter) const;
     [[nodiscard]] Polygon transform(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const;
-    // Polygon::merge_union (polygon.cpp:325-336 over union_one :463-493): this polygon becomes the outer boundary of
-    // (this U other), `other` being projected into this frame first; two disjoint polygons leave the larger one (the
-    // reference keeps the biggest piece of the multi-polygon), then simplify().  Holes that a union can enclose are not
-    // represented (the reference would keep them as interior rings).  Returns false (and changes nothing) if the
-    // result is empty.  Dependency-free: outer-face walk over the arrangement of the two rings, touching vertices and
-    // collinear overlaps included.
+    // Polygon::merge_union (polygon.cpp:325-336 over union_one :463-493): this polygon becomes (this U other), `other`
+    // being projected into this frame first; two disjoint polygons leave the larger one (the reference keeps the biggest
+    // piece of the multi-polygon), then simplify().  A region that the two outlines enclose without covering it becomes an
+    // interior ring, like in the Boost polygon the reference assigns (area, contains and the intersection / union areas
+    // honour it).  A hole one of the operands already had survives if the other operand does not touch it and is
+    // dropped otherwise (a partly re-covered hole counts as filled: the one approximation here).  Returns false (and
+    // changes nothing) if the result is empty.  Dependency-free: face walks over the arrangement of the two outer rings,
+    // touching vertices and collinear overlaps included.
     bool merge_union(const Polygon& other);
     // polygon from an explicit ring in a given frame (polygon.cpp:236-266)
     Polygon(const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center);
@@ -85,7 +89,9 @@ class Polygon
     // internal: `ring` is already open (no repeated closing vertex), so a degenerate ring whose first and last vertices
     // coincide -- e.g. a projection onto a perpendicular plane -- keeps all its vertices
     Polygon(OpenRing, const std::vector<vector2>& ring, const vector3& xAxis, const vector3& yAxis, const vector3& center);
+    void add_hole(std::vector<vector2> hole);
     std::vector<vector2> _ring; // open ring (first vertex not repeated), clockwise like the reference
+    std::vector<std::vector<vector2>> _inners; // holes, open rings, counter-clockwise (boost::geometry::correct)
     vector3 _center {0, 0, 0}, _xAxis {1, 0, 0}, _yAxis {0, 1, 0};
     double _area = 0.0;
 };

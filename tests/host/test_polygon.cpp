@@ -222,6 +222,54 @@ int main()
             EXPECT(m.is_valid());
         }
     }
+    {
+        // interior rings: a union whose outlines enclose a region they do not cover (boost::geometry::union_ returns it as
+        // an inner ring, which the reference assigns to its polygon: polygon.cpp:325-336, :463-470)
+        const vector3 normal {0.0, 0.0, 1.0}, center {0.0, 0.0, 0.0};
+        const auto axes = get_plane_coordinate_system(normal);
+        auto near = [](double a, double b) { return std::abs(a - b) < 1e-3 * std::max(1.0, std::abs(b)); };
+        // a "C" open to the right (3000 x 3000 with the notch x in [1000, 3000], y in [1000, 2000] missing) ...
+        Polygon cShape(std::vector<vector2> {{0, 0}, {3000, 0}, {3000, 1000}, {1000, 1000}, {1000, 2000}, {3000, 2000}, {3000, 3000}, {0, 3000}},
+                       axes.first, axes.second, center);
+        EXPECT(cShape.is_valid() && near(cShape.area(), 9e6 - 2e6));
+        // ... closed by a bar x in [2500, 4000]: the union is 4000 x 3000 with the hole x in [1000, 2500], y in [1000, 2000]
+        Polygon bar(std::vector<vector2> {{2500, 0}, {4000, 0}, {4000, 3000}, {2500, 3000}}, axes.first, axes.second, center);
+        Polygon ring = cShape;
+        EXPECT(ring.merge_union(bar));
+        EXPECT(ring.is_valid() && ring.interior_rings().size() == 1);
+        EXPECT(near(ring.area(), 12e6 - 1.5e6) && near(ring.get_area(), ring.area()));
+        EXPECT(!ring.contains({1700, 1500}) && !ring.contains({1000, 1500}));             // in the hole / on its edge
+        EXPECT(ring.contains({500, 500}) && ring.contains({3000, 1500}) && ring.contains({2700, 1500}));
+        EXPECT(!ring.contains({4500, 1500}));
+        // the other way round gives the same region
+        Polygon ring2 = bar;
+        EXPECT(ring2.merge_union(cShape) && ring2.interior_rings().size() == 1 && near(ring2.area(), ring.area()));
+        // areas against a probe that covers the hole: x in [500, 3000], y in [500, 2500]
+        Polygon probe(std::vector<vector2> {{500, 500}, {3000, 500}, {3000, 2500}, {500, 2500}}, axes.first, axes.second, center);
+        EXPECT(near(ring.inter_area(probe), 5e6 - 1.5e6) && near(probe.inter_area(ring), 5e6 - 1.5e6));
+        EXPECT(near(ring.union_area(probe), 10.5e6 + 5e6 - 3.5e6));
+        EXPECT(near(ring.inter_over_union(probe), 3.5e6 / 12e6));
+        EXPECT(near(ring.inter_area(ring2), ring.area()) && near(ring.inter_over_union(ring2), 1.0));
+        // a rigid move and a re-projection keep the hole
+        const Polygon moved = ring.transform(normal, {100.0, -50.0, 20.0});
+        EXPECT(moved.interior_rings().size() == 1 && near(moved.area(), ring.area()) && moved.is_valid());
+        const Polygon same = ring.project(normal, center);
+        EXPECT(same.interior_rings().size() == 1 && near(same.area(), ring.area()) && !same.contains({1700, 1500}));
+        // a later union that stays clear of the hole keeps it; one that covers it fills it
+        Polygon clear(std::vector<vector2> {{3500, 2500}, {5000, 2500}, {5000, 3500}, {3500, 3500}}, axes.first, axes.second, center);
+        Polygon keep = ring;
+        EXPECT(keep.merge_union(clear) && keep.interior_rings().size() == 1 && !keep.contains({1700, 1500}));
+        EXPECT(near(keep.area(), 10.5e6 + 1.5e6 - 0.25e6));
+        Polygon plug(std::vector<vector2> {{900, 900}, {2600, 900}, {2600, 2100}, {900, 2100}}, axes.first, axes.second, center);
+        Polygon filled = ring;
+        EXPECT(filled.merge_union(plug) && filled.interior_rings().empty() && near(filled.area(), 12e6) && filled.contains({1700, 1500}));
+        // two disjoint operands: the bigger piece stays, with its hole
+        Polygon farAway(std::vector<vector2> {{9000, 0}, {9500, 0}, {9500, 500}, {9000, 500}}, axes.first, axes.second, center);
+        Polygon big = ring;
+        EXPECT(big.merge_union(farAway) && big.interior_rings().size() == 1 && near(big.area(), ring.area()));
+        Polygon small = farAway;
+        EXPECT(small.merge_union(ring) && small.interior_rings().size() == 1 && near(small.area(), ring.area()));
+    }
     std::printf(failures ? "%d FAILURES\n" : "all polygon tests passed\n", failures);
     return failures ? 1 : 0;
 }
