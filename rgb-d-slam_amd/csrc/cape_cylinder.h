@@ -191,18 +191,35 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
     // ---- cov = (M * M^T) / (cols - 1), M = [normals, -normals] (cylinder_segment.cpp:47-89): ascending column order
     double cov6;
     {
-        // lane e -> (r,c) of the lower triangle: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+        // lane e accumulates entry e of the lower triangle: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2), M(r,i) * M(c,i) per column.
+        // The products do not depend on the running sums, so they are formed when a chunk is PARKED, by the lanes that
+        // fetched it: the two pieces of a cell, (nx ny) and (nz d), sit in neighbouring lanes, one DPP swap apart, and the
+        // chunk buffer holds six products per cell.  The chain is then one LDS operand and one add per column; with the
+        // multiply and the second operand on it, it cost a lone wave half as much again.
         const int e = lane < 6 ? lane : 0;
-        const int r = (e == 0) ? 0 : (e <= 2 ? 1 : 2);
-        const int cc = (e == 0 || e == 1 || e == 3) ? 0 : ((e == 2 || e == 4) ? 1 : 2);
         double acc = 0.0;
         for (int half = 0; half < 2; ++half)
         {
-            // records: (nx, ny, nz, d) of every activated cell, staged through LDS (2 pieces of cell_plane)
-            staged_for_each<2, CAPE_STAGE_DEPTH_CYL>(
-                    N, planeBase, kPlaneStride, 0, [&](int e) { return (int)c.s_list[e]; }, c.s_stage, lane, [](int, int) {},
-                    [&](int, const double* rec) { return make_double2(rec[r], rec[cc]); },
-                    [&](int, double2 v) { acc += v.x * v.y; }, // (-a)*(-b) == a*b in the second half
+            staged_for_each_src<2, CAPE_STAGE_DEPTH_CYL>(
+                    N, [&](int i, int) { return (int)c.s_list[i]; },
+                    [&](int rec, int sub) { return reinterpret_cast<const double2*>(planeBase + (size_t)rec * kPlaneStride + 2 * sub); },
+                    [](int) { return true; },
+                    [&](double* buf, int piece, double2 v) {
+                        const double ox = __longlong_as_double((long long)dpp_u64<kDppQuadXor1>((unsigned long long)__double_as_longlong(v.x)));
+                        double* rec = buf + (piece >> 1) * 6;
+                        if (!(piece & 1)) // (nx ny) here, nz next door
+                        {
+                            *reinterpret_cast<double2*>(rec) = make_double2(v.x * v.x, v.y * v.x);
+                            *reinterpret_cast<double2*>(rec + 2) = make_double2(v.y * v.y, ox * v.x);
+                            rec[4] = ox * v.y;
+                        }
+                        else
+                            rec[5] = v.x * v.x;
+                    },
+                    c.s_stage, lane, [](int, int) {},
+                    // (load() is handed the cell's place in the default layout, 4 doubles per cell)
+                    [&](int, const double* rec) { return c.s_stage[((rec - c.s_stage) >> 2) * 6 + e]; },
+                    [&](int, double prod) { acc += prod; }, // (-a)*(-b) == a*b in the second half
                     c.dbg);
             CAPE_CYL_TICK(28 + half); // covariance pass 1 / 2
         }
@@ -475,12 +492,6 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         //   lanes 0-2 sumN, 3-5 sumC, 6 b (the precomputed n.c product);  lanes 16-25 the merged plane's ten sums.
         // The 18-double records are staged in s_dist, idle between the RANSAC loop and the (rare) ordered MSE sum.
         double chain = 0.0;
-        static_assert(kStageChunk <= 32, "inlMask holds one bit per element of a chunk");
-        unsigned inlMask = 0; // bit ci: element c0 + ci of the chunk being consumed is an inlier (uniform)
-        auto ballotInliers = [&](int c0, int cn) {
-            const int ci = lane & (kStageChunk - 1);
-            inlMask = (unsigned)__ballot(lane < kStageChunk && ci < cn && c.s_best[c0 + ci] != 0);
-        };
         {
             const int slot = lane < 7 ? lane : ((lane >= 16 && lane < 26) ? 8 + (lane - 16) : 0); // the lane's double of a record
             staged_for_each_src<9, CAPE_STAGE_DEPTH_CYL>(
@@ -489,13 +500,9 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                         return sub < 4 ? reinterpret_cast<const double2*>(c.scratch + (size_t)rec * kCylStride + 2 * sub)
                                        : reinterpret_cast<const double2*>(sumsBase + (size_t)rec * kSumStride + 2 * (sub - 4));
                     },
-                    c.s_dist, lane, ballotInliers,
-                    // a non-inlier adds +0.0, which leaves the running sum unchanged bit for bit (the sums are never -0.0)
-                    [&](int, const double* t) { return t[slot]; },
-                    [&](int i, double term) {
-                        const bool inl = (inlMask >> (i & (kStageChunk - 1))) & 1u;
-                        chain += inl ? term : 0.0;
-                    });
+                    // a non-inlier is parked as +0.0, which leaves the running sums unchanged bit for bit (they are never -0.0)
+                    [&](int e) { return c.s_best[e] != 0; }, stage_park_records<9>, c.s_dist, lane, [](int, int) {},
+                    [&](int, const double* t) { return t[slot]; }, [&](int, double term) { chain += term; });
         }
         CAPE_CYL_TICK(16); // LLS ordered pass
         const double sNx = readlane_f64(chain, 0), sNy = readlane_f64(chain, 1), sNz = readlane_f64(chain, 2);

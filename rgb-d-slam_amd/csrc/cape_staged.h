@@ -27,6 +27,12 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 #endif
 #define CAPE_STAGE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
+// default park(): the chunk buffer holds the records as they are in memory, [element][2 * PIECES] doubles
+template <int PIECES> __device__ __forceinline__ void stage_park_records(double* buf, int piece, double2 v)
+{
+    *reinterpret_cast<double2*>(buf + (piece / PIECES) * 2 * PIECES + 2 * (piece % PIECES)) = v;
+}
+
 // PIECES  : 16-byte pieces (double2) per record, 1..5
 // index(e): record number of element e (e.g. the activated-cell list), e in [0, N)
 // load(e, rec) -> value  : the lane's operand(s) of element e, plain reads of the record's 2*PIECES doubles in LDS (no
@@ -48,10 +54,17 @@ constexpr int kStageChunk = CAPE_STAGE_CHUNK; // records per chunk; the LDS buff
 //
 // staged_for_each_src is the general form: the pieces of a record may come from more than one array (two traversals over
 // the same elements folded into one chain, e.g. different quantities in different lanes):
-// index(e, sub) -> record number that holds piece `sub` of element e;  addr(rec, sub) -> its 16 bytes.
-template <int PIECES, int DEPTH, typename IndexFn, typename AddrFn, typename Prep, typename Load, typename Fold>
-__device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrFn addr, double* s_buf, int lane, Prep prep, Load load,
-                                                    Fold fold, unsigned long long* prof = nullptr)
+// index(e, sub) -> record number that holds piece `sub` of element e;  addr(rec, sub) -> its 16 bytes;
+// keep(e) -> false parks +0.0 in place of element e's record (a masked sum: the select is paid once per piece by the lanes
+// that stage the chunk, not once per element on the chain; looked up when the chunk is requested).
+// park(buf, piece, v)    : how a fetched piece (number `piece` = element-in-chunk * PIECES + sub, value v) is written to the
+//                          chunk buffer; called by all 64 lanes together, so it may exchange pieces between lanes first (the
+//                          cylinder covariance parks the six products of a cell instead of its normal).  The default
+//                          layout is [element][2 * PIECES] doubles, which is what load() is handed a pointer into.
+template <int PIECES, int DEPTH, typename IndexFn, typename AddrFn, typename Keep, typename Park, typename Prep, typename Load,
+          typename Fold>
+__device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrFn addr, Keep keep, Park park, double* s_buf, int lane,
+                                                    Prep prep, Load load, Fold fold, unsigned long long* prof = nullptr)
 {
     constexpr int kPiecesPerChunk = kStageChunk * PIECES;
     constexpr int kPerLane = (kPiecesPerChunk + 63) / 64; // pieces each lane moves per chunk
@@ -69,12 +82,13 @@ __device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrF
 #define CAPE_STAGE_INDEX(q, c0_) \
     index(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1, CAPE_STAGE_PIECE(q) % PIECES)
 #define CAPE_STAGE_LOAD(q, rec_) (*addr((rec_), CAPE_STAGE_PIECE(q) % PIECES))
-#define CAPE_STAGE_DST(q) \
-    *reinterpret_cast<double2*>(s_buf + (CAPE_STAGE_PIECE(q) / PIECES) * 2 * PIECES + 2 * (CAPE_STAGE_PIECE(q) % PIECES))
+#define CAPE_STAGE_KEEP(q, c0_) \
+    (keep(((c0_) + CAPE_STAGE_PIECE(q) / PIECES) < N ? ((c0_) + CAPE_STAGE_PIECE(q) / PIECES) : N - 1) ? (1u << (q)) : 0u)
     double2 a0 = make_double2(0, 0), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
     double2 b0 = a0, b1 = a0, b2 = a0, b3 = a0, b4 = a0;
     double2 g0 = a0, g1 = a0, g2 = a0, g3 = a0, g4 = a0;
     double2 d0 = a0, d1 = a0, d2 = a0, d3 = a0, d4 = a0;
+    unsigned ka = 0, kb = 0, kg = 0, kd = 0; // bit q: piece q of the set belongs to a kept element
     // unconditional (clamped) on purpose, see above; at most two surplus chunks are fetched at the end of a call.
     // The scheduling barriers keep the loads of one set together: the in-order vmcnt counter can only wait for "all
     // but the k youngest", so interleaving the two sets would make every hand-over wait for both.
@@ -89,6 +103,9 @@ __device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrF
         const int r2_ = kPerLane > 2 ? CAPE_STAGE_INDEX(2, at_) : 0;        \
         const int r3_ = kPerLane > 3 ? CAPE_STAGE_INDEX(3, at_) : 0;        \
         const int r4_ = kPerLane > 4 ? CAPE_STAGE_INDEX(4, at_) : 0;        \
+        k##S = CAPE_STAGE_KEEP(0, at_) | (kPerLane > 1 ? CAPE_STAGE_KEEP(1, at_) : 0u) |                        \
+               (kPerLane > 2 ? CAPE_STAGE_KEEP(2, at_) : 0u) | (kPerLane > 3 ? CAPE_STAGE_KEEP(3, at_) : 0u) |  \
+               (kPerLane > 4 ? CAPE_STAGE_KEEP(4, at_) : 0u);                                                 \
         __builtin_amdgcn_sched_barrier(0);                                  \
         S##0 = CAPE_STAGE_LOAD(0, r0_);                                     \
         if (kPerLane > 1)                                                   \
@@ -101,18 +118,19 @@ __device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrF
             S##4 = CAPE_STAGE_LOAD(4, r4_);                                 \
         __builtin_amdgcn_sched_barrier(0);                                  \
     } while (0)
+#define CAPE_STAGE_STORE1(S, q) park(s_buf, CAPE_STAGE_PIECE(q), ((k##S >> (q)) & 1u) ? S##q : make_double2(0.0, 0.0))
 #define CAPE_STAGE_STORE(S)                   \
     do                                        \
     {                                         \
-        CAPE_STAGE_DST(0) = S##0;             \
+        CAPE_STAGE_STORE1(S, 0);              \
         if (kPerLane > 1)                     \
-            CAPE_STAGE_DST(1) = S##1;         \
+            CAPE_STAGE_STORE1(S, 1);          \
         if (kPerLane > 2)                     \
-            CAPE_STAGE_DST(2) = S##2;         \
+            CAPE_STAGE_STORE1(S, 2);          \
         if (kPerLane > 3)                     \
-            CAPE_STAGE_DST(3) = S##3;         \
+            CAPE_STAGE_STORE1(S, 3);          \
         if (kPerLane > 4)                     \
-            CAPE_STAGE_DST(4) = S##4;         \
+            CAPE_STAGE_STORE1(S, 4);          \
     } while (0)
     auto consume = [&](int c0) {
         const int cn = (N - c0 < kStageChunk) ? (N - c0) : kStageChunk;
@@ -227,9 +245,10 @@ __device__ __forceinline__ void staged_for_each_src(int N_, IndexFn index, AddrF
 #undef CAPE_STAGE_PIECE
 #undef CAPE_STAGE_LOAD
 #undef CAPE_STAGE_INDEX
-#undef CAPE_STAGE_DST
 #undef CAPE_STAGE_ISSUE
 #undef CAPE_STAGE_STORE
+#undef CAPE_STAGE_STORE1
+#undef CAPE_STAGE_KEEP
 }
 
 // all pieces of a record from one array: piece `sub` of record r = base + r * strideDoubles + 2 * (firstPiece + sub)
@@ -241,7 +260,7 @@ __device__ __forceinline__ void staged_for_each(int N, const double* base, int s
     staged_for_each_src<PIECES, DEPTH>(
             N, [&](int e, int) { return index(e); },
             [&](int rec, int sub) { return reinterpret_cast<const double2*>(base + (size_t)rec * strideDoubles + 2 * (firstPiece + sub)); },
-            s_buf, lane, prep, load, fold, prof);
+            [](int) { return true; }, stage_park_records<PIECES>, s_buf, lane, prep, load, fold, prof);
 }
 
 template <int PIECES, int DEPTH, typename IndexFn, typename Load, typename Fold>
