@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <random>
@@ -50,6 +51,12 @@ int fail(int code, const std::string& msg)
         if (_e != hipSuccess)                                                                                \
             return fail(CAPE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                    \
     } while (0)
+
+// completion signal of a chain whose results live in pinned host memory (see wait_results)
+__global__ void cape_signal_kernel(uint32_t* flag, uint32_t seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 constexpr int kHostResultFrames = 8; // see cape_handle_s::resultsOnHost
 constexpr int kRngTable = 40000; // upper bound on RANSAC draws per frame (cylinder section)
@@ -140,6 +147,11 @@ struct cape_handle_s
     // pinned, device-mapped HOST memory: the grow kernel's stores go straight over PCIe (posted writes), and reading the
     // results is a stream synchronisation + a host memcpy instead of three device-to-host copies
     bool resultsOnHost = false;
+    // resultsOnHost: a one-thread kernel behind every chain stores a sequence number into this pinned word; whoever reads
+    // the results spins on it instead of going through the runtime's stream synchronisation (wait_results)
+    uint32_t* doneFlag = nullptr;
+    uint32_t doneSeq = 0;      // sequence number of the last chain enqueued
+    bool doneArmed = false;    // a chain with a signal behind it is (or was) in flight
     // host staging for cape_extract_host
     float* depthStage = nullptr;
     // timing: one event triple per timed cape_extract, folded lazily by cape_get_timings
@@ -240,6 +252,7 @@ void free_all(cape_handle_s* h)
         (void)hipHostFree(h->planeLabels);
         (void)hipHostFree(h->cylLabels);
         (void)hipHostFree(h->boundary);
+        (void)hipHostFree(h->doneFlag);
     }
     else
     {
@@ -425,6 +438,38 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     }
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[3], st));
+    if (h->resultsOnHost && h->doneFlag)
+    {
+        hipLaunchKernelGGL(cape_signal_kernel, dim3(1), dim3(1), 0, st, h->doneFlag, ++h->doneSeq);
+        CAPE_HIP_TRY(hipGetLastError());
+        h->doneArmed = true;
+    }
+    return CAPE_OK;
+}
+
+// Results in pinned host memory: wait for the signal word of the last chain.  The runtime's hipStreamSynchronize costs
+// ~10 us of wake-up on top of the kernels when the whole call is ~130 us; a spin on a pinned word costs a PCIe write.
+// If the word does not arrive in time (a faulted kernel, a descheduled process) the stream synchronisation takes over
+// and reports whatever went wrong.
+int wait_results(cape_handle_s* h)
+{
+    if (h->doneArmed && h->doneFlag)
+    {
+        volatile const uint32_t* flag = h->doneFlag;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin)
+        {
+            if (*flag == h->doneSeq)
+                return CAPE_OK;
+            __builtin_ia32_pause();
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
+                break;
+        }
+    }
+    if (h->hasLastStream)
+        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    else
+        CAPE_HIP_TRY(hipDeviceSynchronize());
     return CAPE_OK;
 }
 
@@ -545,6 +590,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->planeLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->cylLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), B * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->doneFlag), 64, hipHostMallocMapped));
+        *h->doneFlag = 0;
     }
     else
     {
@@ -771,6 +818,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     h->pa.depth = depth_dev;
     h->pa.depth_u16 = depth_u16;
     h->pa.u16_scale = scale;
+    h->doneArmed = false; // only launch_chain puts a signal behind the work; every other path drains the stream
     if (h->cfg.sub_batches > 1 && n_frames >= 2 * h->cfg.sub_batches)
     {
         // fork: both internal streams wait for everything already enqueued on the caller's stream
@@ -880,11 +928,9 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
     const size_t n = (size_t)n_frames, C = (size_t)h->cells;
     if (h->resultsOnHost)
     {
-        // the kernels wrote into pinned host memory: once the handle's stream has drained the data is simply there
-        if (h->hasLastStream)
-            CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
-        else
-            CAPE_HIP_TRY(hipDeviceSynchronize());
+        // the kernels wrote into pinned host memory: once the chain's signal word has arrived the data is simply there
+        if (const int rc = wait_results(h); rc != CAPE_OK)
+            return rc;
         if (records)
             std::memcpy(records, h->records, n * sizeof(cape_frame_record));
         if (plane_labels)
@@ -915,10 +961,8 @@ int cape_host_results(cape_handle h, const cape_frame_record** records, const in
     if (!h->resultsOnHost)
         return fail(CAPE_ERR_UNSUPPORTED, "results live in device memory for this handle (max_batch > 8): use cape_copy_results");
     CAPE_ON_DEVICE(h);
-    if (h->hasLastStream)
-        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
-    else
-        CAPE_HIP_TRY(hipDeviceSynchronize());
+    if (const int rc = wait_results(h); rc != CAPE_OK)
+        return rc;
     if (records)
         *records = h->records;
     if (plane_labels)
