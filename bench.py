@@ -188,6 +188,7 @@ def main():
     ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B_max, sub_batches=args.sub_batches, **intr)
     stream = torch.cuda.current_stream().cuda_stream
     gather = args.gather if multi else "none"
+    gather_note = ""
     lay, recv, works, local_view = None, None, [None, None], [None, None]
     if gather != "none":
         # planes_per_frame = 16 is a budget for the whole shard (a frame may hold up to 64); an overflow would be
@@ -195,8 +196,22 @@ def main():
         lay = ex.gather_configure(B_max, planes_per_frame=16, cylinders_per_frame=8)
         recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device="cuda") for _ in range(2)]
         if gather == "native":
-            uid = cdist.broadcast_unique_id(ex.comm_unique_id, rank, device="cuda")
-            ex.comm_init(uid, rank, world)
+            # The C layer's communicator (librccl through dlopen, ncclCommInitRank).  If that does not come up on every
+            # rank -- a library that cannot be resolved, an init that fails -- all ranks agree to route the same packed
+            # bytes through torch.distributed instead, and the JSON line says which path ran.
+            err = ""
+            try:
+                uid = cdist.broadcast_unique_id(ex.comm_unique_id, rank, device="cuda")
+                ex.comm_init(uid, rank, world)
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong, the bench must still report a number
+                err = f"{type(e).__name__}: {e}"
+            okflag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+            if int(okflag.item()) == 0:
+                gather = "torch"
+                gather_note = "native RCCL gather unavailable" + (f" ({err})" if err else " on another rank") + ": torch.distributed used"
+                if rank == 0:
+                    print("bench.py: " + gather_note, file=sys.stderr)
     step_no = [0]
 
     def step():
@@ -346,6 +361,9 @@ def main():
             },
         }
         if gather_check is not None:
+            gather_check["path"] = gather
+            if gather_note:
+                gather_check["note"] = gather_note
             out["gather"] = gather_check
         if world == 1 and not args.no_cpu_baseline:
             n_host = min(U, 64)

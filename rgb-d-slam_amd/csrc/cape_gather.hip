@@ -20,6 +20,7 @@
 // never load it and a process that already holds torch's copy binds to that one.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <dlfcn.h>
 
 #include <string>
@@ -230,17 +231,23 @@ const char* rccl_load()
     // RTLD_NOLOAD first: a process that already holds an RCCL (torch ships its own librccl.so) must keep ONE copy
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* lib = nullptr;
-    for (const char* n : names)
+    if (const char* forced = std::getenv("CAPE_RCCL_LIB")) // an explicit library (deployments with several ROCm trees)
+        lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    else
+    {
+        for (const char* n : names)
+            if (!lib)
+                lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!lib)
+                lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (!lib)
-            lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    for (const char* n : names)
-        if (!lib)
-            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!lib)
-        lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!lib)
     {
-        g_rccl.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+        const char* why = dlerror(); // (a second call would return null: the first one clears the message)
+        g_rccl.error = std::string("librccl.so not found: ") + (why ? why : "");
         return g_rccl.error.c_str();
     }
     auto sym = [&](const char* n) { return dlsym(lib, n); };

@@ -63,3 +63,24 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "cape_oracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
+
+
+def test_unresolvable_rccl_is_an_error_not_a_crash(hip_library):
+    """cape_comm_unique_id with a librccl that cannot be opened (CAPE_RCCL_LIB) returns CAPE_ERR_UNSUPPORTED with the
+    loader's message; it used to dereference the second, null, dlerror().  Needs no GPU: the loader runs first."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import cape_amd\n"
+        "L = cape_amd.load_library()\n"
+        "buf = (C.c_ubyte * cape_amd.COMM_ID_BYTES)()\n"
+        "rc = L.cape_comm_unique_id(buf)\n"
+        "print(rc, L.cape_last_error().decode())\n" % os.path.join(ROOT, "rgb-d-slam_amd", "python"))
+    env = dict(os.environ, CAPE_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-800:]
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) == -5 and "librccl.so not found" in msg and "/nonexistent/librccl.so" in msg
