@@ -32,6 +32,9 @@ constexpr int kChunk = kStageChunk; // cells staged per step of the ordered mome
 #ifndef CAPE_B_PLANE_WAVES
 #define CAPE_B_PLANE_WAVES 2 // waves per SIMD the plane-only instances are compiled for: 256 registers, nothing spills (3 = 168 registers spills ~50)
 #endif
+#ifndef CAPE_B_MSE_REGS
+#define CAPE_B_MSE_REGS 12 // cell MSEs a lane keeps in registers across the seed loop (x 64 lanes = cells covered)
+#endif
 #ifndef CAPE_B_WAVES_PER_GROUP
 #define CAPE_B_WAVES_PER_GROUP 4
 #endif
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
 
     // The cell MSEs never change: with up to 12 cells per lane (the 640x480 grid) they are fetched ONCE into registers
     // in exactly the lane <-> cell pattern of the candidate scan, so picking a seed costs no memory round trip.
-    constexpr int kMseRegs = 12;
+    constexpr int kMseRegs = CAPE_B_MSE_REGS;
     const bool mseInRegs = C <= 64 * kMseRegs;
     const double* mseBase = p.cell_mse + cellBase;
     double mreg[kMseRegs];
