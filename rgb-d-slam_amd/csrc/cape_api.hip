@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <new>
@@ -460,7 +461,10 @@ int wait_results(cape_handle_s* h)
         for (int spin = 0;; ++spin)
         {
             if (*flag == h->doneSeq)
+            {
+                std::atomic_thread_fence(std::memory_order_acquire); // the results are read after the word
                 return CAPE_OK;
+            }
             __builtin_ia32_pause();
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
                 break;
