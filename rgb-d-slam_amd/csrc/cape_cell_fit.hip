@@ -86,6 +86,32 @@ __device__ __forceinline__ float acc_px(float zr, double a, double b, PxAcc& A)
     return z; // the clamped depth (+0 if invalid): what the exactness guard looks at
 }
 
+// The same pixel in the streaming kernel, WITHOUT the validity test: a compare, a select and a carry add are three
+// four-cycle instructions per pixel (profiles/r02_valu_rates.txt).  A pixel that is +0 adds +0 to every sum on its own, and
+// a cell that holds anything else the reference would call invalid or that poisons a sum -- a negative depth, -0, NaN,
+// +inf: every bit pattern above 0x7F7FFFFF -- is caught by the per-cell range guard (its largest pattern is tracked anyway)
+// and redone by A2 with acc_px in the reference's order.  What is left to count is the non-zero pixels: v_min_u32 + v_add_u32.
+// The count can only be too HIGH in a cell the guard rejects, never too low, so A2's "enough points for the in-order
+// pass?" test errs on the side of redoing the cell.  Returns the bit pattern for the guard.
+__device__ __forceinline__ uint32_t acc_px_fast(float z, double a, double b, PxAcc& A)
+{
+    const uint32_t bits = __float_as_uint(z);
+    A.n += min(bits, 1u);
+    const double zd = (double)z;
+    const float x = (float)(zd * a);
+    const float y = (float)(zd * b);
+    A.S[0] += (double)x;
+    A.S[1] += (double)y;
+    A.S[2] += zd;
+    A.S[3] += (double)(x * x);
+    A.S[4] += (double)(y * y);
+    A.S[5] += (double)(z * z);
+    A.S[6] += (double)(x * y);
+    A.S[7] += (double)(y * z);
+    A.S[8] += (double)(x * z);
+    return bits;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Two horizontally adjacent pixels at once: the six f32 products of both pixels are three v_pk_mul_f32 pairs each
@@ -133,11 +159,12 @@ __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, do
     acc_px2(v.x, v.y, a0, a1, b, A);
     acc_px2(v.z, v.w, a2, a3, b, A);
 #else
-    const uint32_t bx = __float_as_uint(acc_px(v.x, a0, b, A));
-    const uint32_t by = __float_as_uint(acc_px(v.y, a1, b, A));
-    const uint32_t bz = __float_as_uint(acc_px(v.z, a2, b, A));
-    const uint32_t bw = __float_as_uint(acc_px(v.w, a3, b, A));
-    // z range of the valid pixels (exactness guard), on the clamped depths: v_max3_u32 / v_min3_u32 + four v_sub_u32
+    const uint32_t bx = acc_px_fast(v.x, a0, b, A);
+    const uint32_t by = acc_px_fast(v.y, a1, b, A);
+    const uint32_t bz = acc_px_fast(v.z, a2, b, A);
+    const uint32_t bw = acc_px_fast(v.w, a3, b, A);
+    // z range of the pixels (exactness guard) on the bit patterns: v_max3_u32 / v_min3_u32 + four v_sub_u32; a pattern with
+    // the sign bit or above +inf's ends up in zmaxBits and fails the guard
     A.zmaxBits = max(max(A.zmaxBits, bx), max(by, max(bz, bw)));
     A.zminBits1 = min(min(A.zminBits1, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
 #endif
@@ -424,7 +451,8 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     // back to depths: with n > 0 at least one pixel was valid, so the minimum is a real pattern - 1
     const float zmin = __uint_as_float(zminBits1 + 1u), zmax = __uint_as_float(zmaxBits);
     const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);
-    const bool exact_ok = (n == 0) || (zmax * rab <= 512.0f * zmin);
+    // all pixels +0 or positive and finite (acc_px_fast's precondition), and their range within the exactness bound
+    const bool exact_ok = zmaxBits <= 0x7F7FFFFFu && ((n == 0) || (zmax * rab <= 512.0f * zmin));
 
     const size_t gcell = (size_t)frame * p.cells + fRow * p.hCells + fCol;
     CellAux aux;

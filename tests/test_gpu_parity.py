@@ -137,6 +137,49 @@ def test_edge_inputs(oracle_mod):
     ex.close()
 
 
+def test_sparse_invalid_patterns_inside_valid_cells(oracle_mod):
+    """The streaming kernel accumulates pixels without the reference's `z > 0` test and leaves every cell that holds a
+    bit pattern the test would reject (negative, -0, NaN) or that cannot be summed exactly (+inf) to the in-order pass
+    of the per-cell kernel.  Sprinkle such values thinly over cells that stay valid (>= 200 good pixels, continuous):
+    every observable has to match the oracle bit for bit, counts included."""
+    from cape_amd import Extractor, synth
+
+    rng = np.random.default_rng(19)
+    base = synth.room(seed=8, frame=3)
+    frames = []
+    for value, density in ((-1200.0, 0.02), (-0.0, 0.05), (np.nan, 0.01), (np.inf, 0.004), (-np.inf, 0.01)):
+        f = base.copy()
+        mask = rng.random(f.shape) < density
+        mask[:, 10::20] = False   # keep the centre row / column samples of the continuity scan clean
+        mask[10::20, :] = False
+        f[mask] = value
+        frames.append(f)
+    mixed = base.copy()
+    for value in (-3.0, -0.0, np.nan):
+        m = rng.random(mixed.shape) < 0.01
+        m[:, 10::20] = False
+        m[10::20, :] = False
+        mixed[m] = value
+    frames.append(mixed)
+    frames = np.stack(frames).astype(np.float32)
+    intr = _intr("room")
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    ex = Extractor(640, 480, cylinders=False, max_batch=len(frames), **intr)
+    n = ex.extract_host(frames)
+    res = ex.results(n)
+    for f in range(n):
+        r = orc.run(frames[f])
+        if f != 3:  # (+inf is a valid depth for the reference: its sums are inf / NaN, compared as labels and counts)
+            compare_frame(r, ex, res, f)
+        cs = ex.cell_stats(f)
+        assert np.array_equal(cs["point_count"], r.n) and np.array_equal(cs["planar"], r.planar)
+        assert np.array_equal(res.plane_labels[f], r.plane_labels)
+    # the damaged cells really took the in-order pass (CAPE_FRAME_INORDER_CELLS), and planes were still found around them
+    assert (res.records["header"]["status"][[0, 1, 2, 4, 5]] & 0x10).all()
+    assert (res.records["header"]["n_planes"][[0, 1, 2, 4, 5]] >= 1).all()
+    ex.close()
+
+
 def test_parity_1280x960(oracle_mod):
     from cape_amd import Extractor, synth
 
