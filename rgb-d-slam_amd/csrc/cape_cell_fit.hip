@@ -33,6 +33,13 @@ namespace cape {
 #ifndef CAPE_A_DEPTH
 #define CAPE_A_DEPTH 1   // prefetch groups in flight ahead of the arithmetic (1 = the ping-pong loop)
 #endif
+#ifndef CAPE_A_RING
+#define CAPE_A_RING 0    // 1: float32 image rows travel global -> LDS by LDS-DMA into a per-wave ring, CAPE_A_RING_AHEAD rows ahead
+#endif                   // of the arithmetic, at no register cost.  Bit-identical; measured 1.464 ms (4 ahead) / 1.466 ms (5 ahead)
+                         // against 1.442 ms for the register ping-pong loop: the kernel is not waiting for memory
+#ifndef CAPE_A_RING_AHEAD
+#define CAPE_A_RING_AHEAD 4
+#endif
 #ifndef CAPE_A_WAVES
 #define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
 #endif
@@ -197,6 +204,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
     __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
+    __shared__ double s_brow[2 * kCell]; // the row factors of the workgroup's two bands (ring variant: no vector load in the loop)
 
     const int t = threadIdx.x;
     const int frame = blockIdx.x / p.pairsPerFrame;
@@ -224,6 +232,16 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     }
     __syncthreads();
 #endif
+    if constexpr (!U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC)
+    {
+        if (t < 2 * kCell)
+        {
+            const int bnd = pair * 2 + t / kCell;
+            const int cr = (bnd < p.bandsPerFrame ? bnd : p.bandsPerFrame - 1) / p.segsPerRow;
+            s_brow[t] = p.brow[cr * kCell + (t % kCell)];
+        }
+        __syncthreads();
+    }
     // ------------------------------------------------------------------ streaming accumulation
     PxAcc A;
 #pragma unroll
@@ -306,6 +324,94 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                     s_corner[lcell * 3 + 2] = buf[i].z;
             }
         };
+        constexpr bool kRing = !U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC;
+        if constexpr (kRing)
+        {
+            // ---- LDS-DMA ring.  The register ping-pong below keeps one group (two rows) in flight per wave, ~22 KB per CU,
+            // and a load takes a couple of microseconds under this kernel's own traffic: ~30 KB are needed.  Deeper
+            // REGISTER prefetch costs occupancy (measured slower).  global_load_lds_dwordx4 moves a row (1 KiB per wave:
+            // lane l's 16 bytes land at base + 16 l) straight into LDS without touching a register, so each wave keeps
+            // kAhead rows in flight in a private ring carved out of s_part, which is idle until the epilogue.  A wave
+            // reads back only what it loaded itself: no barrier, just its own vmcnt -- counted by hand, because hipcc
+            // drains vmcnt to 0 around LDS-DMA it can see (cdna_hip_programming.md); hence no other vector memory
+            // instruction may sit in this loop (the row factors come from s_brow).
+            constexpr int kAhead = CAPE_A_RING_AHEAD, kSlots = kAhead; // the row held in registers has already left its slot: row k lives in slot k mod kAhead
+            static_assert((kThreadsA / 64) * kSlots * 1024 <= (int)sizeof(s_part), "the ring must fit in s_part");
+            const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+            char* ring = reinterpret_cast<char*>(s_part) + wave * kSlots * 1024;
+            const uint32_t ringLds = (uint32_t)reinterpret_cast<uintptr_t>(ring); // LDS byte offset = low half of the flat address
+            const float* myCol = frameBase + pixOff32;                             // the lane's float4 column, row 0 of the band
+            const double* browL = s_brow + bsel * kCell;
+            auto issue_row = [&](int r, int slot) { // r, slot uniform
+                const float* g = myCol + (size_t)r * W;
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ringLds + (uint32_t)slot * 1024u);
+                uint32_t keep; // M0 = LDS base of the transfer; the compiler's own M0 is put back
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(g), "s"(m0v)
+                             : "memory");
+            };
+            auto take_row = [&](int slot) {
+                return *reinterpret_cast<const float4*>(ring + slot * 1024 + (t & 63) * 16);
+            };
+            auto sum_row = [&](const float4& v, int r) {
+                acc_f4(v, a0, a1, a2, a3, browL[r], A);
+                // samples for the continuity cross scan and the tolerance corners
+                if (r == kCell / 2)
+                    *reinterpret_cast<float4*>(&s_row[lcell * kCell + 4 * j]) = v;
+                if (j == 2)
+                    s_col[lcell * kCell + r] = v.z; // pixel column 10 of the cell
+                if (r == 0 && j == 0)
+                    s_corner[lcell * 3] = v.x;
+                if (r == kCell - 1 && j == 4)
+                    s_corner[lcell * 3 + 1] = v.w;
+                if (r == kCell / 2 && j == 2)
+                    s_corner[lcell * 3 + 2] = v.z;
+            };
+            // the column factors must have ARRIVED before the first transfer is issued: a compiler-visible load still pending
+            // at the loop head makes hipcc wait for vmcnt(0) in every iteration, which also drains the ring
+            asm volatile("" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+#pragma unroll
+            for (int r = 0; r < kAhead; ++r)
+                issue_row(r, r);
+            // one row is held in registers ahead of the arithmetic, so that its LDS read is not exposed either: while row r is
+            // summed, row r + 1 is on its way out of LDS and rows r + 2 .. r + kAhead on their way in
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kAhead - 1) : "memory");
+            float4 cur = take_row(0);
+            int slot = 0; // slot of the row held in `cur`
+#pragma unroll 1
+            for (int r = 0; r + kAhead < kCell; ++r)
+            {
+                const int nextSlot = (slot + 1 == kSlots) ? 0 : slot + 1;
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kAhead - 2) : "memory"); // row r + 1 has landed
+                const float4 nxt = take_row(nextSlot);
+                issue_row(r + kAhead, slot); // the slot of row r is free: the row is in registers
+                sum_row(cur, r);
+                cur = nxt;
+                slot = nextSlot;
+            }
+            // the last kAhead rows: nothing left to request, one row fewer in flight per step
+            {
+                int ns = (slot + 1 == kSlots) ? 0 : slot + 1;
+#define CAPE_A_TAIL_STEP(N, rowFromEnd)                                   \
+    {                                                                     \
+        asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory");           \
+        const float4 nxt = take_row(ns);                                  \
+        sum_row(cur, kCell - (rowFromEnd));                               \
+        cur = nxt, ns = (ns + 1 == kSlots) ? 0 : ns + 1;                  \
+    }
+                if constexpr (kAhead >= 6) CAPE_A_TAIL_STEP(4, 6)
+                if constexpr (kAhead >= 5) CAPE_A_TAIL_STEP(3, 5)
+                CAPE_A_TAIL_STEP(2, 4)
+                CAPE_A_TAIL_STEP(1, 3)
+                CAPE_A_TAIL_STEP(0, 2)
+#undef CAPE_A_TAIL_STEP
+                sum_row(cur, kCell - 1);
+            }
+            static_assert(kAhead >= 4 && kAhead <= 6, "the tail above is written out for four to six rows ahead");
+        }
+        else
+        {
 #if CAPE_A_DEPTH == 1
         load_group(bufA, 0);
 #pragma unroll 1
@@ -343,7 +449,10 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         if (g + 1 < kGroups)
             sum_group(bufB, g + 1);
 #endif
+        } // !kRing
     }
+    if constexpr (!U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC)
+        __syncthreads(); // every wave is done with its ring before the partials overwrite s_part
 #if CAPE_A_LDS_ATOMIC
     if (active)
     {
