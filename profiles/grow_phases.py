@@ -15,11 +15,14 @@ NAMES = ["hist + edge-mask prologue", "hist argmax", "candidate scan", "seed pic
          "cyl: plane fit", "cyl: select+labels", "cov staged: consume + other sets", "#RANSAC rounds", "#cells in region", "#inliers", "#hypotheses", "cyl: cov pass 1", "cyl: cov pass 2", "cov staged: hand-over of set a (vmcnt wait)", "cov staged: request of set a"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 scene = sys.argv[2] if len(sys.argv) > 2 else "room"
-u = synth.stream(scene, seed=100, n_frames=16)
+W = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+H = int(sys.argv[5]) if len(sys.argv) > 5 else 480
+u = synth.stream(scene, seed=100, n_frames=16, width=W, height=H)
 d = torch.from_numpy(u).cuda().repeat(B // 16, 1, 1).contiguous()
 intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+intr = {k: v * W / 640.0 for k, v in intr.items()}
 cyl = len(sys.argv) > 3 and sys.argv[3] == "cyl"
-ex = Extractor(640, 480, max_batch=B, cylinders=cyl, **intr)
+ex = Extractor(W, H, max_batch=B, cylinders=cyl, **intr)
 ex.extract_device(d.data_ptr(), B, torch.cuda.current_stream().cuda_stream)
 cyc = ex.debug_cycles(B).astype(np.float64)
 tot = cyc[:, :23].sum(1) + cyc[:, 28:30].sum(1)  # slots 23, 30, 31 are sub-intervals of the covariance passes

@@ -128,6 +128,12 @@ constexpr int kCylCacheRounds = 12;
     if (j0 + lane + 64 * (k) < m)                                                                            \
         c.s_best[cqi##k] = (unsigned char)((inlBits >> (k)) & 1u);
 
+// streamed path (more cells than the register cache holds): the inlier flags of the hypothesis being scored go to s_cur, so
+// that a winner copies them instead of fetching and scoring every cell a second time
+#define CAPE_CYL_CURFLAGS(k)                                                                                 \
+    if (j0 + lane + 64 * (k) < m)                                                                            \
+        c.s_cur[cqi##k] = (unsigned char)((inlBits >> (k)) & 1u);
+
 // relative distance between the tree-order sum and the ordered sum of m <= 4096 non-negative doubles: each is within
 // (m - 1) * 2^-53 <= 2^-41 of the exact sum.  A test build widens it (-DCAPE_CYL_EPS=0.25) to drive the exact path.
 #ifndef CAPE_CYL_EPS
@@ -417,10 +423,14 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 }
                 else
                 {
-                    for (int j0 = 0; j0 < m; j0 += 256)
+                    // twelve rounds (768 cells) per trip, all 36 loads requested before the first distance: every trip exposes
+                    // one memory round trip, and a lone wave has nothing else to hide it with
+                    for (int j0 = 0; j0 < m; j0 += 64 * kCylCacheRounds)
                     {
-                        CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                        CAPE_CYL_SCORE4(0, 1, 2, 3)
+                        CAPE_CYL_ROUNDS(CAPE_CYL_FETCH)
+                        inlBits = 0;
+                        CAPE_CYL_SCORE_ALL
+                        CAPE_CYL_ROUNDS(CAPE_CYL_CURFLAGS)
                     }
                 }
                 const int curCount = cyl_wave_sum(curLocal);
@@ -455,17 +465,11 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     }
                     else
                     {
-                        for (int j0 = 0; j0 < m; j0 += 256)
+                        CAPE_CYL_SYNC(); // the flags the scoring pass left in s_cur
+                        for (int jj = lane; jj < m; jj += 64)
                         {
-                            CAPE_CYL_TRIP(CAPE_CYL_FETCH)
-                            inlBits = 0;
-                            {
-                                int curLocal = 0;
-                                double psum = 0.0;
-                                CAPE_CYL_SCORE4(0, 1, 2, 3)
-                                (void)curLocal, (void)psum;
-                            }
-                            CAPE_CYL_TRIP(CAPE_CYL_FLAGS)
+                            const int i = c.s_ids[jj];
+                            c.s_best[i] = c.s_cur[i];
                         }
                     }
                     prevBestCount = bestCount; // inlierIndexes now holds the previous best (swap)
