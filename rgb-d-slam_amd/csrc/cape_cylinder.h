@@ -136,6 +136,9 @@ constexpr int kCylCacheRounds = 12;
 
 // relative distance between the tree-order sum and the ordered sum of m <= 4096 non-negative doubles: each is within
 // (m - 1) * 2^-53 <= 2^-41 of the exact sum.  A test build widens it (-DCAPE_CYL_EPS=0.25) to drive the exact path.
+#ifndef CAPE_CYL_PROJ_ROUNDS
+#define CAPE_CYL_PROJ_ROUNDS 4
+#endif
 #ifndef CAPE_CYL_EPS
 #define CAPE_CYL_EPS 0x1p-40
 #endif
@@ -243,11 +246,12 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
 
     // ---- projection on the plane orthogonal to the axis (:107-125); four rounds (256 cells) per trip with the sixteen
     //      16-byte loads of a trip requested before the first result is needed: one memory round trip per trip
-    for (int j0 = 0; j0 < N; j0 += 256)
+    constexpr int kProjRounds = CAPE_CYL_PROJ_ROUNDS; // rounds of 64 cells whose loads are requested together
+    for (int j0 = 0; j0 < N; j0 += 64 * kProjRounds)
     {
-        double2 q0[4], q1[4], q2[4], q3[4]; // (nx ny) (nz d) (cx cy) (cz mse) of cell_plane
+        double2 q0[kProjRounds], q1[kProjRounds], q2[kProjRounds], q3[kProjRounds]; // (nx ny) (nz d) (cx cy) (cz mse) of cell_plane
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < kProjRounds; ++k)
         {
             const int j = j0 + lane + 64 * k;
             const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)c.s_list[j < N ? j : 0] * kPlaneStride);
@@ -258,7 +262,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < kProjRounds; ++k)
         {
             const int j = j0 + lane + 64 * k;
             if (j < N)
@@ -556,11 +560,12 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         // The per-cell squared distances are independent: all lanes compute them (cx, cy, cz straight from cell_plane).
         auto mse_addends = [&](bool park) {
             double ps = 0.0;
-            for (int i0 = 0; i0 < N; i0 += 256)
+            constexpr int kMseRounds = 2 * CAPE_CYL_PROJ_ROUNDS;
+            for (int i0 = 0; i0 < N; i0 += 64 * kMseRounds)
             {
-                double2 w0[4], w1[4]; // (cx cy) (cz mse) of cell_plane
+                double2 w0[kMseRounds], w1[kMseRounds]; // (cx cy) (cz mse) of cell_plane
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < kMseRounds; ++k)
                 {
                     const int i = i0 + lane + 64 * k;
                     const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)c.s_list[i < N ? i : 0] * kPlaneStride);
@@ -569,7 +574,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < kMseRounds; ++k)
                 {
                     const int i = i0 + lane + 64 * k;
                     if (i < N)
