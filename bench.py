@@ -91,6 +91,89 @@ def cpu_baseline(unique_frames, intr, budget_s=12.0, cylinders=False, scene="roo
     }
 
 
+def self_spawn(n_gpus):
+    """Re-run this very command line as N ranks under torch.distributed.run and forward rank 0's JSON line.
+    Everything else the children print goes to stderr, so stdout carries exactly one line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, CAPE_BENCH_SPAWNED="1")
+    env.pop("CAPE_BENCH_FORCE_SPAWN", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n_gpus}-rank run failed (exit code {proc.returncode}, JSON line {'present' if line else 'absent'})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def parity_check(ex, frames_host, intr, cylinders, n):
+    """The work proves itself: the first `n` frames of the LAST timed step (their results are still on the device) against
+    the CPU oracle run on the very same frames -- label grids, counts, and every plane-segment record bit for bit.  The
+    oracle is the checker here, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import cape_oracle_py as O
+
+    n = min(n, len(frames_host))
+    H, W = frames_host.shape[1:]
+    res = ex.results(n, with_boundary=False)
+    orc = O.Oracle(W, H, cylinders=cylinders, **intr)
+    labels_equal = counts_equal = segments_bitwise = cylinders_bitwise = True
+    n_planes = n_segments = n_cyl = 0
+
+    def bits(a):
+        return np.ascontiguousarray(a).view(np.uint64)
+
+    for f in range(n):
+        r = orc.run(frames_host[f])
+        hdr = res.records["header"][f]
+        labels_equal &= bool(np.array_equal(res.plane_labels[f], r.plane_labels) and np.array_equal(res.cyl_labels[f], r.cyl_labels))
+        counts_equal &= bool(hdr["n_plane_segments"] == len(r.segments) and hdr["n_planes"] == len(r.planes)
+                             and hdr["n_cylinders"] == len(r.cylinders) and hdr["n_seeds"] == len(r.seeds))
+        segs = res.segments(f)
+        if len(segs) == len(r.segments) and len(segs):
+            o = r.segments
+            segments_bitwise &= bool(
+                np.array_equal(bits(segs["normal"]), bits(o[:, 0:3])) and np.array_equal(bits(segs["d"]), bits(o[:, 3]))
+                and np.array_equal(bits(segs["centroid"]), bits(o[:, 4:7])) and np.array_equal(bits(segs["mse"]), bits(o[:, 7]))
+                and np.array_equal(bits(segs["score"]), bits(o[:, 8])) and np.array_equal(bits(segs["sums"]), bits(o[:, 9:18]))
+                and np.array_equal(segs["merge_label"], r.merge_labels))
+        elif len(segs) != len(r.segments):
+            segments_bitwise = False
+        kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+        kept = kept[kept["kept"] == 1]
+        if len(kept) == len(r.cylinders) and len(kept):
+            cylinders_bitwise &= bool(np.array_equal(bits(kept["axis"]), bits(r.cylinders[:, 0:3])))
+        elif len(kept) != len(r.cylinders):
+            cylinders_bitwise = False
+        n_planes += int(hdr["n_planes"])
+        n_segments += int(hdr["n_plane_segments"])
+        n_cyl += int(hdr["n_cylinders"])
+    return {"frames": n, "labels_equal": labels_equal, "counts_equal": counts_equal, "segments_bitwise": segments_bitwise,
+            "cylinders_bitwise": cylinders_bitwise, "planes": n_planes, "plane_segments": n_segments, "cylinders": n_cyl,
+            "checker": "oracle/libcape_oracle.so on the first frames of the last timed step"}
+
+
+def parity_ok(pc):
+    return bool(pc["labels_equal"] and pc["counts_equal"] and pc["segments_bitwise"] and pc["cylinders_bitwise"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,14 +199,27 @@ def main():
     ap.add_argument("--host-synth", action="store_true", help="render the frames with the numpy generators (slow; parity fixtures use these)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=0, help="cape_config.sub_batches (0 = one kernel chain per step)")
+    ap.add_argument("--planes-per-frame", type=int, default=0,
+                    help="N>1: plane budget of the packed payload per frame (0 = measured on the stream: mean x 1.25 + 1)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the self-spawning launcher even at --gpus 1 (what `--gpus N` does for N > 1 when no "
+                         "launcher started this process); also CAPE_BENCH_FORCE_SPAWN=1")
+    ap.add_argument("--gather-root", action="store_true",
+                    help="N>1: gather the packed lists to rank 0 only (cape_gather_primitives_root) instead of all-gathering them")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the in-run comparison of the last step's results with the CPU oracle")
+    ap.add_argument("--no-cylinders-on", action="store_true",
+                    help="N=1 default workload: skip the extra 'cylinders_on' leg (same stream with the reference's unconditional cylinder branch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn or os.environ.get("CAPE_BENCH_FORCE_SPAWN") == "1"):
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, exactly the command line the driver would use) and hand its single JSON line on
+        raise SystemExit(self_spawn(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
 
     import numpy as np
     import torch
@@ -190,11 +286,30 @@ def main():
     gather = args.gather if multi else "none"
     gather_note = ""
     lay, recv, works, local_view = None, None, [None, None], [None, None]
+    planes_budget, budget_note = 16, "default"
     if gather != "none":
-        # planes_per_frame = 16 is a budget for the whole shard (a frame may hold up to 64); an overflow would be
-        # reported in the packed header, and is checked after the timed region
-        lay = ex.gather_configure(B_max, planes_per_frame=16, cylinders_per_frame=8)
-        recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+        # The payload is a fixed byte count per rank (what the collective needs), sized by a plane budget for the whole
+        # shard.  The budget comes from the stream itself: one un-gathered pass, the mean number of planes per frame over
+        # all ranks, 25 % head-room (an overflow would be reported in the packed header and is checked after the timed
+        # region; planes_per_frame = 64 can never overflow)
+        ex.extract_device(depth.data_ptr(), B, stream) if not args.u16 else ex.extract_device_u16(depth.data_ptr(), 0.2, B, stream)
+        n_pl0, n_cy0, _ = ex.count_primitives(B)  # cape_count_primitives: a device-side reduction over the batch's headers
+        cnt = torch.tensor([float(n_pl0), float(n_cy0), float(B)], dtype=torch.float64, device="cuda")
+        mx = torch.tensor([n_pl0 / B, n_cy0 / B], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        if args.planes_per_frame > 0:
+            planes_budget, budget_note = args.planes_per_frame, "--planes-per-frame"
+        else:
+            # the budget is per SHARD, so it is the fullest shard's mean that must fit
+            planes_budget = int(min(64, np.ceil(float(mx[0]) * 1.25) + 1))
+            budget_note = f"measured: fullest shard holds {float(mx[0]):.2f} planes per frame (stream mean {float(cnt[0] / cnt[2]):.2f}), x 1.25 + 1"
+        cyl_budget = int(min(64, np.ceil(float(mx[1]) * 1.25) + 1)) if args.cylinders else 1
+        lay = ex.gather_configure(B_max, planes_per_frame=planes_budget, cylinders_per_frame=cyl_budget)
+        if args.gather_root and gather == "native" and rank != 0:
+            recv = [None, None]  # ncclGather: only the root receives
+        else:
+            recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device="cuda") for _ in range(2)]
         if gather == "native":
             # The C layer's communicator (librccl through dlopen, ncclCommInitRank).  If that does not come up on every
             # rank -- a library that cannot be resolved, an init that fails -- all ranks agree to route the same packed
@@ -224,7 +339,10 @@ def main():
         if gather == "native":
             # pack kernels on this stream, ONE ncclAllGather on the handle's communication stream behind an event: the
             # collective of step k runs under the kernels of step k+1 (two staging slots, two receive buffers)
-            ex.gather(B, first, recv[step_no[0] & 1].data_ptr(), stream)
+            if args.gather_root:
+                ex.gather_root(B, first, 0, recv[step_no[0] & 1].data_ptr() if rank == 0 else 0, stream)
+            else:
+                ex.gather(B, first, recv[step_no[0] & 1].data_ptr(), stream)
             step_no[0] += 1
         elif gather == "torch":
             k = step_no[0] & 1
@@ -243,45 +361,102 @@ def main():
                 works[k].wait()
                 works[k] = None
 
+    def timed(n_steps, fn):
+        """barrier + device sync, n_steps x fn, drain, device sync + barrier: this rank's seconds"""
+        drain()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            fn()
+        drain()  # every gather has landed before the clock stops
+        torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0  # this rank's own work, before it waits for the others
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, t_own
+
+    def over_ranks(v):
+        """(max, min, list) of a per-rank scalar"""
+        if not multi:
+            return v, v, [v]
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        vals = [float(x.item()) for x in allv]
+        return max(vals), min(vals), vals
+
     for _ in range(args.warmup):
         step()
-    drain()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
     ex.reset_timings()
     ex.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()  # every gather has landed before the clock stops
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, own = timed(args.steps, step)
     ex.enable_timing(False)
     tm = ex.timings()
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if multi:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, _, _ = over_ranks(elapsed)                  # the contract's clock: max over ranks, barriers inside
+    own_max, own_min, own_all = over_ranks(own)
 
     gather_check = None
     if gather != "none":
         # outside the timed region: what arrived is every rank's shard, in rank order, nothing dropped
-        shards = cdist.unpack_gathered(recv[(step_no[0] - 1) & 1].cpu().numpy(), world, lay)
-        spans = [cdist.shard_range(total, r, world) for r in range(world)]
-        ok = all(sh.first_frame == spans[r][0] and int(sh.header["n_frames"]) == spans[r][1] - spans[r][0]
-                 for r, sh in enumerate(shards))
-        gather_check = {"ok": bool(ok), "frames": int(sum(int(sh.header["n_frames"]) for sh in shards)),
-                        "planes": int(sum(int(sh.header["n_planes_total"]) for sh in shards)),
-                        "overflow": int(max(int(sh.header["overflow"]) for sh in shards)),
-                        "bytes_per_rank": int(lay["bytes_per_rank"])}
-        if not ok:
-            raise SystemExit(f"gathered shards are inconsistent: {gather_check}")
+        got = recv[(step_no[0] - 1) & 1]
+        if got is None:
+            gather_check = {"ok": True}  # a non-root rank of the gather-to-root path receives nothing
+        else:
+            shards = cdist.unpack_gathered(got.cpu().numpy(), world, lay)
+            spans = [cdist.shard_range(total, r, world) for r in range(world)]
+            ok = all(sh.first_frame == spans[r][0] and int(sh.header["n_frames"]) == spans[r][1] - spans[r][0]
+                     for r, sh in enumerate(shards))
+            n_pl = int(sum(int(sh.header["n_planes_total"]) for sh in shards))
+            n_cy = int(sum(int(sh.header["n_cylinders_total"]) for sh in shards))
+            from cape_amd import PACKED_CYLINDER_DTYPE, PACKED_FRAME_DTYPE, PACKED_HEADER_DTYPE, PACKED_PLANE_DTYPE
+            used = (world * PACKED_HEADER_DTYPE.itemsize + total * PACKED_FRAME_DTYPE.itemsize + n_pl * PACKED_PLANE_DTYPE.itemsize
+                    + n_cy * PACKED_CYLINDER_DTYPE.itemsize)
+            gather_check = {"ok": bool(ok), "frames": int(sum(int(sh.header["n_frames"]) for sh in shards)),
+                            "planes": n_pl, "cylinders": n_cy,
+                            "overflow": int(max(int(sh.header["overflow"]) for sh in shards)),
+                            "bytes_per_rank": int(lay["bytes_per_rank"]),
+                            "payload_bytes_per_frame": lay["bytes_per_rank"] * world / total,
+                            "used_bytes_per_frame": used / total,
+                            "padding_frac": 1.0 - used / (lay["bytes_per_rank"] * world),
+                            "planes_per_frame_budget": planes_budget, "planes_per_frame_mean": n_pl / total,
+                            "budget_from": budget_note}
+            if not ok:
+                raise SystemExit(f"gathered shards are inconsistent: {gather_check}")
+        # what the exchange costs the step: the same steps again without it (same clock, max over ranks)
+        saved = gather
+        gather = "none"
+        k2 = max(1, min(args.steps, 10))
+        e2, _ = timed(k2, step)
+        e2, _, _ = over_ranks(e2)
+        gather = saved
+        gather_check["ms_per_step_without_gather"] = 1e3 * e2 / k2
+        gather_check["exposed_ms_per_step"] = 1e3 * (elapsed / args.steps - e2 / k2)
+
+    # ---- the work proves itself: first frames of the last timed step vs the CPU oracle (every rank checks its own shard)
+    parity = None
+    if not args.no_parity_check:
+        n_chk = min(U, 64)
+        if args.u16:
+            chk = unique_dev[:n_chk].cpu().numpy().view(np.uint16).astype(np.float32) * np.float32(0.2)
+        else:
+            chk = unique_dev[:n_chk].cpu().numpy()
+        if gather_check is not None:
+            step()  # the extra steps above ran the same frames; make the last batch's results current again
+            drain()
+            torch.cuda.synchronize()
+        parity = parity_check(ex, chk, intr, args.cylinders, n_chk)
+        _, okmin, _ = over_ranks(1.0 if parity_ok(parity) else 0.0)
+        parity["ranks_checked"] = world
+        parity["all_ranks_ok"] = bool(okmin == 1.0)
+        if okmin != 1.0:
+            print(f"bench.py: rank {rank}: results differ from the oracle: {parity}", file=sys.stderr)
+            if multi:
+                dist.destroy_process_group()
+            raise SystemExit(3)
 
     if rank == 0:
         frames_total = total * args.steps if multi else B * args.steps
@@ -360,8 +535,18 @@ def main():
                 "end_to_end_frac": frames_total / world * e2e_bytes_per_frame / elapsed / HBM_PEAK_BYTES_S,
             },
         }
+        out["ranks"] = {"ms_per_step_max": 1e3 * own_max / args.steps, "ms_per_step_min": 1e3 * own_min / args.steps,
+                        "ms_per_step": [1e3 * v / args.steps for v in own_all],
+                        "note": "each rank's own clock around its K steps (device-synchronised, before the closing barrier); "
+                                "`ms_per_step` above is the contract's clock: barriers inside, max over ranks",
+                        "launcher": "self-spawned (python bench.py --gpus N -> torch.distributed.run)" if os.environ.get("CAPE_BENCH_SPAWNED") == "1"
+                                    else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process")}
+        out["results"] = ("stay in HBM inside the timed region (records 19.5 KB + label grids 6 KB per frame: copying them out would cost "
+                          "more than the step over PCIe); the packed primitive lists (cape_pack_primitives) are what is meant to travel")
+        if parity is not None:
+            out["parity_check"] = parity
         if gather_check is not None:
-            gather_check["path"] = gather
+            gather_check["path"] = gather + (" gather-to-root" if args.gather_root else " all-gather")
             if gather_note:
                 gather_check["note"] = gather_note
             out["gather"] = gather_check
@@ -372,13 +557,47 @@ def main():
             else:
                 sample = unique_dev[:n_host].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, intr, cylinders=args.cylinders, scene=scene)
-        result_line = json.dumps(out)
     else:
-        result_line = None
+        out = None
 
     if gather == "native":
         ex.comm_destroy()
     ex.close()
+
+    if (rank == 0 and world == 1 and not multi and not args.cylinders and not args.no_cylinders_on and not args.u16
+            and not args.match and scene == "room"):
+        # The reference has no plane-only switch: its cylinder branch is unconditional (primitive_detection.cpp:385-388).
+        # Same stream, same frames, cylinders enabled -- outside the main timed region, reported next to `value`.
+        ex2 = Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, sub_batches=args.sub_batches, **intr)
+        k2 = max(10, min(args.steps, 20))
+        for _ in range(3):
+            ex2.extract_device(depth.data_ptr(), B, stream)
+        torch.cuda.synchronize()
+        ex2.reset_timings()
+        ex2.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            ex2.extract_device(depth.data_ptr(), B, stream)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        ex2.enable_timing(False)
+        t2 = ex2.timings()
+        c2 = max(1, t2["calls"])
+        cyl = {"value": B * k2 / e2, "unit": "frames/s", "steps": k2, "ms_per_step": 1e3 * e2 / k2,
+               "kernel_ms": {"cape_cell_moments_kernel": 1e3 * t2["cell_moments_s"] / c2,
+                             "cape_cell_plane_kernel": 1e3 * t2["cell_plane_s"] / c2,
+                             "cape_grow_kernel": 1e3 * t2["grow_s"] / c2},
+               "workload": f"the same {W}x{H} room stream with the reference's unconditional cylinder branch on "
+                           "(primitive_detection.cpp:385-388): the reference-faithful mode"}
+        if not args.no_parity_check:
+            pc2 = parity_check(ex2, unique_dev[:16].cpu().numpy(), intr, True, 16)
+            cyl["parity_check"] = pc2
+            if not parity_ok(pc2):
+                print(f"bench.py: cylinders-on results differ from the oracle: {pc2}", file=sys.stderr)
+                raise SystemExit(3)
+        ex2.close()
+        out["cylinders_on"] = cyl
+    result_line = json.dumps(out) if out is not None else None
     if multi:
         dist.destroy_process_group()
     if result_line is not None:

@@ -12,6 +12,13 @@
  * histogram.hpp:105-109, become error codes).  A handle is not thread-safe; distinct handles are.
  * All device work of a call is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as
  * void*; NULL = the null stream).
+ *
+ * Streams: ONE stream is in flight per handle -- the per-handle scratch and result buffers carry no per-buffer events.
+ * A call made with another stream than the previous call's is ordered behind the handle's earlier work ON THE DEVICE
+ * (hipStreamWaitEvent on a handle-owned event recorded behind every enqueue): it neither blocks the host nor touches
+ * the previous stream, which the caller may destroy as soon as it has no further use for it.  The stream of the LAST
+ * call must stay alive until that work has been waited for (cape_copy_results / cape_host_results / a stream
+ * synchronisation of the caller's) -- the usual HIP rule for any enqueued work.
  */
 #ifndef CAPE_HIP_H
 #define CAPE_HIP_H
@@ -342,6 +349,15 @@ int cape_comm_destroy(cape_handle h);
  * recv_dev: world x bytes_per_rank device bytes, rank r's shard at r x bytes_per_rank; it must stay untouched until the
  * gather has completed.  A staging slot is reused only after the gather that read it is done (two slots). */
 int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void* recv_dev, void* stream);
+/* "gather" in the narrow sense (BASELINE.json north_star): the same exchange with ONE receiver -- ncclGather (an RCCL
+ * extension) of bytes_per_rank per rank to rank `root`; recv_dev is read on the root only (may be NULL elsewhere).  At
+ * world 8 every other GPU receives nothing instead of 8 x bytes_per_rank.  CAPE_ERR_UNSUPPORTED if the loaded librccl has
+ * no ncclGather. */
+int cape_gather_primitives_root(cape_handle h, int32_t n_frames, int32_t first_frame, int32_t root, void* recv_dev, void* stream);
+/* Totals of the last cape_extract batch (frames [0, n_frames)): what a caller sizes cape_gather_config.planes_per_frame
+ * with -- e.g. ceil(1.25 x n_planes / n_frames) + 1 from the previous batch of the same stream -- instead of the default
+ * budget.  Synchronous (waits for the batch).  Any output pointer may be NULL. */
+int cape_count_primitives(cape_handle h, int32_t n_frames, int32_t* n_planes, int32_t* n_cylinders, int32_t* max_planes_per_frame);
 /* Orders after the last cape_gather_primitives: with host_sync != 0 the call returns when the gather has landed,
  * otherwise `stream` is made to wait for it (hipStreamWaitEvent). */
 int cape_gather_wait(cape_handle h, void* stream, int32_t host_sync);

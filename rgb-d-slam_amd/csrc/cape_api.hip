@@ -31,6 +31,9 @@ int rccl_comm_init(void** comm, int world, const RcclUniqueId& id, int rank);
 int rccl_comm_destroy(void* comm);
 int rccl_all_gather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t stream);
 const char* rccl_error_string(int code);
+bool rccl_has_gather();
+int rccl_gather_bytes(const void* send, void* recv, size_t bytes, int root, void* comm, hipStream_t stream);
+hipError_t launch_count_primitives(const cape_frame_record* records, int nFrames, int32_t* out, hipStream_t stream);
 int grow_waves_per_group();
 int grow_waves_per_cu(const StageBParams& p);
 } // namespace cape
@@ -174,10 +177,14 @@ struct cape_handle_s
     std::vector<hipEvent_t> pipeStage;
     int lastFrames = 0;
     // Per-handle scratch (depth staging, rectify keys, hand-over feedback, result buffers) is reused from call to call
-    // without per-buffer events: ONE stream is in flight per handle.  A call that arrives on another stream first waits
-    // for everything the handle enqueued on the previous one (enter_stream).
+    // without per-buffer events: ONE stream is in flight per handle.  Every enqueueing call leaves a handle-owned event
+    // behind its work (StreamScope); a call that arrives on ANOTHER stream makes that stream wait for the event
+    // (hipStreamWaitEvent: no host block, and the previous stream's handle is never touched again -- the caller may have
+    // destroyed it).  lastStream is only compared, never dereferenced.
     hipStream_t lastStream = nullptr;
     bool hasLastStream = false;
+    hipEvent_t workDone = nullptr;  // recorded behind the last enqueued work of this handle
+    bool workRecorded = false;
     // multi-GPU gather: two packed staging slots, the RCCL communicator and its stream
     cape_gather_config gatherCfg{};
     cape_gather_layout gatherLayout{};
@@ -191,6 +198,7 @@ struct cape_handle_s
     hipStream_t commStream = nullptr;
     hipEvent_t gatherDone = nullptr;
     bool gatherPending = false;
+    int32_t* countScratch = nullptr; // cape_count_primitives
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
     cape::StageBParams pb{};
@@ -234,6 +242,7 @@ void free_all(cape_handle_s* h)
     if (h->handedOverReady)
         (void)hipEventDestroy(h->handedOverReady);
     (void)hipFree(h->debugCycles);
+    (void)hipFree(h->countScratch);
     (void)hipFree(h->xpre);
     (void)hipFree(h->ypre);
     (void)hipFree(h->rectKeys);
@@ -294,6 +303,8 @@ void free_all(cape_handle_s* h)
             (void)hipStreamDestroy(st);
     if (h->pipeFork)
         (void)hipEventDestroy(h->pipeFork);
+    if (h->workDone)
+        (void)hipEventDestroy(h->workDone);
     for (auto& e : h->pipeJoin)
         if (e)
             (void)hipEventDestroy(e);
@@ -371,15 +382,46 @@ int acquire_events(cape_handle_s* h, int frames, cape_handle_s::EvTriple** out)
     return CAPE_OK;
 }
 
-// one stream in flight per handle (see cape_handle_s::lastStream)
+// one stream in flight per handle (see cape_handle_s::lastStream): a call on another stream is ordered behind the
+// handle's previous work on the device, through the handle's own event
 int enter_stream(cape_handle_s* h, hipStream_t st)
 {
-    if (h->hasLastStream && h->lastStream != st)
-        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    const bool other = h->hasLastStream && h->lastStream != st;
     h->lastStream = st;
     h->hasLastStream = true;
+    if (other && h->workRecorded)
+        CAPE_HIP_TRY(hipStreamWaitEvent(st, h->workDone, 0));
     return CAPE_OK;
 }
+
+// everything this handle has enqueued so far is done (host side)
+hipError_t drain_handle(cape_handle_s* h)
+{
+    if (h->workRecorded)
+        return hipEventSynchronize(h->workDone);
+    return hipSuccess;
+}
+
+// Brackets the enqueueing part of an entry point: orders the call behind the handle's earlier work (enter_stream) and,
+// on the way out -- whether or not a launch in between failed -- records the handle's event behind what was enqueued.
+class StreamScope
+{
+  public:
+    StreamScope(cape_handle_s* h, hipStream_t st) : _h(h), _st(st) { _rc = enter_stream(h, st); }
+    ~StreamScope()
+    {
+        if (_rc == CAPE_OK && _h->workDone && hipEventRecord(_h->workDone, _st) == hipSuccess)
+            _h->workRecorded = true;
+    }
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+    int rc() const { return _rc; }
+
+  private:
+    cape_handle_s* _h;
+    hipStream_t _st;
+    int _rc;
+};
 
 // one kernel chain (A1 -> A2 -> B) on `st`, optionally bracketed by timing events
 int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::StageBParams& b, int frames, hipStream_t st)
@@ -465,13 +507,17 @@ int wait_results(cape_handle_s* h)
                 std::atomic_thread_fence(std::memory_order_acquire); // the results are read after the word
                 return CAPE_OK;
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            __asm__ __volatile__("yield");
+#endif
             if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
                 break;
         }
     }
-    if (h->hasLastStream)
-        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    if (h->workRecorded)
+        CAPE_HIP_TRY(hipEventSynchronize(h->workDone));
     else
         CAPE_HIP_TRY(hipDeviceSynchronize());
     return CAPE_OK;
@@ -585,16 +631,17 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
+    CAPE_ALLOC(hipEventCreateWithFlags(&h->workDone, hipEventDisableTiming));
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
     if (h->resultsOnHost)
     {
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->records), B * sizeof(cape_frame_record), hipHostMallocMapped));
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->planeLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->cylLabels), B * C * sizeof(int32_t), hipHostMallocMapped));
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), B * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped));
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->doneFlag), 64, hipHostMallocMapped));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->records), B * sizeof(cape_frame_record), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->planeLabels), B * C * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->cylLabels), B * C * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), B * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->doneFlag), 64, hipHostMallocMapped | hipHostMallocCoherent));
         *h->doneFlag = 0;
     }
     else
@@ -762,8 +809,7 @@ void cape_destroy(cape_handle h)
         return;
     {
         DeviceGuard deviceGuard(h->cfg.device);
-        if (h->hasLastStream)
-            (void)hipStreamSynchronize(h->lastStream); // nothing of the handle's may still be running on its buffers
+        (void)drain_handle(h); // nothing of the handle's may still be running on its buffers
         free_all(h);
     }
     delete h;
@@ -817,8 +863,9 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
         return CAPE_OK;
     CAPE_ON_DEVICE(h); // the handle's device, whatever the calling thread had current
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     h->pa.depth = depth_dev;
     h->pa.depth_u16 = depth_u16;
     h->pa.u16_scale = scale;
@@ -888,8 +935,9 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
     CAPE_ON_DEVICE(h);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     // Pinned input (cape_host_alloc / cape_host_register, or any hipHostMalloc'ed / registered buffer): a few frames are
     // read by the streaming kernel straight from host memory -- the image is read exactly once, so the PCIe transfer IS the
     // kernel's input stream and no staging copy precedes it; larger batches take one DMA from the pinned pages.  Pageable
@@ -995,8 +1043,7 @@ int cape_host_free(cape_handle h, void* p)
     if (!p)
         return CAPE_OK;
     CAPE_ON_DEVICE(h);
-    if (h->hasLastStream)
-        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream)); // a kernel of this handle may still be reading the buffer
+    CAPE_HIP_TRY(drain_handle(h)); // a kernel of this handle may still be reading the buffer
     CAPE_HIP_TRY(hipHostFree(p));
     return CAPE_OK;
 }
@@ -1015,8 +1062,7 @@ int cape_host_unregister(cape_handle h, void* p)
     if (!h || !p)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
     CAPE_ON_DEVICE(h);
-    if (h->hasLastStream)
-        CAPE_HIP_TRY(hipStreamSynchronize(h->lastStream));
+    CAPE_HIP_TRY(drain_handle(h));
     CAPE_HIP_TRY(hipHostUnregister(p));
     return CAPE_OK;
 }
@@ -1089,8 +1135,9 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
         return fail(CAPE_ERR_INVALID_ARGUMENT, "rectify_depth is not in-place");
     CAPE_ON_DEVICE(h);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     const size_t frameSize = (size_t)h->cfg.width * h->cfg.height;
     if (h->rectKeyFrames < (size_t)n_frames)
     {
@@ -1159,8 +1206,9 @@ int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h);
-    if (const int rc = enter_stream(h, static_cast<hipStream_t>(stream_)); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, static_cast<hipStream_t>(stream_));
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     if (!h->matches)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matches), (size_t)h->cfg.max_batch * sizeof(cape_frame_match)));
     cape::MatchParams p;
@@ -1328,8 +1376,9 @@ int cape_pack_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, v
     if (n_frames > h->gatherLayout.frames_capacity)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds cape_gather_config.frames_capacity");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     if (const int rc = pack_into_next_slot(h, n_frames, first_frame, stream); rc != CAPE_OK)
         return rc;
     if (packed_dev)
@@ -1402,12 +1451,19 @@ int cape_comm_destroy(cape_handle h)
     return CAPE_OK;
 }
 
-int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void* recv_dev, void* stream_)
+// root < 0: ncclAllGather (every rank receives); root >= 0: ncclGather to that rank (recv_dev is read on the root only)
+static int gather_impl(cape_handle h, int32_t n_frames, int32_t first_frame, int32_t root, void* recv_dev, void* stream_)
 {
-    if (!h || !recv_dev || n_frames < 0)
-        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or negative frame count");
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
     if (!h->comm)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "no communicator: call cape_comm_init first");
+    if (root >= h->commWorld)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "root outside [0, world)");
+    if (!recv_dev && (root < 0 || root == h->commRank))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "recv_dev is null on a receiving rank");
+    if (root >= 0 && !cape::rccl_has_gather())
+        return fail(CAPE_ERR_UNSUPPORTED, "this librccl.so has no ncclGather: use cape_gather_primitives");
     if (n_frames > h->lastFrames)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
     CAPE_ON_DEVICE(h);
@@ -1416,8 +1472,9 @@ int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame,
     if (n_frames > h->gatherLayout.frames_capacity)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds cape_gather_config.frames_capacity");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (const int rc = enter_stream(h, stream); rc != CAPE_OK)
-        return rc;
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
     if (const int rc = pack_into_next_slot(h, n_frames, first_frame, stream); rc != CAPE_OK)
         return rc;
     const int slot = h->packSlot;
@@ -1425,13 +1482,59 @@ int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame,
     // kernels of the next batch
     CAPE_HIP_TRY(hipEventRecord(h->packReady, stream));
     CAPE_HIP_TRY(hipStreamWaitEvent(h->commStream, h->packReady, 0));
-    if (const int rc = cape::rccl_all_gather_bytes(h->packed[slot], recv_dev, h->gatherLayout.bytes_per_rank, h->comm, h->commStream);
-        rc != 0)
-        return fail(CAPE_ERR_HIP, std::string("ncclAllGather: ") + cape::rccl_error_string(rc));
+    if (root < 0)
+    {
+        if (const int rc = cape::rccl_all_gather_bytes(h->packed[slot], recv_dev, h->gatherLayout.bytes_per_rank, h->comm, h->commStream);
+            rc != 0)
+            return fail(CAPE_ERR_HIP, std::string("ncclAllGather: ") + cape::rccl_error_string(rc));
+    }
+    else if (const int rc = cape::rccl_gather_bytes(h->packed[slot], recv_dev, h->gatherLayout.bytes_per_rank, root, h->comm, h->commStream);
+             rc != 0)
+        return fail(CAPE_ERR_HIP, std::string("ncclGather: ") + cape::rccl_error_string(rc));
     CAPE_HIP_TRY(hipEventRecord(h->packedFree[slot], h->commStream));
     h->packedBusy[slot] = true;
     CAPE_HIP_TRY(hipEventRecord(h->gatherDone, h->commStream));
     h->gatherPending = true;
+    return CAPE_OK;
+}
+
+int cape_gather_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, void* recv_dev, void* stream_)
+{
+    return gather_impl(h, n_frames, first_frame, -1, recv_dev, stream_);
+}
+
+int cape_gather_primitives_root(cape_handle h, int32_t n_frames, int32_t first_frame, int32_t root, void* recv_dev, void* stream_)
+{
+    if (root < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "root outside [0, world)");
+    return gather_impl(h, n_frames, first_frame, root, recv_dev, stream_);
+}
+
+int cape_count_primitives(cape_handle h, int32_t n_frames, int32_t* n_planes, int32_t* n_cylinders, int32_t* max_planes_per_frame)
+{
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
+    if (n_frames > h->lastFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
+    CAPE_ON_DEVICE(h);
+    int32_t tot[4] = {0, 0, 0, 0};
+    if (n_frames > 0)
+    {
+        if (!h->countScratch)
+            CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->countScratch), 4 * sizeof(int32_t)));
+        // behind the batch, wherever it was enqueued, without touching that stream
+        CAPE_HIP_TRY(h->workRecorded ? hipEventSynchronize(h->workDone) : hipDeviceSynchronize());
+        hipStream_t st = nullptr;
+        CAPE_HIP_TRY(cape::launch_count_primitives(h->records, n_frames, h->countScratch, st));
+        CAPE_HIP_TRY(hipMemcpyAsync(tot, h->countScratch, sizeof(tot), hipMemcpyDeviceToHost, st));
+        CAPE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (n_planes)
+        *n_planes = tot[0];
+    if (n_cylinders)
+        *n_cylinders = tot[1];
+    if (max_planes_per_frame)
+        *max_planes_per_frame = tot[2];
     return CAPE_OK;
 }
 

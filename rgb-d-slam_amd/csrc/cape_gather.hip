@@ -193,6 +193,40 @@ __global__ __launch_bounds__(256) void cape_pack_clear_tail_kernel(PackParams p)
         cw[i] = 0ull;
 }
 
+// totals of a batch (what sizes a tight payload budget): one wave-reduced atomic per workgroup
+__global__ __launch_bounds__(256) void cape_count_primitives_kernel(const cape_frame_record* records, int nFrames, int32_t* out)
+{
+    int planes = 0, cyls = 0, maxPlanes = 0;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nFrames; f += gridDim.x * blockDim.x)
+    {
+        const int np = records[f].header.n_planes;
+        planes += np;
+        cyls += records[f].header.n_cylinders;
+        maxPlanes = max(maxPlanes, np);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        planes += __shfl_xor(planes, o);
+        cyls += __shfl_xor(cyls, o);
+        maxPlanes = max(maxPlanes, __shfl_xor(maxPlanes, o));
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicAdd(&out[0], planes);
+        atomicAdd(&out[1], cyls);
+        atomicMax(&out[2], maxPlanes);
+    }
+}
+
+hipError_t launch_count_primitives(const cape_frame_record* records, int nFrames, int32_t* out, hipStream_t stream)
+{
+    if (const hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream); e != hipSuccess)
+        return e;
+    const int blocks = max(1, min(64, (nFrames + 255) / 256));
+    hipLaunchKernelGGL(cape_count_primitives_kernel, dim3(blocks), dim3(256), 0, stream, records, nFrames, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(const PackParams& p, hipStream_t stream)
 {
     hipLaunchKernelGGL(cape_pack_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, p);
@@ -216,6 +250,7 @@ struct RcclApi
     int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Gather)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr; // RCCL extension; optional
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -256,6 +291,7 @@ const char* rccl_load()
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    g_rccl.Gather = reinterpret_cast<decltype(g_rccl.Gather)>(sym("ncclGather"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
     {
         g_rccl.error = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather";
@@ -271,6 +307,11 @@ int rccl_comm_destroy(void* comm) { return g_rccl.CommDestroy(comm); }
 int rccl_all_gather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t stream)
 {
     return g_rccl.AllGather(send, recv, bytes, /* ncclChar */ 0, comm, stream);
+}
+bool rccl_has_gather() { return g_rccl.Gather != nullptr; }
+int rccl_gather_bytes(const void* send, void* recv, size_t bytes, int root, void* comm, hipStream_t stream)
+{
+    return g_rccl.Gather(send, recv, bytes, /* ncclChar */ 0, root, comm, stream);
 }
 const char* rccl_error_string(int code) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "rccl not loaded"; }
 

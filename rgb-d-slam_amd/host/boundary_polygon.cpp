@@ -816,7 +816,12 @@ bool Polygon::merge_union(const Polygon& other)
     {
         disjoint = true;
         if (area() >= o.area())
-            return true; // this polygon is the biggest piece: unchanged (holes included)
+        {
+            // this polygon is the biggest piece of the multi-polygon: union_one returns it as is, and merge_union
+            // still simplifies what it assigned (polygon.cpp:325-336)
+            simplify();
+            return true;
+        }
         outer = o._ring;
     }
     if (outer.size() < 3 || !ring_is_simple(outer))
@@ -860,47 +865,46 @@ std::vector<vector3> Polygon::get_unprojected_boundary() const
 
 void Polygon::simplify(const double distanceThreshold) noexcept
 {
-    _area = area();
+    _area = area(); // total area: outer ring minus the interior rings
     if (_ring.size() < 4)
         return;
     const double eps = std::max(_area / 1e5, distanceThreshold);
-    // closed ring: run Douglas-Peucker on the ring opened at vertex 0 and closed back onto it
-    std::vector<vector2> closed = _ring;
-    closed.push_back(_ring.front());
-    std::vector<char> keep(closed.size(), 0);
-    keep.front() = keep.back() = 1;
-    douglas_peucker(closed, 0, closed.size() - 1, eps, keep);
-    std::vector<vector2> out;
-    for (size_t i = 0; i + 1 < closed.size(); ++i)
-        if (keep[i])
-            out.push_back(closed[i]);
-    if (ring_is_simple(out))
+    // Douglas-Peucker on a closed ring: opened at vertex 0 and closed back onto it
+    auto simplified = [eps](const std::vector<vector2>& ring) {
+        std::vector<vector2> closed = ring;
+        closed.push_back(ring.front());
+        std::vector<char> keep(closed.size(), 0);
+        keep.front() = keep.back() = 1;
+        douglas_peucker(closed, 0, closed.size() - 1, eps, keep);
+        std::vector<vector2> out;
+        for (size_t i = 0; i + 1 < closed.size(); ++i)
+            if (keep[i])
+                out.push_back(closed[i]);
+        return out;
+    };
+    // the reference simplifies the WHOLE polygon into a temporary, keeps it only if that temporary is valid and its total
+    // area (holes included) stays above 75 % of the old total area (polygon.cpp:577-598): all rings or none
+    Polygon cand = *this;
+    cand._ring = simplified(_ring);
+    bool valid = cand._ring.size() >= 3 && ring_is_simple(cand._ring);
+    for (size_t k = 0; valid && k < _inners.size(); ++k)
     {
-        const double newArea = std::abs(ring_area_signed(out));
-        if (newArea > std::abs(ring_area_signed(_ring)) * 0.75) // "check that the area is not too reduced" (polygon.cpp:592-598)
-            _ring = out;
+        if (_inners[k].size() < 4)
+            continue; // a triangle has nothing to drop
+        cand._inners[k] = simplified(_inners[k]);
+        valid = cand._inners[k].size() >= 3 && ring_is_simple(cand._inners[k]);
+        for (size_t i = 0; valid && i < cand._inners[k].size(); ++i)
+            valid = point_in_ring(cand._inners[k][i], cand._ring, true);
     }
-    // interior rings with the same tolerance; one that degenerates or leaves the outer ring keeps its vertices
-    for (auto& h : _inners)
+    if (!valid)
+        return; // "could not optimize polygon boundary": unchanged
+    const double newArea = cand.area();
+    if (newArea > _area * 0.75)
     {
-        if (h.size() < 4)
-            continue;
-        std::vector<vector2> hc = h;
-        hc.push_back(h.front());
-        std::vector<char> hk(hc.size(), 0);
-        hk.front() = hk.back() = 1;
-        douglas_peucker(hc, 0, hc.size() - 1, eps, hk);
-        std::vector<vector2> ho;
-        for (size_t i = 0; i + 1 < hc.size(); ++i)
-            if (hk[i])
-                ho.push_back(hc[i]);
-        bool inside = ho.size() >= 3 && ring_is_simple(ho);
-        for (size_t i = 0; inside && i < ho.size(); ++i)
-            inside = point_in_ring(ho[i], _ring, true);
-        if (inside)
-            h = ho;
+        _ring = std::move(cand._ring);
+        _inners = std::move(cand._inners);
+        _area = newArea;
     }
-    _area = area();
 }
 
 } // namespace rgbd_slam::utils

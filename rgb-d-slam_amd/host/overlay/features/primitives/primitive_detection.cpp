@@ -204,6 +204,15 @@ void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames
             return;
         }
         const int shards = static_cast<int>(_shards.size()) < wanted ? static_cast<int>(_shards.size()) : wanted;
+        _lastBatchShards = shards;
+        {
+            // frames of shard 0's last chunk: what its handle still holds
+            int first = 0, count = n_frames;
+            if (shards > 1)
+                block_of(n_frames, 0, shards, first, count);
+            const int mb = _shards[0].maxBatch;
+            _lastBatchResident = count <= 0 ? 0 : (count % mb == 0 ? mb : count % mb);
+        }
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<char> ok(shards, 1);
         if (shards == 1)
@@ -287,8 +296,22 @@ bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame
     try
     {
         matches.clear();
-        if (_shards.empty() || n_frames < 0)
+        if (_shards.empty() || n_frames < 0 || _lastBatchShards == 0)
             return false; // the batch handle of shard 0 holds the frames: find_primitives_batch comes first
+        if (_lastBatchShards != 1)
+        {
+            // frame f-1 and frame f of a shard boundary live on different devices, and a shard's local indices are not the
+            // batch's: refuse instead of returning matches that do not line up
+            outputs::log_error("match_consecutive: the last batch was cut over " + std::to_string(_lastBatchShards) +
+                               " shards; call set_shard_count(1) before find_primitives_batch");
+            return false;
+        }
+        if (n_frames > _lastBatchResident)
+        {
+            outputs::log_error("match_consecutive: only the last chunk of the batch (" + std::to_string(_lastBatchResident) +
+                               " frames) is still resident on the device");
+            return false;
+        }
         const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
                                (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
         matches.resize(n_frames);

@@ -53,7 +53,8 @@ class Primitive_Detection
     [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
 
     // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
-    // shard (the last chunk of <= 64 frames); see cape_match_consecutive.  Plane indices count the segments flagged
+    // shard (the last chunk of <= 64 frames); see cape_match_consecutive.  Enforced: returns false (and logs why) when the
+    // last batch was cut over several shards, or when n_frames exceeds the frames of its last chunk.  Plane indices count the segments flagged
     // is_output, i.e. the planes BEFORE the polygon validity test drops any.
     bool match_consecutive(int n_frames,
                            std::vector<cape_frame_match>& matches,
@@ -92,6 +93,8 @@ class Primitive_Detection
     int _cells = 0, _boundaryCapacity = 0;
     int _maxBatch = 64;
     int _requestedShards = 0;
+    int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
+    int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
     mutable std::vector<Shard> _shards;    // batch shards (max_batch = 64 each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164

@@ -108,7 +108,7 @@ CELL_STATS_DTYPE = np.dtype([
 EXPORTED_SYMBOLS = [
     "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
-    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_wait", "cape_copy_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
+    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
@@ -163,6 +163,8 @@ def load_library():
     L.cape_comm_destroy.argtypes = [vp]
     L.cape_gather_primitives.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     L.cape_gather_wait.argtypes = [vp, vp, C.c_int32]
+    L.cape_gather_primitives_root.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    L.cape_count_primitives.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.cape_match_consecutive.argtypes = [vp, C.c_int32, C.c_uint32, vp]
     L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
     L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
@@ -224,6 +226,9 @@ class Extractor:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
+            for p in list(getattr(self, "_pinned", {}).values()):  # buffers from host_alloc that were never freed
+                self.L.cape_host_free(self.h, C.c_void_p(p))
+            self._pinned = {}
             self.L.cape_destroy(self.h)
             self.h = None
 
@@ -333,13 +338,21 @@ class Extractor:
         self.gather_layout = {f: int(getattr(lay, f)) for f, _ in cape_gather_layout._fields_}
         return self.gather_layout
 
+    def _ensure_gather_layout(self):
+        # the C layer would configure itself with the defaults on the first pack; do it here so that the layout is known
+        if getattr(self, "gather_layout", None) is None:
+            self.gather_configure(self.max_batch)
+
     def pack(self, n_frames, first_frame=0, stream=0):
+        self._ensure_gather_layout()
         p = C.c_void_p()
         _check(self.L, self.L.cape_pack_primitives(self.h, n_frames, first_frame, C.byref(p), C.c_void_p(stream)),
                "cape_pack_primitives")
         return p.value
 
     def packed_host(self):
+        if getattr(self, "gather_layout", None) is None:
+            raise CapeError("nothing has been packed yet")
         out = np.zeros(self.gather_layout["bytes_per_rank"], np.uint8)
         _check(self.L, self.L.cape_copy_packed(self.h, out.ctypes.data_as(C.c_void_p)), "cape_copy_packed")
         return out
@@ -358,8 +371,22 @@ class Extractor:
 
     def gather(self, n_frames, first_frame, recv_ptr, stream=0):
         """pack + ONE ncclAllGather (RCCL called from the C layer) of bytes_per_rank per rank into recv_ptr."""
+        self._ensure_gather_layout()
         _check(self.L, self.L.cape_gather_primitives(self.h, n_frames, first_frame, C.c_void_p(recv_ptr), C.c_void_p(stream)),
                "cape_gather_primitives")
+
+    def gather_root(self, n_frames, first_frame, root, recv_ptr, stream=0):
+        """pack + ONE ncclGather to rank `root` (recv_ptr may be 0 on the other ranks)."""
+        self._ensure_gather_layout()
+        _check(self.L, self.L.cape_gather_primitives_root(self.h, n_frames, first_frame, root,
+                                                          C.c_void_p(recv_ptr) if recv_ptr else None, C.c_void_p(stream)),
+               "cape_gather_primitives_root")
+
+    def count_primitives(self, n_frames):
+        """(planes, cylinders, most planes in one frame) over the last batch -- sizes a tight gather budget."""
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(self.L, self.L.cape_count_primitives(self.h, n_frames, C.byref(a), C.byref(b), C.byref(c)), "cape_count_primitives")
+        return a.value, b.value, c.value
 
     def gather_wait(self, stream=0, host_sync=True):
         _check(self.L, self.L.cape_gather_wait(self.h, C.c_void_p(stream), 1 if host_sync else 0), "cape_gather_wait")

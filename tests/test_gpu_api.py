@@ -99,3 +99,44 @@ def test_seed_sequence_entry(oracle_mod):
     assert n.value == len(ref.seeds) and np.array_equal(out, ref.seeds[:2])
     assert ex.L.cape_copy_seed_sequence(ex.h, 5, out.ctypes.data_as(C.c_void_p), 2, C.byref(n)) == -1  # frame >= max_batch
     ex.close()
+
+
+def test_previous_stream_may_be_destroyed(oracle_mod):
+    """the handle never touches the stream of an earlier call again -- a caller may synchronise a temporary
+    stream, destroy it, and go on with another one (the order is kept by a handle-owned event)."""
+    import ctypes
+
+    from cape_amd import Extractor, synth
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    frames = np.stack([synth.room(seed=4, frame=i) for i in range(4)])
+    ex = Extractor(640, 480, cylinders=False, max_batch=4, **_intr())
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **_intr())
+    for rounds in range(3):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        ex.extract_host(frames, st.value)
+        assert hip.hipStreamSynchronize(st) == 0
+        assert hip.hipStreamDestroy(st) == 0          # legal: its work is done
+        ex.extract_host(frames[::-1].copy(), 0)       # next call on the null stream: must not fail or hang
+    res = ex.results(4)
+    for f in range(4):
+        assert np.array_equal(res.plane_labels[f], orc.run(frames[3 - f]).plane_labels)
+    buf = ex.host_alloc((2, 480, 640))                # a pinned buffer left to close()
+    buf[:] = frames[:2]
+    ex.extract_host(buf)
+    assert np.array_equal(ex.results(2).plane_labels[1], orc.run(frames[1]).plane_labels)
+    ex.close()
+
+
+def test_count_primitives_entry(oracle_mod):
+    from cape_amd import Extractor, synth
+
+    frames = np.stack([synth.room(seed=6, frame=i) for i in range(12)])
+    ex = Extractor(640, 480, cylinders=False, max_batch=12, **_intr())
+    ex.extract_host(frames)
+    planes, cyls, most = ex.count_primitives(12)
+    hdr = ex.results(12, with_boundary=False).records["header"]
+    assert planes == int(hdr["n_planes"].sum()) and cyls == int(hdr["n_cylinders"].sum()) and most == int(hdr["n_planes"].max())
+    assert planes > 0
+    ex.close()

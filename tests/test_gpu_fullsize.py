@@ -1,0 +1,111 @@
+"""GPU parity at BASELINE.json's full batch sizes (configs[1], [2], [4]'s one-GPU leg).
+
+The oracle runs at ~500 frames/s per core, so a 4 096-frame batch is checked the way the contract allows: the CPU oracle
+on every 16th frame (all observables of `compare_frame`, bit for bit), and size-independent properties on ALL frames --
+every frame terminated without a capacity/seed-limit status, counts are self-consistent with the label grids, and the
+batch result of a frame equals what the same frame gives alone in a batch of one (scheduling independence: which
+wave / kernel instance / redo list a frame lands in must not change a bit of it).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _intr, compare_frame
+
+pytestmark = pytest.mark.gpu
+
+BAD_STATUS = 1 | 2 | 4 | 32 | 64  # plane / boundary / cylinder overflow, RNG exhausted, seed limit
+
+
+def _properties_all_frames(res, n, cells):
+    hdr = res.records["header"][:n]
+    assert not (hdr["status"] & BAD_STATUS).any(), "no frame may hit a capacity or iteration guard on these streams"
+    assert (hdr["n_plane_segments"] >= hdr["n_planes"]).all()
+    # label grids: every plane label in [0, n_plane_segments], every cylinder label in [0, n_cylinder_labels]
+    assert (res.plane_labels[:n].min(axis=1) >= 0).all()
+    assert (res.plane_labels[:n].max(axis=1) <= hdr["n_plane_segments"]).all()
+    assert (res.cyl_labels[:n].max(axis=1) <= hdr["n_cylinder_labels"]).all()
+    # a cell is never both a plane cell and a cylinder cell
+    assert not ((res.plane_labels[:n] > 0) & (res.cyl_labels[:n] > 0)).any()
+
+
+def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=False, chunk=64):
+    import torch
+    from cape_amd import Extractor, synth_gpu
+
+    scale = W / 640.0
+    intr = _intr(scene, scale)
+    dev = synth_gpu.stream(scene, 100, n, width=W, height=H, start=0, device="cuda", chunk=chunk)
+    ex = Extractor(W, H, cylinders=cyl, max_batch=n, **intr)
+    stream = torch.cuda.current_stream().cuda_stream
+    ex.extract_device(dev.data_ptr(), n, stream)
+    if match:
+        ex.match_consecutive(n, 0, stream)
+    res = ex.results(n, with_boundary=True)
+    _properties_all_frames(res, n, ex.cells)
+    orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
+    picked = list(range(0, n, stride))
+    frames = dev[picked].cpu().numpy()
+    n_planes = n_cyl = 0
+    for k, f in enumerate(picked):
+        r = orc.run(frames[k])
+        compare_frame(r, ex, res, f, check_cells=(k % 8 == 0))
+        n_planes += len(r.planes)
+        n_cyl += len(r.cylinders)
+    # scheduling independence on a few frames the oracle did NOT see: alone in a batch of one == inside the big batch
+    ex1 = Extractor(W, H, cylinders=cyl, max_batch=1, **intr)
+    for f in (1, n // 3 + 1, n - 3):
+        ex1.extract_device(dev[f:f + 1].data_ptr(), 1, stream)
+        one = ex1.results(1)
+        assert np.array_equal(one.plane_labels[0], res.plane_labels[f])
+        assert np.array_equal(one.cyl_labels[0], res.cyl_labels[f])
+        assert one.records["header"][0].tobytes() == res.records["header"][f].tobytes()
+        ns = int(one.records["header"]["n_plane_segments"][0])
+        assert one.records["segments"][0][:ns].tobytes() == res.records["segments"][f][:ns].tobytes()
+    ex1.close()
+    matches = ex.matches(n) if match else None
+    ex.close()
+    return n_planes, n_cyl, res, matches
+
+
+def test_configs1_room_4096_plane_only(oracle_mod):
+    """BASELINE.json configs[1] at the size bench.py times: 4 096 distinct device-rendered room frames, planes only."""
+    n_planes, _, res, _ = _check_stream(oracle_mod, "room", False, 4096)
+    assert n_planes >= 256 * 2, "a room shows walls"
+    assert (res.records["header"]["n_planes"] > 0).mean() > 0.95
+
+
+def test_configs2_tunnel_2048_cylinders(oracle_mod):
+    """BASELINE.json configs[2]: 2 048 tunnel frames, planes + cylinder RANSAC."""
+    _, n_cyl, res, _ = _check_stream(oracle_mod, "tunnel", True, 2048)
+    assert n_cyl >= 64, "the tunnel is a cylinder"
+    assert (res.records["header"]["n_cylinders"] > 0).mean() > 0.5
+
+
+def test_configs4_1280x960_tunnel_1024_cylinders_match(oracle_mod):
+    """BASELINE.json configs[4], one-GPU leg: 1 024 frames of 1280x960, planes + cylinders + consecutive-frame matching."""
+    import match_oracle
+    from cape_amd import synth_gpu
+
+    n = 1024
+    _, n_cyl, res, matches = _check_stream(oracle_mod, "tunnel", True, n, W=1280, H=960, stride=32, match=True, chunk=16)
+    assert n_cyl >= 16
+    # the matcher on two consecutive pairs, against match_oracle fed with the oracle's own frames
+    intr = _intr("tunnel", 2.0)
+    orc = oracle_mod.Oracle(1280, 960, cylinders=True, **intr)
+    dev = synth_gpu.stream("tunnel", 100, 4, width=1280, height=960, start=510, device="cuda", chunk=4).cpu().numpy()
+
+    def per(depth):
+        r = orc.run(depth)
+        roots = r.planes[:, 19].astype(int) if len(r.planes) else np.zeros(0, int)
+        is_out = np.zeros(len(r.merge_labels), bool)
+        is_out[roots] = True
+        masks, _ = match_oracle.plane_masks(r.plane_labels, r.segments, r.merge_labels, is_out)
+        return {"masks": masks, "normals": r.planes[:, 0:3], "d": r.planes[:, 3]}
+
+    fr = [per(d) for d in dev]
+    for k in (1, 2, 3):
+        m, ap, ac, inter = match_oracle.match_frame(fr[k - 1], fr[k], advanced=False, allow_index0=False)
+        g = matches[510 + k]
+        assert g["n_prev"] == len(ap) and g["n_cur"] == len(ac)
+        assert list(g["match"][: len(ap)]) == m
+        assert np.array_equal(g["inter"][: len(ap), : len(ac)], inter)
