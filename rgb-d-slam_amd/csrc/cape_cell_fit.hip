@@ -26,33 +26,14 @@
 
 namespace cape {
 
-// tuning knobs (overridable for A/B builds, see profiles/sweep.py)
+// tuning knobs (overridable for A/B builds, see profiles/sweep.py).  Four measured-and-rejected variants of this kernel
+// (LDS-DMA ring prefetch, ds_add_f64 partials, v_pk_mul_f32 pixel pairs, a three-buffer prefetch) lived here behind
+// macros through round 2; their numbers are kept in DESIGN.md 4.1, their code in the history (commit 4d9050d).
 #ifndef CAPE_A_GROUP
 #define CAPE_A_GROUP 2   // image rows per prefetch group
 #endif
-#ifndef CAPE_A_DEPTH
-#define CAPE_A_DEPTH 1   // prefetch groups in flight ahead of the arithmetic (1 = the ping-pong loop)
-#endif
-#ifndef CAPE_A_RING
-#define CAPE_A_RING 0    // 1: float32 image rows travel global -> LDS by LDS-DMA into a per-wave ring, CAPE_A_RING_AHEAD rows ahead
-#endif                   // of the arithmetic, at no register cost.  Bit-identical; measured 1.464 ms (4 ahead) / 1.466 ms (5 ahead)
-                         // against 1.442 ms for the register ping-pong loop: the kernel is not waiting for memory
-#ifndef CAPE_A_RING_AHEAD
-#define CAPE_A_RING_AHEAD 4
-#endif
 #ifndef CAPE_A_WAVES
 #define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
-#endif
-#ifndef CAPE_A_LDS_ATOMIC
-#define CAPE_A_LDS_ATOMIC 0 // 0: per-thread partial sums meet through a [thread][11] f64 staging array (38.9 KB LDS per
-                            //    workgroup) -- default, 1.48 ms per 4 096 frames;
-                            // 1: through ds_add_f64 into [cell][10] (16.6 KB).  The sums are exact, so the atomics'
-                            //    arbitrary order cannot change a bit (parity tests pass), but it measures 3 % slower
-                            //    (1.53 ms) and the LDS it frees did not let the grow kernel of another sub-batch overlap.
-#endif
-#ifndef CAPE_A_PACKED
-#define CAPE_A_PACKED 0  // 1: pixel pairs with v_pk_mul_f32 -- measured SLOWER (1.66-1.94 ms): gfx950 SIMDs are 32 wide,
-                         // a packed f32 op costs two issue slots, so packing buys nothing here
 #endif
 
 constexpr int kThreadsA = 320;
@@ -119,53 +100,8 @@ __device__ __forceinline__ uint32_t acc_px_fast(float z, double a, double b, PxA
     return bits;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Two horizontally adjacent pixels at once: the six f32 products of both pixels are three v_pk_mul_f32 pairs each
-// (same IEEE results as scalar v_mul_f32), everything else is the per-pixel sequence of acc_px.
-__device__ __forceinline__ void acc_px2(float zr0, float zr1, double a0, double a1, double b, PxAcc& A)
-{
-    const float z0 = fmaxf(zr0, 0.0f), z1 = fmaxf(zr1, 0.0f); // invalid (<= 0, NaN) -> +0: adds nothing to any sum
-    const bool v0 = z0 > 0.0f, v1 = z1 > 0.0f;                // == `if (z > 0)` on the raw value
-    A.n += (v0 ? 1u : 0u) + (v1 ? 1u : 0u);
-    // z range of the valid pixels (exactness guard)
-    A.zminBits1 = min(A.zminBits1, min(__float_as_uint(z0) - 1u, __float_as_uint(z1) - 1u));
-    A.zmaxBits = max(A.zmaxBits, max(__float_as_uint(z0), __float_as_uint(z1)));
-    const double zd0 = (double)z0, zd1 = (double)z1;
-    f32x2 z, x, y;
-    z.x = z0;
-    z.y = z1;
-    x.x = (float)(zd0 * a0);
-    x.y = (float)(zd1 * a1);
-    y.x = (float)(zd0 * b);
-    y.y = (float)(zd1 * b);
-    const f32x2 xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    A.S[0] += (double)x.x;
-    A.S[1] += (double)y.x;
-    A.S[2] += zd0;
-    A.S[3] += (double)xx.x;
-    A.S[4] += (double)yy.x;
-    A.S[5] += (double)zz.x;
-    A.S[6] += (double)xy.x;
-    A.S[7] += (double)yz.x;
-    A.S[8] += (double)xz.x;
-    A.S[0] += (double)x.y;
-    A.S[1] += (double)y.y;
-    A.S[2] += zd1;
-    A.S[3] += (double)xx.y;
-    A.S[4] += (double)yy.y;
-    A.S[5] += (double)zz.y;
-    A.S[6] += (double)xy.y;
-    A.S[7] += (double)yz.y;
-    A.S[8] += (double)xz.y;
-}
-
 __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, double a2, double a3, double b, PxAcc& A)
 {
-#if CAPE_A_PACKED
-    acc_px2(v.x, v.y, a0, a1, b, A);
-    acc_px2(v.z, v.w, a2, a3, b, A);
-#else
     const uint32_t bx = acc_px_fast(v.x, a0, b, A);
     const uint32_t by = acc_px_fast(v.y, a1, b, A);
     const uint32_t bz = acc_px_fast(v.z, a2, b, A);
@@ -174,7 +110,6 @@ __device__ __forceinline__ void acc_f4(const float4& v, double a0, double a1, do
     // the sign bit or above +inf's ends up in zmaxBits and fails the guard
     A.zmaxBits = max(max(A.zmaxBits, bx), max(by, max(bz, bw)));
     A.zminBits1 = min(min(A.zminBits1, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
-#endif
 }
 
 // plane_segment.cpp:44-60
@@ -195,16 +130,10 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
 template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
 {
     // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
-#if CAPE_A_LDS_ATOMIC
-    __shared__ double s_cellsum[64 * 10];   // [cell][9 sums, count]
-    __shared__ unsigned s_zminmax[64 * 2];  // float bits of (zmin, zmax): non-negative floats order like unsigned ints
-#else
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
-#endif
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
     __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
-    __shared__ double s_brow[2 * kCell]; // the row factors of the workgroup's two bands (ring variant: no vector load in the loop)
 
     const int t = threadIdx.x;
     const int frame = blockIdx.x / p.pairsPerFrame;
@@ -222,26 +151,6 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     const int j = q - cseg * 5;      // float4 within the cell row
     const int lcell = bsel * 32 + cseg;
 
-#if CAPE_A_LDS_ATOMIC
-    for (int e = t; e < 640; e += kThreadsA)
-        s_cellsum[e] = 0.0;
-    if (t < 64)
-    {
-        s_zminmax[2 * t] = 0xFFFFFFFFu; // neutral element of the (pattern - 1) minimum
-        s_zminmax[2 * t + 1] = 0u;
-    }
-    __syncthreads();
-#endif
-    if constexpr (!U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC)
-    {
-        if (t < 2 * kCell)
-        {
-            const int bnd = pair * 2 + t / kCell;
-            const int cr = (bnd < p.bandsPerFrame ? bnd : p.bandsPerFrame - 1) / p.segsPerRow;
-            s_brow[t] = p.brow[cr * kCell + (t % kCell)];
-        }
-        __syncthreads();
-    }
     // ------------------------------------------------------------------ streaming accumulation
     PxAcc A;
 #pragma unroll
@@ -324,95 +233,6 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                     s_corner[lcell * 3 + 2] = buf[i].z;
             }
         };
-        constexpr bool kRing = !U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC;
-        if constexpr (kRing)
-        {
-            // ---- LDS-DMA ring.  The register ping-pong below keeps one group (two rows) in flight per wave, ~22 KB per CU,
-            // and a load takes a couple of microseconds under this kernel's own traffic: ~30 KB are needed.  Deeper
-            // REGISTER prefetch costs occupancy (measured slower).  global_load_lds_dwordx4 moves a row (1 KiB per wave:
-            // lane l's 16 bytes land at base + 16 l) straight into LDS without touching a register, so each wave keeps
-            // kAhead rows in flight in a private ring carved out of s_part, which is idle until the epilogue.  A wave
-            // reads back only what it loaded itself: no barrier, just its own vmcnt -- counted by hand, because hipcc
-            // drains vmcnt to 0 around LDS-DMA it can see (cdna_hip_programming.md); hence no other vector memory
-            // instruction may sit in this loop (the row factors come from s_brow).
-            constexpr int kAhead = CAPE_A_RING_AHEAD, kSlots = kAhead; // the row held in registers has already left its slot: row k lives in slot k mod kAhead
-            static_assert((kThreadsA / 64) * kSlots * 1024 <= (int)sizeof(s_part), "the ring must fit in s_part");
-            const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-            char* ring = reinterpret_cast<char*>(s_part) + wave * kSlots * 1024;
-            const uint32_t ringLds = (uint32_t)reinterpret_cast<uintptr_t>(ring); // LDS byte offset = low half of the flat address
-            const float* myCol = frameBase + pixOff32;                             // the lane's float4 column, row 0 of the band
-            const double* browL = s_brow + bsel * kCell;
-            auto issue_row = [&](int r, int slot) { // r, slot uniform
-                const float* g = myCol + (size_t)r * W;
-                const uint32_t m0v = __builtin_amdgcn_readfirstlane(ringLds + (uint32_t)slot * 1024u);
-                uint32_t keep; // M0 = LDS base of the transfer; the compiler's own M0 is put back
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(g), "s"(m0v)
-                             : "memory");
-            };
-            auto take_row = [&](int slot) {
-                return *reinterpret_cast<const float4*>(ring + slot * 1024 + (t & 63) * 16);
-            };
-            auto sum_row = [&](const float4& v, int r) {
-                acc_f4(v, a0, a1, a2, a3, browL[r], A);
-                // samples for the continuity cross scan and the tolerance corners
-                if (r == kCell / 2)
-                    *reinterpret_cast<float4*>(&s_row[lcell * kCell + 4 * j]) = v;
-                if (j == 2)
-                    s_col[lcell * kCell + r] = v.z; // pixel column 10 of the cell
-                if (r == 0 && j == 0)
-                    s_corner[lcell * 3] = v.x;
-                if (r == kCell - 1 && j == 4)
-                    s_corner[lcell * 3 + 1] = v.w;
-                if (r == kCell / 2 && j == 2)
-                    s_corner[lcell * 3 + 2] = v.z;
-            };
-            // the column factors must have ARRIVED before the first transfer is issued: a compiler-visible load still pending
-            // at the loop head makes hipcc wait for vmcnt(0) in every iteration, which also drains the ring
-            asm volatile("" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-#pragma unroll
-            for (int r = 0; r < kAhead; ++r)
-                issue_row(r, r);
-            // one row is held in registers ahead of the arithmetic, so that its LDS read is not exposed either: while row r is
-            // summed, row r + 1 is on its way out of LDS and rows r + 2 .. r + kAhead on their way in
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kAhead - 1) : "memory");
-            float4 cur = take_row(0);
-            int slot = 0; // slot of the row held in `cur`
-#pragma unroll 1
-            for (int r = 0; r + kAhead < kCell; ++r)
-            {
-                const int nextSlot = (slot + 1 == kSlots) ? 0 : slot + 1;
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kAhead - 2) : "memory"); // row r + 1 has landed
-                const float4 nxt = take_row(nextSlot);
-                issue_row(r + kAhead, slot); // the slot of row r is free: the row is in registers
-                sum_row(cur, r);
-                cur = nxt;
-                slot = nextSlot;
-            }
-            // the last kAhead rows: nothing left to request, one row fewer in flight per step
-            {
-                int ns = (slot + 1 == kSlots) ? 0 : slot + 1;
-#define CAPE_A_TAIL_STEP(N, rowFromEnd)                                   \
-    {                                                                     \
-        asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory");           \
-        const float4 nxt = take_row(ns);                                  \
-        sum_row(cur, kCell - (rowFromEnd));                               \
-        cur = nxt, ns = (ns + 1 == kSlots) ? 0 : ns + 1;                  \
-    }
-                if constexpr (kAhead >= 6) CAPE_A_TAIL_STEP(4, 6)
-                if constexpr (kAhead >= 5) CAPE_A_TAIL_STEP(3, 5)
-                CAPE_A_TAIL_STEP(2, 4)
-                CAPE_A_TAIL_STEP(1, 3)
-                CAPE_A_TAIL_STEP(0, 2)
-#undef CAPE_A_TAIL_STEP
-                sum_row(cur, kCell - 1);
-            }
-            static_assert(kAhead >= 4 && kAhead <= 6, "the tail above is written out for four to six rows ahead");
-        }
-        else
-        {
-#if CAPE_A_DEPTH == 1
         load_group(bufA, 0);
 #pragma unroll 1
         for (int g = 0; g < kGroups; g += 2)
@@ -423,48 +243,7 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                 load_group(bufA, g + 2);
             sum_group(bufB, g + 1);
         }
-#else
-        // two groups requested ahead of the one being summed: three register buffers in rotation, three groups per trip of a
-        // ROLLED loop (unrolled, the scheduler hoists every load of the band to the top and the kernel spills).  The kernel
-        // moves ~14 bytes per nanosecond per CU and a load takes a couple of microseconds under that load, so a CU needs ~30 KB
-        // in flight; with one group (2 rows x 16 B per lane) ahead and the ~11 waves a CU holds on average it had 22 KB.
-        Raw bufC[kGroup];
-        load_group(bufA, 0);
-        load_group(bufB, 1);
-        int g = 0;
-#pragma unroll 1
-        for (; g + 2 < kGroups; g += 3)
-        {
-            load_group(bufC, g + 2);
-            sum_group(bufA, g);
-            if (g + 3 < kGroups)
-                load_group(bufA, g + 3);
-            sum_group(bufB, g + 1);
-            if (g + 4 < kGroups)
-                load_group(bufB, g + 4);
-            sum_group(bufC, g + 2);
-        }
-        if (g < kGroups)
-            sum_group(bufA, g);
-        if (g + 1 < kGroups)
-            sum_group(bufB, g + 1);
-#endif
-        } // !kRing
     }
-    if constexpr (!U16 && (CAPE_A_RING != 0) && !CAPE_A_LDS_ATOMIC)
-        __syncthreads(); // every wave is done with its ring before the partials overwrite s_part
-#if CAPE_A_LDS_ATOMIC
-    if (active)
-    {
-        double* dst = s_cellsum + lcell * 10;
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            atomicAdd(dst + k, A.S[k]); // ds_add_f64; exact sums => order-free
-        atomicAdd(dst + 9, (double)A.n);
-        atomicMin(&s_zminmax[2 * lcell], A.zminBits1);
-        atomicMax(&s_zminmax[2 * lcell + 1], A.zmaxBits);
-    }
-#else
     {
         double* dst = s_part + t * kPartStride;
 #pragma unroll
@@ -473,7 +252,6 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         dst[9] = (double)A.n;
         reinterpret_cast<uint2*>(dst + 10)[0] = make_uint2(A.zminBits1, A.zmaxBits);
     }
-#endif
     __syncthreads();
 
     // ------------------------------------------------------------------ 5 partials -> one cell (exact, any order)
@@ -490,16 +268,12 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         const int cc = sg * 32 + cs;
         if (bnd < p.bandsPerFrame && cc < p.hCells)
         {
-#if CAPE_A_LDS_ATOMIC
-            const double acc = s_cellsum[e];
-#else
             const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
             double acc = src[0];
             acc += src[kPartStride];
             acc += src[2 * kPartStride];
             acc += src[3 * kPartStride];
             acc += src[4 * kPartStride];
-#endif
             p.cell_sums[((size_t)frame * p.cells + cr * p.hCells + cc) * kSumStride + m] = acc;
         }
     }
@@ -539,10 +313,6 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             continuous = continuous && is_continuous(zc[i], last);
     }
     // exactness guard: all addends of every sum within 2^20 of each other (see header)
-#if CAPE_A_LDS_ATOMIC
-    const uint32_t zminBits1 = s_zminmax[2 * t], zmaxBits = s_zminmax[2 * t + 1];
-    const uint32_t n = (uint32_t)s_cellsum[t * 10 + 9];
-#else
     uint32_t zminBits1 = 0xFFFFFFFFu, zmaxBits = 0u;
     uint32_t n = 0;
     {
@@ -556,7 +326,6 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             n += (uint32_t)s_part[(pbase + k) * kPartStride + 9];
         }
     }
-#endif
     // back to depths: with n > 0 at least one pixel was valid, so the minimum is a real pattern - 1
     const float zmin = __uint_as_float(zminBits1 + 1u), zmax = __uint_as_float(zmaxBits);
     const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);

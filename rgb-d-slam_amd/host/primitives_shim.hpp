@@ -5,4 +5,4 @@
 #pragma once
 #include "overlay/features/primitives/depth_map_transformation.hpp"
 #include "overlay/features/primitives/primitive_detection.hpp"
-#include "overlay/features/primitives/shape_primitives.hpp"
+#include "compat/shape_primitives.hpp"
