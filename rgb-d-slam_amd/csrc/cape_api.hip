@@ -22,6 +22,7 @@ hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t str
 int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
+size_t grow_state_bytes(int cells);
 hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_pack(const PackParams& p, hipStream_t stream);
@@ -113,6 +114,8 @@ struct cape_handle_s
     double* cylScratch = nullptr;
     uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
     uint32_t* redoList = nullptr;     // [0] count, [1..] frames that need more than 32 plane-segment slots
+    uint32_t* resumeList = nullptr;   // [0] count, [1..] frames handed to the cylinder kernel WITH their recorded regions
+    unsigned char* growState = nullptr; // max_batch x grow_state_bytes(): the parked state of those frames
     // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
     // (never waited for) before the next call.  The cylinder kernel works in rounds of cylSlots resident frames; the
     // plane-only first pass pays off when it saves at least one such round (see launch_chain)
@@ -237,6 +240,8 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cylScratch);
     (void)hipFree(h->needCylinder);
     (void)hipFree(h->redoList);
+    (void)hipFree(h->resumeList);
+    (void)hipFree(h->growState);
     if (h->handedOverHost)
         (void)hipHostFree(h->handedOverHost);
     if (h->handedOverReady)
@@ -345,6 +350,11 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
         b.cylScratch += F * C * cape::kCylStride;
     if (b.needCylinder)
         b.needCylinder += 2 * F; // a sub-batch of n frames uses 1 + n entries of its own
+    if (b.resumeList)
+    {
+        b.resumeList += 2 * F;
+        b.growState += F * (size_t)b.growStateStride;
+    }
     b.redoList += 2 * F;
     b.seed_sequence += F * C;
     b.debugCycles += F * cape::kProfileSlots;
@@ -438,6 +448,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     cape::StageAParams a2 = a;
     a2.clear0 = b.redoList;
     a2.clear1 = b.needCylinder;
+    a2.clear2 = b.resumeList;
     CAPE_HIP_TRY(cape::launch_cell_plane(a2, frames, st));
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
@@ -627,6 +638,12 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     {
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * cape::kCylStride));
         CAPE_ALLOC(dalloc(h->needCylinder, 2 * B + 2));
+        if (!std::getenv("CAPE_NO_RESUME")) // debug knob: the round-2 schedule (every handed-over frame is grown again from scratch)
+        {
+            CAPE_ALLOC(dalloc(h->resumeList, 2 * B + 2));
+            CAPE_ALLOC(hipMemset(h->resumeList, 0, (2 * B + 2) * sizeof(uint32_t)));
+            CAPE_ALLOC(dalloc(h->growState, B * cape::grow_state_bytes(h->cells)));
+        }
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), sizeof(uint32_t)));
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
@@ -766,6 +783,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cylScratch = h->cylScratch;
     b.needCylinder = h->needCylinder;
     b.redoList = h->redoList;
+    b.resumeList = h->resumeList;
+    b.growState = h->growState;
+    b.growStateStride = (uint32_t)cape::grow_state_bytes(h->cells);
     b.twoPass = h->needCylinder ? 1 : 0;
     b.ldsLimitBytes = h->ldsLimit;
     if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > (size_t)h->ldsLimit)
@@ -907,6 +927,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
                 CAPE_HIP_TRY(hipEventRecord(t->e2b, h->pipeStream[1]));
             a.clear0 = b.redoList;
             a.clear1 = b.needCylinder;
+            a.clear2 = b.resumeList;
             CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));

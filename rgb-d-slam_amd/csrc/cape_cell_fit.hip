@@ -370,6 +370,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
             *p.clear0 = 0u;
         if (p.clear1)
             *p.clear1 = 0u;
+        if (p.clear2)
+            *p.clear2 = 0u;
     }
     const int HC = p.hCells, VC = p.vCells;
     const int rowsPerTile = THREADS / HC > 0 ? THREADS / HC : 1;

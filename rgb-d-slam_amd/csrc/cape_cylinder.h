@@ -60,7 +60,7 @@ struct CylCtx
     int C;
     const unsigned short* s_list; // activated cells, ascending (= _local2globalMap)
     int total;                    // _cellActivatedCount
-    double* s_dist;               // N f64: MSAC cost of every remaining cell for the current hypothesis
+    double* s_dist;               // kStageChunk x 18 f64: staging of the combined LLS / merged-plane traversal
     unsigned short* s_ids;        // idsLeft
     unsigned char* s_idmask;      // idsLeftMask
     unsigned char* s_cur;         // inliers of the current hypothesis
@@ -121,7 +121,7 @@ constexpr int kCylCacheRounds = 12;
         bool inl_;                                                                                           \
         const double d_ = msac(cqa##k.x, cqa##k.y, cqb##k.x, cqb##k.y, cqc##k.x, cqc##k.y, inl_);            \
         if (j0 + lane + 64 * (k) < m)                                                                        \
-            c.s_dist[j0 + lane + 64 * (k)] = d_;                                                             \
+            c.scratch[(size_t)(j0 + lane + 64 * (k)) * kCylStride + 7] = d_;                                 \
     }
 // the inlier flags of the winning hypothesis, from the bits the scoring pass left in inlBits (bit k = round k)
 #define CAPE_CYL_FLAGS(k)                                                                                    \
@@ -152,16 +152,17 @@ __device__ __forceinline__ int cyl_wave_sum(int v) { return wave_sum_i32(v); }
 // requested) and the chain takes its operands out of that register with v_readlane: two scalar moves per element in the
 // shadow of the dependent add.  Reading every element with a wave-uniform LDS load cost an LDS instruction per two
 // elements, and a wave gets one through only every ~16 cycles (profiles/r02_lds_rates.txt): 28 cycles per element.
-// `s` is readable up to s[n + 63] (the surplus lanes of the last block read whatever is there and add +0.0 instead).
-__device__ __forceinline__ double ordered_sum_lds(const double* s, int n_, double limit, int lane)
+// STRIDE: doubles between consecutive elements (the costs of the rare exact path are parked in the free eighth double of
+// the per-cell cylinder scratch in HBM, not in LDS: a C-double LDS array cost 24 KB per wave on a 64x48 grid).
+template <int STRIDE> __device__ __forceinline__ double ordered_sum_lds(const double* s, int n_, double limit, int lane)
 {
     const int n = __builtin_amdgcn_readfirstlane(n_);
     double sum = 0.0;
-    double cur = (lane < n) ? s[lane] : 0.0;
+    double cur = (lane < n) ? s[(size_t)lane * STRIDE] : 0.0;
     for (int j0 = 0; j0 < n; j0 += 64)
     {
         const int jn = j0 + 64 + lane;
-        const double nxt = (jn < n) ? s[jn] : 0.0; // x + (+0.0) == x for every x >= +0.0
+        const double nxt = (jn < n) ? s[(size_t)jn * STRIDE] : 0.0; // x + (+0.0) == x for every x >= +0.0
         __builtin_amdgcn_sched_barrier(0);
         // the operand of element l + 1 is taken out while the add of element l waits for the one before it: issued right
         // in front of its own add, the scalar moves (and their way into the VALU) sat on the chain, 26 cycles per element
@@ -320,44 +321,49 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                 constexpr int j0 = 0;
                 CAPE_CYL_ROUNDS(CAPE_CYL_FETCH)
             }
-            // The draws of this loop (3 per hypothesis, <= 192) are turned into sample cells once, one draw per lane and
-            // register (idsLeft does not change during one run_ransac_loop), and handed out with v_readlane; the three
-            // sample cells of hypothesis it + 1 are requested while hypothesis it is evaluated.  Both take dependent
-            // round trips (memory, LDS crossbar) per hypothesis off the critical path of this one-wave-per-SIMD kernel.
+            // Every hypothesis of this loop is known before the loop starts: idsLeft does not change during one
+            // run_ransac_loop and the draws come from the precomputed table, so lane `it` builds hypothesis `it` -- its three
+            // draws, its three sample cells (one gathered memory round trip for ALL hypotheses instead of one per
+            // hypothesis) and the reference's arithmetic for radius and centre (:262-283), operation for operation -- and the
+            // sequential loop below only takes the five numbers out of lane `it`.  Hypotheses past an early stop are
+            // computed and never looked at.  (Through round 2 the wave fetched and computed one hypothesis per iteration,
+            // all lanes the same values: ~2 k cycles of exposed latency per hypothesis, which was all a small region cost.)
             const int rngBase = rngPos;
-            int sc0, sc1, sc2; // sample cell of draw lane, lane + 64, lane + 128
+            if (p.ransacMaxIterations > 64)
+                status |= CAPE_FRAME_RNG_EXHAUSTED; // cannot happen with the reference's constants (43 iterations)
+            double hypR, hypInvR2, hypCx, hypCy, hypCz;
             {
+                const int itL = lane < p.ransacMaxIterations ? lane : p.ransacMaxIterations - 1;
                 const int last = p.rngCount - 1;
-                const int i0 = rngBase + lane, i1 = i0 + 64, i2 = i0 + 128;
-                // table exhausted: U = 0, flagged when (if) the hypothesis is actually evaluated
-                const double u0 = i0 < p.rngCount ? p.rngTable[i0 < last ? i0 : last] : 0.0;
-                const double u1 = i1 < p.rngCount ? p.rngTable[i1 < last ? i1 : last] : 0.0;
-                const double u2 = i2 < p.rngCount ? p.rngTable[i2 < last ? i2 : last] : 0.0;
-                sc0 = (int)c.s_ids[(unsigned)floor(u0 * (double)(unsigned)m)];
-                sc1 = (int)c.s_ids[(unsigned)floor(u1 * (double)(unsigned)m)];
-                sc2 = (int)c.s_ids[(unsigned)floor(u2 * (double)(unsigned)m)];
-            }
-            auto sample_of = [&](int drawIndex) { // drawIndex = 3 * it + q, uniform
-                const int dl = drawIndex & 63;
-                const int r0 = __builtin_amdgcn_readlane(sc0, dl), r1 = __builtin_amdgcn_readlane(sc1, dl), r2 = __builtin_amdgcn_readlane(sc2, dl);
-                return drawIndex < 64 ? r0 : (drawIndex < 128 ? r1 : r2);
-            };
-            struct Triplet
-            {
-                double2 a[3], b[3], c[3]; // (n.x n.y) (n.z c.x) (c.y c.z) of the three sample cells
-            };
-            auto fetch_triplet = [&](Triplet& T, int it) {
+                double2 ta[3], tb[3], tc[3]; // (n.x n.y) (n.z c.x) (c.y c.z) of the three sample cells
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                 {
-                    const double2* t_ = reinterpret_cast<const double2*>(c.scratch + (size_t)sample_of(3 * it + q) * kCylStride);
-                    T.a[q] = t_[0];
-                    T.b[q] = t_[1];
-                    T.c[q] = t_[2];
+                    const int di = rngBase + 3 * itL + q;
+                    // table exhausted: U = 0, flagged when (if) the hypothesis is actually evaluated
+                    const double u = di < p.rngCount ? p.rngTable[di < last ? di : last] : 0.0;
+                    const int cell = (int)c.s_ids[(unsigned)floor(u * (double)(unsigned)m)];
+                    const double2* t_ = reinterpret_cast<const double2*>(c.scratch + (size_t)cell * kCylStride);
+                    ta[q] = t_[0];
+                    tb[q] = t_[1];
+                    tc[q] = t_[2];
                 }
-            };
-            if (p.ransacMaxIterations * 3 > 192)
-                status |= CAPE_FRAME_RNG_EXHAUSTED; // cannot happen with the reference's constants (43 iterations)
+                const double n1x = ta[0].x, n1y = ta[0].y, n1z = tb[0].x, c1x = tb[0].y, c1y = tc[0].x, c1z = tc[0].y;
+                const double n2x = ta[1].x, n2y = ta[1].y, n2z = tb[1].x, c2x = tb[1].y, c2y = tc[1].x, c2z = tc[1].y;
+                const double n3x = ta[2].x, n3y = ta[2].y, n3z = tb[2].x, c3x = tb[2].y, c3y = tc[2].x, c3z = tc[2].y;
+                const double sNx = (n1x + n2x) + n3x, sNy = (n1y + n2y) + n3y, sNz = (n1z + n2z) + n3z;
+                const double sCx = (c1x + c2x) + c3x, sCy = (c1y + c2y) + c3y, sCz = (c1z + c2z) + c3z;
+                const double a = 1.0 - ((sNx * sNx + sNy * sNy) + sNz * sNz) / 9.0;
+                const double prx = (n1x * c1x + n2x * c2x) + n3x * c3x;
+                const double pry = (n1y * c1y + n2y * c2y) + n3y * c3y;
+                const double prz = (n1z * c1z + n2z * c2z) + n3z * c3z;
+                const double b = ((prx + pry) + prz) / 3.0 - (dot3(sNx, sNy, sNz, sCx, sCy, sCz) / 9.0);
+                hypR = b / a;
+                hypInvR2 = 1.0 / (hypR * hypR);
+                hypCx = (sCx - hypR * sNx) / 3.0;
+                hypCy = (sCy - hypR * sNy) / 3.0;
+                hypCz = (sCz - hypR * sNz) / 3.0;
+            }
             // the hypothesis the distance macros evaluate (uniform)
             double radius = 0.0, invR2 = 0.0, ctx = 0.0, cty = 0.0, ctz = 0.0;
             auto msac = [&](double t0, double t1, double t2, double t3, double t4, double t5, bool& inl) {
@@ -384,36 +390,18 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                     }
                 }
                 CAPE_CYL_SYNC();
-                const double d = ordered_sum_lds(c.s_dist, m, limit, lane);
-                CAPE_CYL_SYNC(); // s_dist is rewritten by the next call
+                const double d = ordered_sum_lds<kCylStride>(c.scratch + 7, m, limit, lane);
+                CAPE_CYL_SYNC(); // the parked costs are rewritten by the next call
                 return d;
             };
-            Triplet cur;
-            fetch_triplet(cur, 0);
             for (int it = 0; it < p.ransacMaxIterations; ++it)
             {
                 if (rngBase + 3 * it + 2 >= p.rngCount)
                     status |= CAPE_FRAME_RNG_EXHAUSTED;
                 rngPos = rngBase + 3 * (it + 1);
-                Triplet nxt;
-                fetch_triplet(nxt, it + 1 < p.ransacMaxIterations ? it + 1 : it);
-                __builtin_amdgcn_sched_barrier(0);
-                const double n1x = cur.a[0].x, n1y = cur.a[0].y, n1z = cur.b[0].x, c1x = cur.b[0].y, c1y = cur.c[0].x, c1z = cur.c[0].y;
-                const double n2x = cur.a[1].x, n2y = cur.a[1].y, n2z = cur.b[1].x, c2x = cur.b[1].y, c2y = cur.c[1].x, c2z = cur.c[1].y;
-                const double n3x = cur.a[2].x, n3y = cur.a[2].y, n3z = cur.b[2].x, c3x = cur.b[2].y, c3y = cur.c[2].x, c3z = cur.c[2].y;
-                cur = nxt;
-                const double sNx = (n1x + n2x) + n3x, sNy = (n1y + n2y) + n3y, sNz = (n1z + n2z) + n3z;
-                const double sCx = (c1x + c2x) + c3x, sCy = (c1y + c2y) + c3y, sCz = (c1z + c2z) + c3z;
-                const double a = 1.0 - ((sNx * sNx + sNy * sNy) + sNz * sNz) / 9.0;
-                const double prx = (n1x * c1x + n2x * c2x) + n3x * c3x;
-                const double pry = (n1y * c1y + n2y * c2y) + n3y * c3y;
-                const double prz = (n1z * c1z + n2z * c2z) + n3z * c3z;
-                const double b = ((prx + pry) + prz) / 3.0 - (dot3(sNx, sNy, sNz, sCx, sCy, sCz) / 9.0);
-                const double hR = b / a;
-                const double hInvR2 = 1.0 / (hR * hR);
-                const double hCx = (sCx - hR * sNx) / 3.0;
-                const double hCy = (sCy - hR * sNy) / 3.0;
-                const double hCz = (sCz - hR * sNz) / 3.0;
+                const int itLane = it & 63;
+                const double hR = readlane_f64(hypR, itLane), hInvR2 = readlane_f64(hypInvR2, itLane);
+                const double hCx = readlane_f64(hypCx, itLane), hCy = readlane_f64(hypCy, itLane), hCz = readlane_f64(hypCz, itLane);
                 radius = hR, invR2 = hInvR2, ctx = hCx, cty = hCy, ctz = hCz;
 
                 // MSAC truncated distances of all remaining cells, in parallel, summed in tree order
@@ -590,7 +578,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
                             t2 = t * t;
                         }
                         if (park)
-                            c.s_dist[i] = t2; // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach
+                            c.scratch[(size_t)i * kCylStride + 7] = t2; // non-inliers hold +0.0, and x + 0.0 == x for every x this sum can reach
                         ps += t2;
                     }
                 }
@@ -628,7 +616,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             {
                 (void)mse_addends(true);
                 CAPE_CYL_SYNC();
-                const double mse = ordered_sum_lds(c.s_dist, N, __builtin_inf(), lane) / kInl;
+                const double mse = ordered_sum_lds<kCylStride>(c.scratch + 7, N, __builtin_inf(), lane) / kInl;
                 CAPE_CYL_SYNC();
                 planeWins = f.mse < mse;
             }

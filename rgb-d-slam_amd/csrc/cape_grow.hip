@@ -32,6 +32,9 @@ constexpr int kChunk = kStageChunk; // cells staged per step of the ordered mome
 #ifndef CAPE_B_PLANE_WAVES
 #define CAPE_B_PLANE_WAVES 2 // waves per SIMD the plane-only instances are compiled for: 256 registers, nothing spills (3 = 168 registers spills ~50)
 #endif
+#ifndef CAPE_B_RESUME_WAVES
+#define CAPE_B_RESUME_WAVES 1 // waves per SIMD the RESUME instance of the cylinder kernel is compiled for (2: 256 registers, ~120 spilled -- measured slower)
+#endif
 #ifndef CAPE_B_MSE_REGS
 #define CAPE_B_MSE_REGS 12 // cell MSEs a lane keeps in registers across the seed loop (x 64 lanes = cells covered)
 #endif
@@ -40,9 +43,10 @@ constexpr int kChunk = kStageChunk; // cells staged per step of the ordered mome
 #endif
 constexpr int kWavesPerGroup = CAPE_B_WAVES_PER_GROUP; // independent frames (waves) per workgroup
 __host__ __device__ constexpr int kChunkDoubles(int) { return kChunk * kSumStride; }
-// s_dist of the cylinder instance: one f64 per cell (+ read-ahead pad); it also stages the 18-double records of the
-// combined LLS / merged-plane traversal (cape_cylinder.h), which small grids would not leave room for
-__host__ __device__ constexpr int cyl_dist_doubles(int cells) { return cells + 16 > kChunk * 18 ? cells + 16 : kChunk * 18; }
+// s_dist of the cylinder instance: staging of the 18-double records of the combined LLS / merged-plane traversal
+// (cape_cylinder.h).  (Through round 2 it also held one MSAC cost per cell for the rare exact-sum path -- 24 KB per wave
+// on a 64x48 grid; those live in the free eighth double of the per-cell cylinder scratch now.)
+__host__ __device__ constexpr int cyl_dist_doubles(int) { return kChunk * 18; }
 
 // kernel-phase ablation for profiling experiments: -DCAPE_B_STOP_AT=k makes the wave leave after phase k
 #ifdef CAPE_B_STOP_AT
@@ -176,12 +180,38 @@ __device__ inline void inverse3_sym(const double (&S)[9], double (&r)[9])
     r[8] = cof(2, 2) * invdet;
 }
 
+// ---- state of a frame parked by the plane-only pass for the RESUME instance (p.growState, grow_state_bytes() per frame)
+struct GrowStateHeader
+{
+    int32_t nSeg;        // plane segments made so far (s_seg[0, nSeg))
+    int32_t pendFrom;    // first record that has not been converted: the cylinder candidate
+    int32_t pendCount;   // records in the window
+    int32_t pendBaseSlot; // s_seg slot of record 0 of the window
+    int32_t nSeeds, nPlanar;
+    uint32_t status;
+    int32_t pad;
+};
+constexpr int kPendCyl = 16;   // recorded regions the cylinder instance keeps at a time
+constexpr int kPendResume = 8; // ... and the RESUME instance: a frame parked with more unconverted regions takes the full redo
+__host__ __device__ constexpr size_t grow_state_seg_off() { return sizeof(GrowStateHeader); }
+__host__ __device__ constexpr size_t grow_state_adj_off() { return grow_state_seg_off() + (size_t)(kFastPlanes + 1) * kSegDoubles * 8; }
+__host__ __device__ constexpr size_t grow_state_list_off() { return grow_state_adj_off() + (size_t)(kFastPlanes + 1) * 8; }
+__host__ __device__ inline size_t grow_state_lab_off(int cells) { return grow_state_list_off() + (((size_t)cells + 4) * 2 + 7) / 8 * 8; }
+__host__ __device__ inline size_t grow_state_bytes_(int cells) { return (grow_state_lab_off(cells) + (size_t)cells + 15) / 16 * 16; }
+
 // MAXP: plane segments a frame may hold in this instance.  The two everyday instances keep kFastPlanes (32) segments in
 // LDS; a frame that needs more is handed to the MAXP = CAPE_MAX_PLANES (64) instance through p.redoList, exactly like
 // cylinder-branch frames are handed from the plane-only to the cylinder instance.
-template <typename MaskT, bool CYL, int MAXP>
-__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
+//
+// RESUME (cylinder instance only): the wave does not grow its frame -- it takes a frame the plane-only pass parked at its
+// first cylinder candidate (GrowStateHeader + arrays in p.growState: the segments made so far, the recorded regions with
+// their fits, the cell lists and the label grid) and carries on from that region: the rest of the record -> segment
+// conversion with cylinder_fitting, then merge_planes, boundaries and records like every other instance.  Without the
+// histogram, the edge masks, the MSE registers and the seed loop this instance is compiled for two waves per SIMD.
+template <typename MaskT, bool CYL, int MAXP, bool RESUME>
+__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_WAVES : 1) : CAPE_B_PLANE_WAVES) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
 {
+    static_assert(!RESUME || (CYL && MAXP == kFastPlanes), "only the 32-segment cylinder instance resumes parked frames");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -196,6 +226,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
             return;
         frame = (int)p.redoList[1 + frame];
     }
+    else if (RESUME)
+    {
+        // second pass, frames parked with their state: wave k takes the k-th of them
+        if (frame >= (int)p.resumeList[0])
+            return;
+        frame = (int)p.resumeList[1 + frame];
+    }
     else if (CYL && p.twoPass)
     {
         // second pass of the two-pass schedule: wave k takes the k-th frame the plane-only pass gave up on
@@ -207,38 +244,45 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
     const int C = p.cells, HC = p.hCells, VC = p.vCells;
     const size_t cellBase = (size_t)frame * C;
 
-    // ---- LDS carve (all offsets multiples of 16)
-    // ---- LDS carve (every offset a multiple of 8; 13.4 KB for 640x480 plane-only -> 12 waves per CU)
-    double* s_seg = reinterpret_cast<double*>(smem);                              // MAXP x 20 f64
-    double* s_chunk = s_seg + (MAXP + 1) * kSegDoubles;               // kChunk x 10 f64 staging of cell sums (s_seg: MAXP + 1 spare slot)
-    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(s_chunk + kChunkDoubles(C)); // MAXP + 1 u64
-    int* s_hist = reinterpret_cast<int*>(s_adj + MAXP + 1);            // 400 i32
-    short* s_bins = reinterpret_cast<short*>(s_hist + kHistBins);                 // C i16
-    unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + C);      // C u16
-    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C + 4);      // C u8  plane labels (list: 1 pad + C entries, rounded to 8 B)
-    unsigned char* s_mlab = s_lab + C;                                            // 32 u8 merge labels
+    // ---- LDS carve (every offset a multiple of 8; grow_lds_bytes() mirrors it).  The RESUME instance has no histogram, bins
+    //      or separate staging chunk (its ordered passes stage through s_dist), and keeps the centre-pixel depths of the
+    //      boundary phase where the RANSAC id arrays were: 17 KB per wave at 640x480.
+    double* s_seg = reinterpret_cast<double*>(smem);                              // (MAXP + 1) x 20 f64 (one spare slot for the record window)
+    double* s_afterSeg = s_seg + (MAXP + 1) * kSegDoubles;
+    double* s_chunkOwn = s_afterSeg;                                               // kChunk x 10 f64 staging of cell sums
+    unsigned long long* s_adj = reinterpret_cast<unsigned long long*>(RESUME ? s_afterSeg : s_chunkOwn + kChunkDoubles(C)); // MAXP + 1 u64
+    int* s_hist = reinterpret_cast<int*>(s_adj + MAXP + 1);                        // 400 i32
+    short* s_bins = reinterpret_cast<short*>(s_hist + (RESUME ? 0 : kHistBins));   // C i16
+    unsigned short* s_list = reinterpret_cast<unsigned short*>(s_bins + (RESUME ? 0 : C)); // 1 pad + C u16 (rounded to 8 B)
+    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_list + C + 4);      // C u8  plane labels
+    unsigned char* s_mlab = s_lab + C;                                            // MAXP u8 merge labels
     // cylinder variant only (see grow_lds_bytes)
-    unsigned char* s_cyl = s_mlab + MAXP;                              // C u8  cylinder labels
-    unsigned short* s_ids = reinterpret_cast<unsigned short*>(s_cyl + C + (C & 1)); // C u16 idsLeft
+    unsigned char* s_cyl = s_mlab + MAXP;                                         // C u8  cylinder labels
+    unsigned short* s_ids = reinterpret_cast<unsigned short*>(smem + (((size_t)(s_cyl + C - smem) + 3) & ~(size_t)3)); // C u16 idsLeft
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);        // C u8
-    unsigned char* s_cur = s_idmask + C;                                          // C u8
-    unsigned char* s_best = s_cur + C;                                            // C u8
+    unsigned char* s_best = s_idmask + C;                                         // C u8
+    // inlier flags of the hypothesis being scored: only the streamed RANSAC path (regions beyond the register cache) uses them
+    const bool needCur = !RESUME || C > 64 * kCylCacheRounds;
+    unsigned char* s_cur = s_best + C;                                            // C u8 (absent when !needCur)
     // (aligned through the OFFSET, not through an integer cast of the pointer: the cast loses the LDS address space and every
     // access through s_dist / s_pendCyl becomes a flat_load that waits for vmcnt AND lgkmcnt)
-    double* s_dist = reinterpret_cast<double*>(smem + (((size_t)(s_best + C - smem) + 15) & ~(size_t)15)); // C f64 (+ read-ahead pad)
-    double* s_pendCyl = s_dist + cyl_dist_doubles(C);                             // 16 region records (cylinder instance)
+    double* s_dist = reinterpret_cast<double*>(smem + (((size_t)(s_cur + (needCur ? C : 0) - smem) + 15) & ~(size_t)15)); // staging, 18 f64 x kChunk
+    double* s_pendCyl = s_dist + cyl_dist_doubles(C);                             // kPendSlots region records (cylinder instances)
+    double* s_chunk = RESUME ? s_dist : s_chunkOwn;
 #ifdef CAPE_B_PROFILE
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsPerWave - 8 * kProfileSlots);
     if (lane < kProfileSlots)
         s_prof[lane] = 0ull;
 #endif
-    // centre-pixel depths of the boundary phase: C f32 = exactly the bytes of s_bins + s_list, both dead after the seed loop
-    float* s_zc = reinterpret_cast<float*>(s_bins);
+    // centre-pixel depths of the boundary phase: C f32 = exactly the bytes of s_bins + s_list (RESUME: of s_ids + s_idmask +
+    // s_best), all dead after the seed loop / the last cylinder fit
+    float* s_zc = RESUME ? reinterpret_cast<float*>(s_ids) : reinterpret_cast<float*>(s_bins);
 
     const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
 
-    for (int i = lane; i < kHistBins; i += 64)
-        s_hist[i] = 0;
+    if constexpr (!RESUME)
+        for (int i = lane; i < kHistBins; i += 64)
+            s_hist[i] = 0;
     for (int i = lane; i < MAXP + 1; i += 64)
     {
         s_adj[i] = 0ull;
@@ -260,141 +304,145 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
     // One pass over flags + bins; the lanes take one grid row per ballot (two rows for grids up to 32 wide), and a batch of
     // steps is requested before the first is used, so the whole prologue costs about one memory round trip.
     // =========================================================================================
-    int nPlanarLocal = 0;
+    int nPlanar = 0;
+    if constexpr (!RESUME)
     {
-        constexpr bool kTwoRows = sizeof(MaskT) == 4;
-        const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
-        const bool colIn = col < HC;
-        const int steps = kTwoRows ? (VC + 1) / 2 : VC;
-        constexpr int kAhead = 12; // steps requested together (the 640x480 grid is 12 steps)
-        for (int t0 = 0; t0 < steps; t0 += kAhead)
+        int nPlanarLocal = 0;
         {
-            uint32_t fl[kAhead];
-            int bn[kAhead];
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k)
+            constexpr bool kTwoRows = sizeof(MaskT) == 4;
+            const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
+            const bool colIn = col < HC;
+            const int steps = kTwoRows ? (VC + 1) / 2 : VC;
+            constexpr int kAhead = 12; // steps requested together (the 640x480 grid is 12 steps)
+            for (int t0 = 0; t0 < steps; t0 += kAhead)
             {
-                const int r = kTwoRows ? 2 * (t0 + k) + h : (t0 + k);
-                const int ci = (r < VC ? r : VC - 1) * HC + (colIn ? col : 0); // clamped: unconditional loads
-                fl[k] = p.cell_flags[cellBase + ci];
-                bn[k] = p.cell_bins[cellBase + ci];
-            }
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k)
-            {
-                const int t = t0 + k;
-                if (t < steps)
+                uint32_t fl[kAhead];
+                int bn[kAhead];
+    #pragma unroll
+                for (int k = 0; k < kAhead; ++k)
                 {
-                    const int r = kTwoRows ? 2 * t + h : t;
-                    const bool in = colIn && r < VC;
-                    const uint32_t f = in ? fl[k] : 0u;
-                    if (in)
+                    const int r = kTwoRows ? 2 * (t0 + k) + h : (t0 + k);
+                    const int ci = (r < VC ? r : VC - 1) * HC + (colIn ? col : 0); // clamped: unconditional loads
+                    fl[k] = p.cell_flags[cellBase + ci];
+                    bn[k] = p.cell_bins[cellBase + ci];
+                }
+    #pragma unroll
+                for (int k = 0; k < kAhead; ++k)
+                {
+                    const int t = t0 + k;
+                    if (t < steps)
                     {
-                        const int ci = r * HC + col;
-                        s_lab[ci] = 0;
-                        if (CYL)
-                            s_cyl[ci] = 0;
-                        s_bins[ci] = (short)bn[k];
-                        if (f & kFlagPlanar)
+                        const int r = kTwoRows ? 2 * t + h : t;
+                        const bool in = colIn && r < VC;
+                        const uint32_t f = in ? fl[k] : 0u;
+                        if (in)
                         {
-                            atomicAdd(&s_hist[bn[k]], 1);
-                            ++nPlanarLocal;
+                            const int ci = r * HC + col;
+                            s_lab[ci] = 0;
+                            if (CYL)
+                                s_cyl[ci] = 0;
+                            s_bins[ci] = (short)bn[k];
+                            if (f & kFlagPlanar)
+                            {
+                                atomicAdd(&s_hist[bn[k]], 1);
+                                ++nPlanarLocal;
+                            }
+                        }
+                        if (f & kFlagNearEdge)
+                            status |= CAPE_FRAME_BIN_NEAR_EDGE;
+                        if (f & kFlagInorder)
+                            status |= CAPE_FRAME_INORDER_CELLS;
+                        const unsigned long long bU = __ballot((f & kFlagPlanar) != 0);
+                        const unsigned long long bL2M = __ballot((f & kFlagLeftToMe) != 0);
+                        const unsigned long long bM2L = __ballot((f & kFlagMeToLeft) != 0);
+                        const unsigned long long bU2M = __ballot((f & kFlagUpToMe) != 0);
+                        const unsigned long long bM2U = __ballot((f & kFlagMeToUp) != 0);
+                        if (kTwoRows)
+                        {
+                            // low words: row 2t, high words: row 2t + 1 ; lane q keeps row q's masks (rows past the grid give zeros)
+                            if (lane == 2 * t)
+                            {
+                                U = (MaskT)(uint32_t)bU;
+                                EL = (MaskT)(uint32_t)bL2M;
+                                ER = (MaskT)((uint32_t)bM2L >> 1);
+                                EU = (MaskT)(uint32_t)bU2M;
+                                ED = (MaskT)(uint32_t)(bM2U >> 32); // parent row 2t + 1 -> child row 2t
+                            }
+                            if (lane == 2 * t + 1)
+                            {
+                                U = (MaskT)(uint32_t)(bU >> 32);
+                                EL = (MaskT)(uint32_t)(bL2M >> 32);
+                                ER = (MaskT)((uint32_t)(bM2L >> 32) >> 1);
+                                EU = (MaskT)(uint32_t)(bU2M >> 32);
+                            }
+                            if (lane == 2 * t - 1)
+                                ED = (MaskT)(uint32_t)bM2U; // parent row 2t -> child row 2t - 1
+                        }
+                        else
+                        {
+                            if (lane == t)
+                            {
+                                U = (MaskT)bU;
+                                EL = (MaskT)bL2M;
+                                ER = (MaskT)(bM2L >> 1);
+                                EU = (MaskT)bU2M;
+                            }
+                            if (lane == t - 1)
+                                ED = (MaskT)bM2U;
                         }
                     }
-                    if (f & kFlagNearEdge)
-                        status |= CAPE_FRAME_BIN_NEAR_EDGE;
-                    if (f & kFlagInorder)
-                        status |= CAPE_FRAME_INORDER_CELLS;
-                    const unsigned long long bU = __ballot((f & kFlagPlanar) != 0);
-                    const unsigned long long bL2M = __ballot((f & kFlagLeftToMe) != 0);
-                    const unsigned long long bM2L = __ballot((f & kFlagMeToLeft) != 0);
-                    const unsigned long long bU2M = __ballot((f & kFlagUpToMe) != 0);
-                    const unsigned long long bM2U = __ballot((f & kFlagMeToUp) != 0);
-                    if (kTwoRows)
+                }
+            }
+        }
+        // the vertical edges between the first cell row of a stage-A2 tile and the row above it (rows k * a2RowsPerTile):
+        // both rows' planes are read back and the predicate is evaluated here, exactly as stage A2 does inside a tile
+        {
+            constexpr bool kTwoRows = sizeof(MaskT) == 4;
+            const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
+            const bool colIn = col < HC;
+            const int RPT = p.a2RowsPerTile;
+            const int nB = (VC - 1) / RPT; // boundaries at rows RPT, 2 RPT, ... < VC
+            for (int s0 = 0; s0 < nB; s0 += (kTwoRows ? 2 : 1))
+            {
+                const int k = s0 + h + 1;
+                const int r = k * RPT;
+                const bool on = colIn && k <= nB;
+                const int rr = (k <= nB ? r : RPT);
+                const size_t ciMe = cellBase + (size_t)rr * HC + (colIn ? col : 0), ciUp = ciMe - HC;
+                const double2* pm = reinterpret_cast<const double2*>(p.cell_plane + ciMe * kPlaneStride);
+                const double2* pu = reinterpret_cast<const double2*>(p.cell_plane + ciUp * kPlaneStride);
+                const double2 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
+                const double2 u0 = pu[0], u1 = pu[1], u2 = pu[2], u3 = pu[3];
+                const double mtol = (double)p.cell_tol[ciMe], utol = (double)p.cell_tol[ciUp];
+                const bool u2m = on & can_be_merged(u0.x, u0.y, u1.x, u1.y, m0.x, m0.y, m1.x, m2.x, m2.y, m3.x, mtol, p.cosMerge);
+                const bool m2u = on & can_be_merged(m0.x, m0.y, m1.x, m1.y, u0.x, u0.y, u1.x, u2.x, u2.y, u3.x, utol, p.cosMerge);
+                const unsigned long long bU2M = __ballot(u2m), bM2U = __ballot(m2u);
+                if (kTwoRows)
+                {
+                    const int ra = (s0 + 1) * RPT, rb = (s0 + 2) * RPT; // boundary rows of the even / odd half
+                    if (lane == ra)
+                        EU = (MaskT)(uint32_t)bU2M;
+                    if (lane == ra - 1)
+                        ED = (MaskT)(uint32_t)bM2U;
+                    if (s0 + 2 <= nB)
                     {
-                        // low words: row 2t, high words: row 2t + 1 ; lane q keeps row q's masks (rows past the grid give zeros)
-                        if (lane == 2 * t)
-                        {
-                            U = (MaskT)(uint32_t)bU;
-                            EL = (MaskT)(uint32_t)bL2M;
-                            ER = (MaskT)((uint32_t)bM2L >> 1);
-                            EU = (MaskT)(uint32_t)bU2M;
-                            ED = (MaskT)(uint32_t)(bM2U >> 32); // parent row 2t + 1 -> child row 2t
-                        }
-                        if (lane == 2 * t + 1)
-                        {
-                            U = (MaskT)(uint32_t)(bU >> 32);
-                            EL = (MaskT)(uint32_t)(bL2M >> 32);
-                            ER = (MaskT)((uint32_t)(bM2L >> 32) >> 1);
+                        if (lane == rb)
                             EU = (MaskT)(uint32_t)(bU2M >> 32);
-                        }
-                        if (lane == 2 * t - 1)
-                            ED = (MaskT)(uint32_t)bM2U; // parent row 2t -> child row 2t - 1
-                    }
-                    else
-                    {
-                        if (lane == t)
-                        {
-                            U = (MaskT)bU;
-                            EL = (MaskT)bL2M;
-                            ER = (MaskT)(bM2L >> 1);
-                            EU = (MaskT)bU2M;
-                        }
-                        if (lane == t - 1)
-                            ED = (MaskT)bM2U;
+                        if (lane == rb - 1)
+                            ED = (MaskT)(uint32_t)(bM2U >> 32);
                     }
                 }
-            }
-        }
-    }
-    // the vertical edges between the first cell row of a stage-A2 tile and the row above it (rows k * a2RowsPerTile):
-    // both rows' planes are read back and the predicate is evaluated here, exactly as stage A2 does inside a tile
-    {
-        constexpr bool kTwoRows = sizeof(MaskT) == 4;
-        const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
-        const bool colIn = col < HC;
-        const int RPT = p.a2RowsPerTile;
-        const int nB = (VC - 1) / RPT; // boundaries at rows RPT, 2 RPT, ... < VC
-        for (int s0 = 0; s0 < nB; s0 += (kTwoRows ? 2 : 1))
-        {
-            const int k = s0 + h + 1;
-            const int r = k * RPT;
-            const bool on = colIn && k <= nB;
-            const int rr = (k <= nB ? r : RPT);
-            const size_t ciMe = cellBase + (size_t)rr * HC + (colIn ? col : 0), ciUp = ciMe - HC;
-            const double2* pm = reinterpret_cast<const double2*>(p.cell_plane + ciMe * kPlaneStride);
-            const double2* pu = reinterpret_cast<const double2*>(p.cell_plane + ciUp * kPlaneStride);
-            const double2 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
-            const double2 u0 = pu[0], u1 = pu[1], u2 = pu[2], u3 = pu[3];
-            const double mtol = (double)p.cell_tol[ciMe], utol = (double)p.cell_tol[ciUp];
-            const bool u2m = on & can_be_merged(u0.x, u0.y, u1.x, u1.y, m0.x, m0.y, m1.x, m2.x, m2.y, m3.x, mtol, p.cosMerge);
-            const bool m2u = on & can_be_merged(m0.x, m0.y, m1.x, m1.y, u0.x, u0.y, u1.x, u2.x, u2.y, u3.x, utol, p.cosMerge);
-            const unsigned long long bU2M = __ballot(u2m), bM2U = __ballot(m2u);
-            if (kTwoRows)
-            {
-                const int ra = (s0 + 1) * RPT, rb = (s0 + 2) * RPT; // boundary rows of the even / odd half
-                if (lane == ra)
-                    EU = (MaskT)(uint32_t)bU2M;
-                if (lane == ra - 1)
-                    ED = (MaskT)(uint32_t)bM2U;
-                if (s0 + 2 <= nB)
+                else
                 {
-                    if (lane == rb)
-                        EU = (MaskT)(uint32_t)(bU2M >> 32);
-                    if (lane == rb - 1)
-                        ED = (MaskT)(uint32_t)(bM2U >> 32);
+                    if (lane == r)
+                        EU = (MaskT)bU2M;
+                    if (lane == r - 1)
+                        ED = (MaskT)bM2U;
                 }
             }
-            else
-            {
-                if (lane == r)
-                    EU = (MaskT)bU2M;
-                if (lane == r - 1)
-                    ED = (MaskT)bM2U;
-            }
         }
+        nPlanar = wave_sum_i32(nPlanarLocal);
     }
-    const int nPlanar = wave_sum_i32(nPlanarLocal);
     CAPE_WAVE_SYNC();
     CAPE_B_STOP(1);
     CAPE_TICK(0);
@@ -418,11 +466,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
     const bool mseInRegs = C <= 64 * kMseRegs;
     const double* mseBase = p.cell_mse + cellBase;
     double mreg[kMseRegs];
-#pragma unroll
-    for (int k = 0; k < kMseRegs; ++k)
+    if constexpr (!RESUME)
     {
-        const int i = lane + 64 * k;
-        mreg[k] = mseBase[i < C ? i : 0];
+#pragma unroll
+        for (int k = 0; k < kMseRegs; ++k)
+        {
+            const int i = lane + 64 * k;
+            mreg[k] = mseBase[i < C ? i : 0];
+        }
     }
 
     // What a seed's region is (label propagation), what it costs the histogram and the unassigned mask, and hence every
@@ -433,16 +484,48 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
     // turned into segments in seed order.  Plane-only instances park the records in the free s_seg slots above nSeg (a
     // segment is never written above the record it comes from); the cylinder instance, whose cylinder_fitting appends
     // segments of its own, has a separate area.
-    constexpr int kPendCyl = 16;
     double* s_pend = CYL ? s_pendCyl : s_seg;     // base of the record window (plane-only: advanced to s_seg + nSeg at each flush)
     int pendCount = 0, pendCap = CYL ? kPendCyl : MAXP + 1;
     int listTop = 0;                               // bump pointer in s_list: recorded regions keep their cell lists
-    bool moreSeeds = true;
+    bool moreSeeds = !RESUME;
+
+    if constexpr (RESUME)
+    {
+        // ---- pick the frame up where the plane-only pass parked it
+        const unsigned char* st = p.growState + (size_t)frame * p.growStateStride;
+        const GrowStateHeader hd = *reinterpret_cast<const GrowStateHeader*>(st);
+        const double* gseg = reinterpret_cast<const double*>(st + grow_state_seg_off());
+        const unsigned long long* gadj = reinterpret_cast<const unsigned long long*>(st + grow_state_adj_off());
+        const unsigned short* glist = reinterpret_cast<const unsigned short*>(st + grow_state_list_off());
+        const unsigned char* glab = st + grow_state_lab_off(C);
+        nSeg = hd.nSeg;
+        nSeeds = hd.nSeeds;
+        nPlanar = hd.nPlanar;
+        untried = 0;
+        status = lane == 0 ? hd.status : 0u;
+        const int nRec = hd.pendCount - hd.pendFrom;
+        for (int i = lane; i < nSeg * kSegDoubles; i += 64)
+            s_seg[i] = gseg[i];
+        for (int i = lane; i < nRec * kSegDoubles; i += 64)
+            s_pendCyl[i] = gseg[(hd.pendBaseSlot + hd.pendFrom) * kSegDoubles + i];
+        if (lane < nRec)
+            s_adj[lane] = gadj[hd.pendFrom + lane];
+        for (int i = lane; i < C + 4; i += 64)
+            s_list[i] = glist[i];
+        for (int i = lane; i < C; i += 64)
+        {
+            s_lab[i] = glab[i];
+            s_cyl[i] = 0;
+        }
+        pendCount = nRec;
+        CAPE_WAVE_SYNC();
+    }
 
     for (;;)
     {
         if (moreSeeds && !(untried > 0 && nSeeds < maxSeedIters))
             moreSeeds = false;
+        if constexpr (!RESUME)
         if (moreSeeds)
             do
             {
@@ -661,7 +744,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
         {
             // ---- fit_plane (plane_segment.cpp:232-284) of every recorded region, one lane per region
             CAPE_TICK_RESTART();
-            if (lane < pendCount)
+            if (!RESUME && lane < pendCount) // (a parked frame's records carry their fits)
             {
                 double* slot = s_pend + lane * kSegDoubles;
                 double S[9];
@@ -714,8 +797,45 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
                 else if (!CYL && !kRedo && p.twoPass && total > 5)
                 {
                     // first pass of the two-pass schedule: this region goes to cylinder_fitting, which the plane-only kernel does
-                    // not carry -- hand the whole frame to the cylinder kernel (it starts over; nothing written so far counts)
-                    if (lane == 0)
+                    // not carry.  If the seed loop is over (every region of the frame is recorded -- the usual case: the window
+                    // holds 33 regions) the frame is PARKED: segments so far, the window with its fits, cell lists and labels go
+                    // to p.growState and the RESUME instance of the cylinder kernel carries on from this record.  Otherwise the
+                    // whole frame is handed to the cylinder kernel, which starts it over (nothing written so far counts).
+                    const bool parked = MAXP == kFastPlanes && p.resumeList != nullptr && !moreSeeds && pendCount - j <= kPendResume;
+                    if (parked)
+                    {
+                        unsigned char* st = p.growState + (size_t)frame * p.growStateStride;
+                        const uint32_t statusAll = wave_or_u32(status);
+                        const int baseSlot = (int)((s_pend - s_seg) / kSegDoubles);
+                        if (lane == 0)
+                        {
+                            GrowStateHeader hd;
+                            hd.nSeg = nSeg;
+                            hd.pendFrom = j;
+                            hd.pendCount = pendCount;
+                            hd.pendBaseSlot = baseSlot;
+                            hd.nSeeds = nSeeds;
+                            hd.nPlanar = nPlanar;
+                            hd.status = statusAll;
+                            hd.pad = 0;
+                            *reinterpret_cast<GrowStateHeader*>(st) = hd;
+                        }
+                        double* gseg = reinterpret_cast<double*>(st + grow_state_seg_off());
+                        unsigned long long* gadj = reinterpret_cast<unsigned long long*>(st + grow_state_adj_off());
+                        unsigned short* glist = reinterpret_cast<unsigned short*>(st + grow_state_list_off());
+                        unsigned char* glab = st + grow_state_lab_off(C);
+                        for (int i = lane; i < (baseSlot + pendCount) * kSegDoubles; i += 64)
+                            gseg[i] = s_seg[i];
+                        if (lane < pendCount)
+                            gadj[lane] = s_adj[lane];
+                        for (int i = lane; i < C + 4; i += 64)
+                            glist[i] = s_list[i];
+                        for (int i = lane; i < C; i += 64)
+                            glab[i] = s_lab[i];
+                        if (lane == 0)
+                            p.resumeList[1 + atomicAdd(&p.resumeList[0], 1u)] = (uint32_t)frame;
+                    }
+                    else if (lane == 0)
                         p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
                     return;
                 }
@@ -1102,25 +1222,39 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? 1 : CAPE_B_PLANE_WAVES) 
 #endif
 }
 
-size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes)
+size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes, bool resume)
 {
     size_t b = 0;
     b += (size_t)(maxPlanes + 1) * kSegDoubles * 8; // s_seg (+ one spare slot for the record window)
-    b += (size_t)kChunkDoubles(cells) * 8;          // s_chunk
+    if (!resume)
+        b += (size_t)kChunkDoubles(cells) * 8;      // s_chunk (the RESUME instance stages through s_dist)
     b += (size_t)(maxPlanes + 1) * 8;               // s_adj
-    b += (size_t)kHistBins * 4;                     // s_hist
-    b += (size_t)cells * 2;                         // s_bins  } after the seed loop these two hold s_zc
+    if (!resume)
+    {
+        b += (size_t)kHistBins * 4;                 // s_hist
+        b += (size_t)cells * 2;                     // s_bins  } after the seed loop these two hold s_zc
+    }
     b += (size_t)cells * 2 + 8;                     // s_list  } (+ pad entry)
     b += (size_t)cells;                             // s_lab
-    b += maxPlanes;                           // s_mlab
+    b += maxPlanes;                                 // s_mlab
     if (cylinders)
-        b += (size_t)cells + 2 + (size_t)cells * 2 + (size_t)cells * 3 + 16 + (size_t)cyl_dist_doubles(cells) * 8 // s_cyl, s_ids, masks, s_dist
-             + 16 * kSegDoubles * 8;                                                                // s_pendCyl
+    {
+        b += (size_t)cells;                         // s_cyl
+        b = (b + 3) & ~(size_t)3;
+        b += (size_t)cells * 2 + (size_t)cells * 2; // s_ids, s_idmask, s_best
+        if (!resume || cells > 64 * kCylCacheRounds)
+            b += (size_t)cells;                     // s_cur
+        b = (b + 15) & ~(size_t)15;
+        b += (size_t)cyl_dist_doubles(cells) * 8;   // s_dist
+        b += (size_t)(resume ? kPendResume : kPendCyl) * kSegDoubles * 8; // s_pendCyl
+    }
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots; // s_prof
 #endif
     return (b + 15) & ~(size_t)15;
 }
+size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes) { return grow_lds_bytes(cells, cylinders, maxPlanes, false); }
+size_t grow_state_bytes(int cells) { return grow_state_bytes_(cells); }
 
 int grow_waves_per_group() { return kWavesPerGroup; }
 
@@ -1135,20 +1269,20 @@ int grow_waves_per_cu(const StageBParams& p)
     int blocks = 0;
     hipError_t e;
     if (p.hCells <= 32)
-        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg);
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
     else
-        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, true, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, false, kFastPlanes>, 64 * wpg, (size_t)ldsPerWave * wpg);
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, true, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<unsigned long long, false, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
     return e == hipSuccess ? blocks * wpg : 0;
 }
 
 namespace {
 
-template <bool CYL, int MAXP>
+template <bool CYL, int MAXP, bool RESUME = false>
 hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t stream)
 {
-    const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL, MAXP);
+    const int ldsPerWave = (int)grow_lds_bytes(p.cells, CYL, MAXP, RESUME);
     int wpg = kWavesPerGroup; // as many independent frame-waves per workgroup as the device's LDS admits (<= kWavesPerGroup)
     while (wpg > 1 && (size_t)ldsPerWave * wpg > (size_t)p.ldsLimitBytes)
         --wpg;
@@ -1157,9 +1291,9 @@ hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t s
         return hipErrorInvalidConfiguration; // cape_create refuses such grids; belt and braces
     const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
-        hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+        hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL, MAXP, RESUME>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     else
-        hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL, MAXP>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+        hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL, MAXP, RESUME>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     return hipGetLastError();
 }
 
@@ -1201,8 +1335,12 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
     {
         if (!p.countersCleared)
             CAPE_LAUNCH_TRY(hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream));
+        if (p.resumeList && !p.countersCleared)
+            CAPE_LAUNCH_TRY(hipMemsetAsync(p.resumeList, 0, sizeof(uint32_t), stream));
         CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
-        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream)));
+        if (p.resumeList)
+            CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes, true>(p, nFrames, stream))); // frames parked with their state
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream)));           // frames that start over (rare once parking is on)
     }
     if (p.redoList)
         CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));

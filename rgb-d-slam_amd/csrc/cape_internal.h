@@ -63,8 +63,9 @@ struct StageAParams
     CellAux* cell_aux;
     double* cell_mse;
     float sinMerge; // sinf((float)(18 * pi / 180)), primitive_detection.cpp:189-190
-    uint32_t* clear0; // hand-over counters of the grow kernel (redo list, cylinder list): zeroed by one thread of stage A2, which
-    uint32_t* clear1; // always runs right before it on the same stream -- instead of two memset nodes per call
+    uint32_t* clear0; // hand-over counters of the grow kernel (redo list, cylinder list, resume list): zeroed by one thread of
+    uint32_t* clear1; // stage A2, which always runs right before it on the same stream -- instead of memset nodes per call
+    uint32_t* clear2;
     double cosMergeA; // cos(18 * pi / 180), plane_segment.cpp:324 (the edge predicates of stage A2)
     int smallBatchFrames; // host side: batches up to this many frames run the latency-oriented kernel instances
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
@@ -101,6 +102,13 @@ struct StageBParams
     // cylinder branch; the cylinder kernel then redoes exactly the listed frames.  nullptr: single pass.
     uint32_t* needCylinder;
     uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
+    // Hand-over WITH state (round 3): when the plane-only pass reaches a cylinder candidate after its seed loop has ended, it
+    // parks what it has -- segments so far, the recorded regions with their fits, cell lists, labels -- in growState and
+    // appends the frame to resumeList; the RESUME instance of the cylinder kernel picks the frame up at that region instead
+    // of growing it again from the first seed (grow_state_bytes() per frame; nullptr: always the full redo).
+    uint32_t* resumeList;
+    unsigned char* growState;
+    uint32_t growStateStride;
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
     int countersCleared;     // 1: stage A2 zeroed redoList[0] / needCylinder[0] (StageAParams::clear0/1); 0: launch_grow does

@@ -28,7 +28,7 @@ def _properties_all_frames(res, n, cells):
     assert not ((res.plane_labels[:n] > 0) & (res.cyl_labels[:n] > 0)).any()
 
 
-def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=False, chunk=64):
+def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=False, chunk=64, keep=()):
     import torch
     from cape_amd import Extractor, synth_gpu
 
@@ -64,7 +64,8 @@ def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=Fals
     ex1.close()
     matches = ex.matches(n) if match else None
     ex.close()
-    return n_planes, n_cyl, res, matches
+    kept = dev[list(keep)].cpu().numpy() if keep else None  # the very frames of the batch (a re-rendered stream may chunk its noise differently)
+    return n_planes, n_cyl, res, (matches, kept) if match else None
 
 
 def test_configs1_room_4096_plane_only(oracle_mod):
@@ -84,15 +85,13 @@ def test_configs2_tunnel_2048_cylinders(oracle_mod):
 def test_configs4_1280x960_tunnel_1024_cylinders_match(oracle_mod):
     """BASELINE.json configs[4], one-GPU leg: 1 024 frames of 1280x960, planes + cylinders + consecutive-frame matching."""
     import match_oracle
-    from cape_amd import synth_gpu
-
     n = 1024
-    _, n_cyl, res, matches = _check_stream(oracle_mod, "tunnel", True, n, W=1280, H=960, stride=32, match=True, chunk=16)
+    _, n_cyl, res, (matches, dev) = _check_stream(oracle_mod, "tunnel", True, n, W=1280, H=960, stride=32, match=True, chunk=16,
+                                                  keep=(510, 511, 512, 513))
     assert n_cyl >= 16
     # the matcher on two consecutive pairs, against match_oracle fed with the oracle's own frames
     intr = _intr("tunnel", 2.0)
     orc = oracle_mod.Oracle(1280, 960, cylinders=True, **intr)
-    dev = synth_gpu.stream("tunnel", 100, 4, width=1280, height=960, start=510, device="cuda", chunk=4).cpu().numpy()
 
     def per(depth):
         r = orc.run(depth)
