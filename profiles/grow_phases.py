@@ -30,6 +30,10 @@ ex = Extractor(W, H, max_batch=B, cylinders=cyl, **intr)
 ex.extract_device(d.data_ptr(), B, torch.cuda.current_stream().cuda_stream)
 cyc = ex.debug_cycles(B).astype(np.float64)
 tot = cyc[:, :23].sum(1) + cyc[:, 28:30].sum(1)  # slots 23, 30, 31 are sub-intervals of the covariance passes
+if os.environ.get("CAPE_PHASES_GROUP"):  # sub-intervals of the group kernel's phases reuse the seed-loop slots (it has no seed loop)
+    for k, nm in {1: "group RANSAC: scoring", 2: "group RANSAC: wave reductions", 3: "group RANSAC: barrier", 4: "group RANSAC: replay",
+                  5: "group LLS: consume (wave 0)", 6: "group LLS: wait for producers"}.items():
+        NAMES[k] = nm
 print(f"frames {B}: mean ticks/frame {tot.mean():.0f} (s_memtime = shader clock, ~2.3 GHz => {tot.mean() / 2300:.1f} us)  seeds/frame {ex.results(B, False).records['header']['n_seeds'].mean():.1f}")
 for k, nm in enumerate(NAMES):
     if nm.startswith("#"):

@@ -23,6 +23,7 @@ int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 size_t grow_state_bytes(int cells);
+bool resume_group_fits(const StageBParams& p);
 hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_pack(const PackParams& p, hipStream_t stream);
@@ -467,13 +468,18 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         constexpr int kProbeEvery = 32; // a single-pass handle re-measures with a two-pass call now and then
         if (h->handedOverFrames > 0 && hipEventQuery(h->handedOverReady) == hipSuccess)
         {
-            h->handedOverFraction = (double)*h->handedOverHost / (double)h->handedOverFrames;
+            h->handedOverFraction = (double)(h->handedOverHost[0] + h->handedOverHost[1]) / (double)h->handedOverFrames; // redone + parked
             h->handedOverFrames = 0;
         }
         {
             const double slots = (double)(h->cylSlots > 0 ? h->cylSlots : 1024);
             const double alone = std::ceil((double)frames / slots);
-            const double twoPass = kPlanePassPerRound * (double)frames / slots + std::ceil(h->handedOverFraction * (double)frames / slots);
+            // a parked frame is finished, not grown again: its round of the second pass is shorter (measured, 640x480: 0.12 ms
+            // per 1 024 tunnel frames by the lone-wave RESUME instance against 0.15 ms for the full kernel; the workgroup
+            // kernel of the wide grids: 0.5 ms against 0.97 ms per 1 024 frames of 1280x960)
+            const double secondPassPerRound = !bb.resumeList ? 1.0 : (bb.resumeMode == 2 ? 0.5 : 0.8);
+            const double twoPass = kPlanePassPerRound * (double)frames / slots +
+                                   secondPassPerRound * std::ceil(h->handedOverFraction * (double)frames / slots);
             h->singlePass = twoPass >= alone;
         }
         const bool probe = h->singlePass && ++h->callsSinceProbe >= kProbeEvery;
@@ -487,6 +493,8 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0)
     {
         CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost, bb.needCylinder, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (bb.resumeList)
+            CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost + 1, bb.resumeList, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CAPE_HIP_TRY(hipEventRecord(h->handedOverReady, st));
         h->handedOverFrames = frames;
     }
@@ -638,13 +646,16 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     {
         CAPE_ALLOC(dalloc(h->cylScratch, B * C * cape::kCylStride));
         CAPE_ALLOC(dalloc(h->needCylinder, 2 * B + 2));
-        if (!std::getenv("CAPE_NO_RESUME")) // debug knob: the round-2 schedule (every handed-over frame is grown again from scratch)
+        // debug knob CAPE_RESUME=off: the round-2 schedule (every handed-over frame is grown again from scratch)
+        const char* resumeEnv = std::getenv("CAPE_RESUME");
+        if (!(resumeEnv && std::string(resumeEnv) == "off") && !std::getenv("CAPE_NO_RESUME"))
         {
             CAPE_ALLOC(dalloc(h->resumeList, 2 * B + 2));
             CAPE_ALLOC(hipMemset(h->resumeList, 0, (2 * B + 2) * sizeof(uint32_t)));
             CAPE_ALLOC(dalloc(h->growState, B * cape::grow_state_bytes(h->cells)));
         }
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), sizeof(uint32_t)));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), 2 * sizeof(uint32_t)));
+        h->handedOverHost[0] = h->handedOverHost[1] = 0;
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
@@ -786,6 +797,18 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.resumeList = h->resumeList;
     b.growState = h->growState;
     b.growStateStride = (uint32_t)cape::grow_state_bytes(h->cells);
+    b.ldsLimitBytes = h->ldsLimit;
+    {
+        // Parked frames are finished by one WORKGROUP each on the wide grids (1280x960: 0.64 ms against 0.74 ms per 1 024 tunnel
+        // frames) and by one WAVEFRONT each on grids up to 32 cells wide, where the lean lone-wave instance keeps four times as
+        // many frames in flight and wins (640x480: 0.33 against 0.44 ms per 2 048 tunnel frames, 0.52 against 0.60 ms per 4 096
+        // room frames; profiles/r03_cylinder_schedules.txt).  CAPE_RESUME=wave|group forces one (A/B runs, tests).
+        const char* resumeEnv = std::getenv("CAPE_RESUME");
+        const std::string forced = resumeEnv ? resumeEnv : "";
+        b.resumeMode = (h->hCells > 32 && forced != "wave") || forced == "group" ? 2 : 1;
+        if (!cape::resume_group_fits(b))
+            b.resumeMode = 1;
+    }
     b.twoPass = h->needCylinder ? 1 : 0;
     b.ldsLimitBytes = h->ldsLimit;
     if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > (size_t)h->ldsLimit)

@@ -109,6 +109,8 @@ struct StageBParams
     uint32_t* resumeList;
     unsigned char* growState;
     uint32_t growStateStride;
+    int resumeMode;          // how parked frames are finished: 2 = one workgroup per frame (cape_resume.hip), 1 = one wavefront
+                             // per frame (the RESUME instance of the grow kernel; kept for A/B runs: CAPE_RESUME=wave)
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
     int countersCleared;     // 1: stage A2 zeroed redoList[0] / needCylinder[0] (StageAParams::clear0/1); 0: launch_grow does

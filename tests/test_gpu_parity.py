@@ -619,6 +619,38 @@ def test_cylinder_schedules_agree(oracle_mod):
     ex.close()
 
 
+@pytest.mark.parametrize("mode", ["wave", "group", "off"])
+@pytest.mark.parametrize("w,h,n", [(640, 480, 48), (1280, 960, 12)])
+def test_cylinder_resume_modes(oracle_mod, monkeypatch, mode, w, h, n):
+    """A frame that reaches a cylinder candidate is parked by the plane-only pass and finished by one wavefront (the RESUME
+    instance of the grow kernel), by one workgroup (cape_resume.hip) or -- CAPE_RESUME=off, the round-2 schedule -- grown
+    again from scratch by the cylinder kernel.  Three implementations of cylinder_fitting's bookkeeping around the same
+    arithmetic: every one must give the oracle's bits, on both mask widths, on scenes with small and wall-sized candidates."""
+    import torch
+    from cape_amd import Extractor, synth_gpu
+
+    monkeypatch.setenv("CAPE_RESUME", mode)
+    monkeypatch.setenv("CAPE_SCHEDULE", "two")
+    scale = w / 640.0
+    for scene in ("room", "tunnel", "tumlike"):
+        intr = _intr(scene, scale)
+        dev = synth_gpu.stream(scene, 31, n, width=w, height=h, start=200, device="cuda", chunk=8)
+        frames = dev.cpu().numpy()
+        orc = oracle_mod.Oracle(w, h, cylinders=True, **intr)
+        ex = Extractor(w, h, cylinders=True, max_batch=n, **intr)
+        for _ in range(2):
+            ex.extract_device(dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+            res = ex.results(n)
+        cyl_frames = 0
+        for f in range(n):
+            r = orc.run(frames[f])
+            compare_frame(r, ex, res, f, check_cells=False)
+            cyl_frames += int(len(r.cylinders) > 0)
+        ex.close()
+        if scene == "tunnel":
+            assert cyl_frames >= n // 2, "the tunnel stream must exercise cylinder_fitting"
+
+
 @pytest.mark.parametrize("cyl", [False, True])
 def test_sub_batch_pipeline_matches_single_chain(oracle_mod, cyl):
     """cape_config.sub_batches > 1 cuts a batch into sub-batches that alternate between two internal streams; results
