@@ -279,6 +279,11 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     }
 
     // ------------------------------------------------------------------ per-cell scans: wave 0, one lane per cell
+    // (Round 3 spread the 37 steps of a cell's cross scan over all five waves as independent tests -- a step only needs the
+    // latest valid depth before it -- to release the workgroup's LDS earlier.  Bit-exact, and slower: 1.68 ms against 1.46 ms
+    // per 4 096 frames.  One lane per cell runs a step in ~12 instructions for 64 cells at once; one lane per TEST pays the
+    // index arithmetic, the look-back loop and its branches per test, ~5x the wave-instructions, and this kernel is bound by
+    // VALU issue, not by the LDS it holds.)
     if (t >= 64)
         return;
     const int fb = t >> 5, fs = t & 31;
@@ -346,6 +351,9 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef CAPE_A2_WAVES
 #define CAPE_A2_WAVES 4
+#endif
+#ifndef CAPE_A2_ABLATE
+#define CAPE_A2_ABLATE 0
 #endif
 // A workgroup owns a TILE of whole cell rows of one frame (THREADS cells at most, one lane per cell).  After the fit every
 // cell publishes its plane (normal, d, centroid, merge tolerance) in LDS, and each lane evaluates region_growing's merge
@@ -449,7 +457,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
                 n = 0;
                 rewrite = true;
             }
-            else if (n >= (uint32_t)p.minZeroPointCount)
+            // (CAPE_A2_ABLATE: timing experiments only -- profiles/a2_ablation.sh builds one library per bit and reports what
+            //  each part of the kernel costs; results of such a build are wrong by construction.  1 = no plane fit,
+            //  2 = no histogram bin (acos / atan2), 4 = no edge predicates, 8 = no tolerance)
+            else if (n >= (uint32_t)p.minZeroPointCount && !(CAPE_A2_ABLATE & 1))
             {
                 fit_plane(S, n, f);
                 const double qz = depth_quantization(f.cz);
@@ -464,6 +475,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
             }
 
             // _cellDistanceTols (primitive_detection.cpp:201-220): first and last cloud rows of the cell (zeros if invalid)
+            if ((CAPE_A2_ABLATE & 1) && n >= (uint32_t)p.minZeroPointCount)
+            {
+                planar = S[2] > 0.0; // keep the downstream work alive without the fit
+                f.nx = S[0] * 1e-9, f.ny = S[1] * 1e-9, f.nz = -0.5, f.d = S[2] * 1e-6, f.cx = S[0] / n, f.cy = S[1] / n, f.cz = S[2] / n;
+            }
             if (planar)
             {
                 const float z0 = aux.z0, z1 = aux.z399;
@@ -482,12 +498,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
                     zz1 = z1;
                 }
                 const float dx = x1 - x0, dy = y1 - y0, dz = zz1 - zz0;
-                const float diam = sqrtf(dx * dx + (dy * dy + dz * dz));
-                tol = std_minf(50.0f, diam * p.sinMerge * sqrtf((float)n));
+                const float diam = (CAPE_A2_ABLATE & 8) ? dx : sqrtf(dx * dx + (dy * dy + dz * dz));
+                tol = (CAPE_A2_ABLATE & 8) ? diam : std_minf(50.0f, diam * p.sinMerge * sqrtf((float)n));
 
                 // init_histogram (primitive_detection.cpp:253-254) + Histogram::init_histogram (histogram.hpp:48-54)
-                const double theta = acos(-f.nz);
-                const double phi = atan2(f.nx, f.ny);
+                const double theta = (CAPE_A2_ABLATE & 2) ? -f.nz : acos(-f.nz);
+                const double phi = (CAPE_A2_ABLATE & 2) ? f.nx : atan2(f.nx, f.ny);
                 constexpr double kPi = 3.14159265358979323846;
                 const double tx = 19.0 * (theta - 0.0) / kPi;
                 const int xQ = (int)floor(tx);
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
         uint32_t edges = 0;
         if (valid)
         {
-            if (cellCol > 0)
+            if (cellCol > 0 && !(CAPE_A2_ABLATE & 4))
             {
                 const CellPub L = s_pub[tid - 1];
                 if (can_be_merged(L.nx, L.ny, L.nz, L.d, me.nx, me.ny, me.nz, me.cx, me.cy, me.cz, me.tol, p.cosMergeA))
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
                 if (can_be_merged(me.nx, me.ny, me.nz, me.d, L.nx, L.ny, L.nz, L.cx, L.cy, L.cz, L.tol, p.cosMergeA))
                     edges |= kFlagMeToLeft;
             }
-            if (lrow > 0) // the tile's first row: its upper neighbours belong to another workgroup (see above)
+            if (lrow > 0 && !(CAPE_A2_ABLATE & 4)) // the tile's first row: its upper neighbours belong to another workgroup (see above)
             {
                 const CellPub Up = s_pub[tid - HC];
                 if (can_be_merged(Up.nx, Up.ny, Up.nz, Up.d, me.nx, me.ny, me.nz, me.cx, me.cy, me.cz, me.tol, p.cosMergeA))
