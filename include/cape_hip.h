@@ -319,6 +319,47 @@ int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void
 int cape_device_matches(cape_handle h, void** matches);
 int cape_copy_matches(cape_handle h, int32_t n_frames, cape_frame_match* out);
 
+/* "Next" row N1 on the device: the boundary polygon of every output plane of the last cape_extract batch -- what the
+ * reference builds on the host right after the boundary candidates, `utils::Polygon(points, normal, center)`
+ * (primitive_detection.cpp:622 -> src/utils/polygon.cpp:168-229: plane frame :74-115, projection :125-144, concave hull
+ * :283-318 with the convex hull :268-281 as fallback, area :453-461, simplify :578-601), one wavefront per plane.
+ * A polygon is a ring of 2-D vertices in the plane frame (x_axis, y_axis, center), clockwise, first vertex not repeated:
+ * exactly the arguments of the reference's Polygon(ring, xAxis, yAxis, center) constructor (polygon.cpp:236-266), which is
+ * how the overlay turns a record into a CameraPolygon without running a hull on the host.  The vertices are bit-identical
+ * to this repo's host class (rgb-d-slam_amd/host/boundary_polygon.cpp; the reference's own vertices are not reproducible:
+ * FLANN's randomized kd-trees over a nondeterministically ordered point list). */
+enum
+{
+    CAPE_POLY_VALID = 1u << 0,           /* simple ring of >= 3 vertices: Primitive_Detection keeps the plane (:623-631) */
+    CAPE_POLY_CONVEX_FALLBACK = 1u << 1, /* no concave hull on the k ladder: compute_convex_hull was used */
+    CAPE_POLY_SIMPLIFIED = 1u << 2,      /* simplify() replaced the ring (area stayed above 75 %) */
+    CAPE_POLY_OVERFLOW = 1u << 3,        /* more than 1024 boundary points: not built, left to the host class */
+    CAPE_POLY_REJECTED = 1u << 4         /* the host constructor would throw (fewer than 3 points / normal not unit) */
+};
+typedef struct cape_polygon
+{
+    double x_axis[3], y_axis[3]; /* get_plane_coordinate_system(segment normal) */
+    double center[3];            /* the segment's centroid */
+    double area;                 /* Polygon::_area after simplify */
+    uint32_t vertex_offset;      /* first vertex in the frame's vertex array (= the segment's boundary_offset) */
+    uint32_t vertex_count;
+    uint32_t flags;              /* CAPE_POLY_* ; 0 for a segment that is not an output plane */
+    uint32_t segment;            /* index of the segment in the frame record */
+} cape_polygon;
+/* Builds the polygons of frames [0, n_frames) of the last cape_extract; asynchronous on `stream`. */
+int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream);
+/* Device pointers: polygons = n_frames x CAPE_MAX_PLANES cape_polygon (indexed by segment), vertices = n_frames x
+ * boundary_capacity x 2 doubles.  Valid until the next cape_build_polygons / destroy. */
+int cape_device_polygons(cape_handle h, cape_polygon** polygons, double** vertices);
+/* Synchronous D2H copy of both arrays (either pointer may be NULL). */
+int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, double* vertices);
+
+/* Debug / parity: the device polygon of an arbitrary point set (host pointers; n <= boundary_capacity points x 3 doubles,
+ * unit normal, centre) -- one launch of the same kernel over a one-plane record.  `vertices_out` takes up to n x 2 doubles.
+ * Synchronous; does not disturb the results of the last cape_extract. */
+int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const double* normal, const double* center,
+                       cape_polygon* polygon_out, double* vertices_out);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -27,6 +27,7 @@ bool resume_group_fits(const StageBParams& p);
 hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_pack(const PackParams& p, hipStream_t stream);
+hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream);
 const char* rccl_load(); // nullptr on success, else the reason
 int rccl_unique_id(RcclUniqueId* id);
 int rccl_comm_init(void** comm, int world, const RcclUniqueId& id, int rank);
@@ -203,6 +204,9 @@ struct cape_handle_s
     hipEvent_t gatherDone = nullptr;
     bool gatherPending = false;
     int32_t* countScratch = nullptr; // cape_count_primitives
+    // N1 on the device: polygons of the last batch (allocated on first use)
+    cape_polygon* polygons = nullptr;
+    double* polyVertices = nullptr;
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
     cape::StageBParams pb{};
@@ -249,6 +253,18 @@ void free_all(cape_handle_s* h)
         (void)hipEventDestroy(h->handedOverReady);
     (void)hipFree(h->debugCycles);
     (void)hipFree(h->countScratch);
+    if (h->resultsOnHost)
+    {
+        if (h->polygons)
+            (void)hipHostFree(h->polygons);
+        if (h->polyVertices)
+            (void)hipHostFree(h->polyVertices);
+    }
+    else
+    {
+        (void)hipFree(h->polygons);
+        (void)hipFree(h->polyVertices);
+    }
     (void)hipFree(h->xpre);
     (void)hipFree(h->ypre);
     (void)hipFree(h->rectKeys);
@@ -1599,6 +1615,139 @@ int cape_gather_wait(cape_handle h, void* stream_, int32_t host_sync)
         CAPE_HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream_), h->gatherDone, 0));
     }
     return CAPE_OK;
+}
+
+int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
+{
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
+    if (n_frames > h->lastFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
+    if (n_frames == 0)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    const size_t B = (size_t)h->cfg.max_batch;
+    if (!h->polygons)
+    {
+        if (h->resultsOnHost)
+        {
+            // the records and boundary points of a few-frame handle live in pinned host memory (the kernel reads them over
+            // PCIe); the polygons follow them there
+            CAPE_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->polygons), B * CAPE_MAX_PLANES * sizeof(cape_polygon),
+                                       hipHostMallocMapped | hipHostMallocCoherent));
+            CAPE_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->polyVertices), B * (size_t)h->boundaryCap * 2 * sizeof(double),
+                                       hipHostMallocMapped | hipHostMallocCoherent));
+        }
+        else
+        {
+            CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polygons), B * CAPE_MAX_PLANES * sizeof(cape_polygon)));
+            CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyVertices), B * (size_t)h->boundaryCap * 2 * sizeof(double)));
+        }
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
+    cape::PolygonParams p;
+    p.records = h->records;
+    p.boundary = h->boundary;
+    p.polygons = h->polygons;
+    p.vertices = reinterpret_cast<double2*>(h->polyVertices);
+    p.boundaryCapacity = h->boundaryCap;
+    h->doneArmed = false; // the chain's completion word was written before this kernel: results are waited for the slow way
+    CAPE_HIP_TRY(cape::launch_polygons(p, n_frames, stream));
+    return CAPE_OK;
+}
+
+int cape_device_polygons(cape_handle h, cape_polygon** polygons, double** vertices)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (polygons)
+        *polygons = h->polygons;
+    if (vertices)
+        *vertices = h->polyVertices;
+    return CAPE_OK;
+}
+
+int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, double* vertices)
+{
+    if (!h || n_frames < 0 || n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
+    if (!h->polygons)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "no polygons have been built yet");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h));
+    const size_t n = (size_t)n_frames;
+    const hipMemcpyKind kind = h->resultsOnHost ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+    if (polygons)
+        CAPE_HIP_TRY(hipMemcpy(polygons, h->polygons, n * CAPE_MAX_PLANES * sizeof(cape_polygon), kind));
+    if (vertices)
+        CAPE_HIP_TRY(hipMemcpy(vertices, h->polyVertices, n * (size_t)h->boundaryCap * 2 * sizeof(double), kind));
+    return CAPE_OK;
+}
+
+int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const double* normal, const double* center,
+                       cape_polygon* polygon_out, double* vertices_out)
+{
+    if (!h || !points3 || !normal || !center || !polygon_out || n < 0 || n > h->boundaryCap)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument or more points than boundary_capacity");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h));
+    // a one-plane frame of its own: record, boundary points, polygon and vertex arrays (freed on the way out)
+    cape_frame_record* rec = nullptr;
+    double* bnd = nullptr;
+    cape_polygon* poly = nullptr;
+    double* verts = nullptr;
+    cape_frame_record* hostRec = new (std::nothrow) cape_frame_record();
+    if (!hostRec)
+        return fail(CAPE_ERR_HIP, "out of host memory");
+    std::memset(hostRec, 0, sizeof(*hostRec));
+    hostRec->header.n_plane_segments = 1;
+    hostRec->header.n_planes = 1;
+    cape_plane_segment& s = hostRec->segments[0];
+    for (int k = 0; k < 3; ++k)
+    {
+        s.normal[k] = normal[k];
+        s.centroid[k] = center[k];
+    }
+    s.is_output = 1;
+    s.planar = 1;
+    s.boundary_offset = 0;
+    s.boundary_count = (uint32_t)n;
+    int rc = CAPE_OK;
+    auto step = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == CAPE_OK)
+            rc = fail(CAPE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    const size_t cap = (size_t)h->boundaryCap;
+    if (step(hipMalloc(reinterpret_cast<void**>(&rec), sizeof(cape_frame_record)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&bnd), cap * 3 * sizeof(double)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&poly), CAPE_MAX_PLANES * sizeof(cape_polygon)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&verts), cap * 2 * sizeof(double)), "hipMalloc") &&
+        step(hipMemcpy(rec, hostRec, sizeof(cape_frame_record), hipMemcpyHostToDevice), "hipMemcpy") &&
+        step(n ? hipMemcpy(bnd, points3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice) : hipSuccess, "hipMemcpy"))
+    {
+        cape::PolygonParams p;
+        p.records = rec;
+        p.boundary = bnd;
+        p.polygons = poly;
+        p.vertices = reinterpret_cast<double2*>(verts);
+        p.boundaryCapacity = h->boundaryCap;
+        if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
+            step(hipMemcpy(polygon_out, poly, sizeof(cape_polygon), hipMemcpyDeviceToHost), "hipMemcpy"))
+        {
+            if (vertices_out && polygon_out->vertex_count)
+                step(hipMemcpy(vertices_out, verts, (size_t)polygon_out->vertex_count * 2 * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+        }
+    }
+    (void)hipFree(rec);
+    (void)hipFree(bnd);
+    (void)hipFree(poly);
+    (void)hipFree(verts);
+    delete hostRec;
+    return rc;
 }
 
 int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out)

@@ -161,6 +161,18 @@ struct PackParams
     uint32_t flags;
 };
 
+// N1 on the device: boundary polygons (cape_polygon.hip)
+constexpr int kPolyMaxPoints = 1024; // boundary candidates of one plane the device hull takes (more: CAPE_POLY_OVERFLOW, host class)
+constexpr int kPolySlots = 8;        // wavefronts per frame: wave s builds the polygons of the frame's planes s, s + 8, ...
+struct PolygonParams
+{
+    const cape_frame_record* records;
+    const double* boundary;  // frames x boundaryCapacity x 3
+    cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
+    double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
+    int boundaryCapacity;
+};
+
 struct RcclUniqueId
 {
     char internal[CAPE_COMM_ID_BYTES]; // ncclUniqueId

@@ -1,0 +1,712 @@
+// "Next" row N1 on the device: the boundary polygon of every output plane, ONE WAVEFRONT PER PLANE.
+//
+// Replaces, for a batch, what the reference does on the host right after compute_plane_segment_boundary
+// (primitive_detection.cpp:622): utils::Polygon(points, normal, center) -- reference src/utils/polygon.cpp:168-229:
+// plane frame (:74-115), projection (:125-144), concave hull (:283-318, third_party/concave_fitting.cpp: Moreira-Santos
+// k-nearest-neighbours hull on the k ladder 3,3,5,7,11,13,17,21), convex-hull fallback (:268-281), area (:453-461) and
+// simplify (:578-601).  The algorithm is the one of this repo's dependency-free host class (host/boundary_polygon.cpp),
+// statement for statement and in the same operation order: + - x / sqrt and comparisons only (no libm call whose rounding
+// could differ between glibc and ocml), so the vertices are compared BIT FOR BIT against the host class
+// (tests/test_gpu_polygon.py).  The reference's own vertices are not a parity target -- it feeds FLANN's randomized
+// kd-trees a nondeterministically ordered point list (host/boundary_polygon.hpp) -- its validity / area / containment
+// contract is what tests/host/test_polygon.cpp replays.
+//
+// Layout: the points of a plane are its boundary candidates (<= kPolyMaxPoints), projected and sorted in LDS; a hull is a
+// list of point indices.  Lanes are parallel over points (distances, point-in-ring tests), over hull edges (intersection
+// tests) and over the compare-exchanges of a bitonic sort; what the algorithm orders sequentially (the walk along the
+// hull, the candidate tried first) is uniform control flow.  No workgroup barrier: a workgroup carries four independent
+// waves, like the grow kernel.
+#include <hip/hip_runtime.h>
+
+#include "cape_device.h"
+#include "cape_internal.h"
+#include "cape_wave.h"
+
+namespace cape {
+
+constexpr int kPolyWavesPerGroup = 4;
+constexpr int kPolyPerLane = kPolyMaxPoints / 64; // points a lane owns in the lane-parallel passes
+
+#define CAPE_POLY_SYNC()                                                                                      \
+    do                                                                                                       \
+    {                                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                               \
+    } while (0)
+
+struct PolyLds
+{
+    double2* pts;          // kPolyMaxPoints (+ padding of the sort) projected points, sorted, deduplicated
+    unsigned short* hull;  // kPolyMaxPoints + 1 point indices
+    unsigned short* ring;  // kPolyMaxPoints + 1 point indices: the ring being built / simplified (closed copy for Douglas-Peucker)
+    unsigned char* used;   // kPolyMaxPoints
+    unsigned char* keep;   // kPolyMaxPoints + 1
+    unsigned int* stack;   // kPolyMaxPoints range stack of the simplification
+};
+
+__device__ __forceinline__ double pcross2(const double2& o, const double2& a, const double2& b)
+{
+    return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
+}
+__device__ __forceinline__ double pmin(double a, double b) { return (b < a) ? b : a; } // std::min
+__device__ __forceinline__ double pmax(double a, double b) { return (a < b) ? b : a; } // std::max
+
+// host/boundary_polygon.cpp: segments_intersect -- proper or touching intersection of the open segments; shared endpoints
+// do not count
+__device__ __forceinline__ bool segments_intersect(const double2& a1, const double2& a2, const double2& b1, const double2& b2)
+{
+    if (pmax(a1.x, a2.x) < pmin(b1.x, b2.x) || pmax(b1.x, b2.x) < pmin(a1.x, a2.x) || pmax(a1.y, a2.y) < pmin(b1.y, b2.y) ||
+        pmax(b1.y, b2.y) < pmin(a1.y, a2.y))
+        return false;
+    auto same = [](const double2& p, const double2& q) { return p.x == q.x && p.y == q.y; };
+    if (same(a1, b1) || same(a1, b2) || same(a2, b1) || same(a2, b2))
+        return false;
+    const double d1 = pcross2(b1, b2, a1), d2 = pcross2(b1, b2, a2), d3 = pcross2(a1, a2, b1), d4 = pcross2(a1, a2, b2);
+    if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0)))
+        return true;
+    auto on = [](const double2& p, const double2& q, const double2& r) {
+        return pmin(p.x, q.x) <= r.x && r.x <= pmax(p.x, q.x) && pmin(p.y, q.y) <= r.y && r.y <= pmax(p.y, q.y);
+    };
+    if (d1 == 0 && on(b1, b2, a1))
+        return true;
+    if (d2 == 0 && on(b1, b2, a2))
+        return true;
+    if (d3 == 0 && on(a1, a2, b1))
+        return true;
+    if (d4 == 0 && on(a1, a2, b2))
+        return true;
+    return false;
+}
+
+// point_in_ring(p, ring, closed = true): crossing number; a point on the boundary counts as inside.  One lane, whole ring.
+__device__ __forceinline__ bool point_in_ring_closed(const double2& p, const double2* pts, const unsigned short* ring, int n)
+{
+    bool inside = false, onEdge = false;
+    for (int i = 0, j = n - 1; i < n; j = i++)
+    {
+        const double2 a = pts[ring[i]], b = pts[ring[j]];
+        if (pcross2(a, b, p) == 0 && pmin(a.x, b.x) <= p.x && p.x <= pmax(a.x, b.x) && pmin(a.y, b.y) <= p.y && p.y <= pmax(a.y, b.y))
+            onEdge = true; // the host returns `closed` here; the crossings counted so far no longer matter
+        if (((a.y > p.y) != (b.y > p.y)) && (p.x < (b.x - a.x) * (p.y - a.y) / (b.y - a.y) + a.x))
+            inside = !inside;
+    }
+    return onEdge || inside;
+}
+
+// ring_area_signed: ordered sum, one rounding per add (uniform: every lane walks the ring)
+__device__ __forceinline__ double ring_area_signed(const double2* pts, const unsigned short* ring, int n)
+{
+    double s = 0;
+    for (int i = 0, j = n - 1; i < n; j = i++)
+    {
+        const double2 ri = pts[ring[i]], rj = pts[ring[j]];
+        s += (rj.x * ri.y - ri.x * rj.y);
+    }
+    return 0.5 * s;
+}
+
+// ring_is_simple: no two non-adjacent edges touch, and the area is not zero.  Lanes over the first edge of a pair.
+__device__ __forceinline__ bool ring_is_simple(const double2* pts, const unsigned short* ring, int n, int lane)
+{
+    if (n < 3)
+        return false;
+    bool bad = false;
+    for (int i = lane; i < n; i += 64)
+    {
+        const double2 a1 = pts[ring[i]], a2 = pts[ring[(i + 1) % n]];
+        for (int j = i + 1; j < n && !bad; ++j)
+        {
+            if (j == i + 1 || (i == 0 && j == n - 1))
+                continue; // adjacent edges share a vertex
+            bad = segments_intersect(a1, a2, pts[ring[j]], pts[ring[(j + 1) % n]]);
+        }
+    }
+    if (__any(bad))
+        return false;
+    return fabs(ring_area_signed(pts, ring, n)) > 0;
+}
+
+// wave-wide arg-min of (a, b, idx) in lexicographic order (a, b: doubles without NaN)
+__device__ __forceinline__ int wave_argmin2(double a, double b, int idx)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const double oa = __shfl_xor(a, o), ob = __shfl_xor(b, o);
+        const int oi = __shfl_xor(idx, o);
+        const bool take = (oa < a) || (oa == a && (ob < b || (ob == b && oi < idx)));
+        if (take)
+        {
+            a = oa;
+            b = ob;
+            idx = oi;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(idx);
+}
+
+// Clockwise rotation from the direction `P` to the vector `V`, as a class and an exact in-class comparison (the host class
+// orders candidates with the same predicates: no atan2, so host and device cannot disagree on a near-tie):
+//   0: same direction   1: strictly clockwise, less than half a turn   2: opposite   3: more than half a turn
+__device__ __forceinline__ int turn_class(double px, double py, double vx, double vy)
+{
+    const double cr = px * vy - py * vx, dt = px * vx + py * vy;
+    if (cr < 0)
+        return 1;
+    if (cr > 0)
+        return 3;
+    return dt > 0 ? 0 : 2;
+}
+// does candidate a turn further clockwise from P than candidate b (strictly)?
+__device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int cb, double bx, double by)
+{
+    if (ca != cb)
+        return ca > cb;
+    if (ca == 0 || ca == 2)
+        return false;
+    return (bx * ay - by * ax) < 0; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
+}
+
+// One run of the k-nearest-neighbours hull (host: concave_hull_k).  On success the hull's point indices are in L.hull[0, hs).
+__device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut)
+{
+    const double2* pts = L.pts;
+    if (n < 3)
+        return false;
+    if (n == 3)
+    {
+        if (lane < 3)
+            L.hull[lane] = (unsigned short)lane;
+        CAPE_POLY_SYNC();
+        hsOut = 3;
+        return true;
+    }
+    k = k < 3 ? 3 : k;
+    k = k < n - 1 ? k : n - 1;
+    // lowest point (smallest y, then smallest x)
+    int first;
+    {
+        double by = __builtin_inf(), bx = __builtin_inf();
+        int bi = 0x7FFFFFFF;
+        for (int i = lane; i < n; i += 64)
+        {
+            const double2 q = pts[i];
+            if (q.y < by || (q.y == by && q.x < bx))
+            {
+                by = q.y;
+                bx = q.x;
+                bi = i;
+            }
+        }
+        first = wave_argmin2(by, bx, bi);
+    }
+    for (int i = lane; i < n; i += 64)
+        L.used[i] = 0;
+    CAPE_POLY_SYNC();
+    if (lane == 0)
+    {
+        L.hull[0] = (unsigned short)first;
+        L.used[first] = 1;
+    }
+    CAPE_POLY_SYNC();
+    int hs = 1;
+    int current = first;
+    double Px = -1.0, Py = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
+    int step = 1;
+    int remaining = n - 1;
+    while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
+    {
+        if (step == 4)
+        {
+            if (lane == 0)
+                L.used[first] = 0; // the start point becomes reachable again once the hull has three edges
+            CAPE_POLY_SYNC();
+        }
+        const double2 cur = pts[current];
+        // ---- k nearest unused neighbours of the current point, ascending (squared distance, index)
+        unsigned long long d2bits[kPolyPerLane];
+        unsigned avail = 0; // bit j: the lane's point lane + 64 j is a candidate that has not been taken yet
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kPolyPerLane; ++j)
+        {
+            const int i = lane + 64 * j;
+            d2bits[j] = ~0ull;
+            if (i < n && !L.used[i] && i != current)
+            {
+                const double2 q = pts[i];
+                const double dx = q.x - cur.x, dy = q.y - cur.y;
+                d2bits[j] = (unsigned long long)__double_as_longlong(dx * dx + dy * dy); // >= +0: the bits order like the value
+                avail |= 1u << j;
+                ++cnt;
+            }
+        }
+        cnt = wave_sum_i32(cnt);
+        if (cnt == 0)
+            break;
+        const int kk = k < cnt ? k : cnt;
+        // candidate c lives in lane c (kk <= 21 < 64): index, edge vector, turn class
+        int myCand = 0, myClass = 0;
+        double myVx = 0.0, myVy = 0.0;
+        for (int c = 0; c < kk; ++c)
+        {
+            unsigned long long best = ~0ull;
+            int bestJ = -1;
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+                if (((avail >> j) & 1u) && d2bits[j] < best) // ascending j = ascending index inside the lane
+                {
+                    best = d2bits[j];
+                    bestJ = j;
+                }
+            const unsigned long long m = wave_min_u64(best);
+            const unsigned mine = (bestJ >= 0 && best == m) ? (unsigned)(0x7FFFFFFF - (lane + 64 * bestJ)) : 0u;
+            const int idx = 0x7FFFFFFF - (int)wave_max_u32(mine); // smallest index among the equal distances
+            if (bestJ >= 0 && lane + 64 * bestJ == idx)
+                avail &= ~(1u << bestJ);
+            if (lane == c)
+            {
+                const double2 q = pts[idx];
+                myCand = idx;
+                myVx = q.x - cur.x;
+                myVy = q.y - cur.y;
+                myClass = turn_class(Px, Py, myVx, myVy);
+            }
+        }
+        // ---- candidates by decreasing clockwise turn from the previous edge (a scan in nearest-first order, like the host's);
+        //      the first whose edge crosses no hull edge wins
+        unsigned tried = 0;
+        bool found = false;
+        int next = 0;
+        for (int t = 0; t < kk && !found; ++t)
+        {
+            int b = -1, bClass = 0;
+            double bVx = 0.0, bVy = 0.0;
+            for (int c = 0; c < kk; ++c)
+            {
+                if ((tried >> c) & 1u)
+                    continue;
+                const int cClass = __builtin_amdgcn_readlane(myClass, c);
+                const double cVx = readlane_f64(myVx, c), cVy = readlane_f64(myVy, c);
+                if (b < 0 || turns_further(cClass, cVx, cVy, bClass, bVx, bVy))
+                {
+                    b = c;
+                    bClass = cClass;
+                    bVx = cVx;
+                    bVy = cVy;
+                }
+            }
+            tried |= 1u << b;
+            const int cnd = __builtin_amdgcn_readlane(myCand, b);
+            const double2 cp = pts[cnd];
+            const int jFirst = (cnd == first) ? 1 : 0;
+            bool its = false;
+            // hull edges (h[j], h[j+1]), j in [jFirst, hs - 3]: the edge that ends at the current point shares it with the candidate edge
+            for (int j = jFirst + lane; j + 2 < hs && !its; j += 64)
+                its = segments_intersect(cur, cp, pts[L.hull[j]], pts[L.hull[j + 1]]);
+            if (!__any(its))
+            {
+                found = true;
+                next = cnd;
+            }
+        }
+        if (!found)
+            return false;
+        if (next == first)
+        {
+            current = first;
+            break;
+        }
+        const double2 nx = pts[next];
+        Px = cur.x - nx.x; // looking back along the new edge
+        Py = cur.y - nx.y;
+        current = next;
+        if (lane == 0)
+        {
+            L.hull[hs] = (unsigned short)current;
+            L.used[current] = 1;
+        }
+        ++hs;
+        --remaining;
+        ++step;
+        CAPE_POLY_SYNC();
+    }
+    if (current != first || hs < 3)
+        return false;
+    // every input point must lie inside or on the hull
+    bool outside = false;
+    for (int i = lane; i < n; i += 64)
+        if (!L.used[i] && !point_in_ring_closed(pts[i], pts, L.hull, hs))
+            outside = true;
+    if (__any(outside))
+        return false;
+    hsOut = hs;
+    return true;
+}
+
+// bitonic sort of L.pts[0, n) by (x, y), ascending; n is padded to a power of two with +inf points
+__device__ inline void sort_points(const PolyLds& L, int n, int lane)
+{
+    int np = 64;
+    while (np < n)
+        np <<= 1;
+    for (int i = n + lane; i < np; i += 64)
+        L.pts[i] = make_double2(__builtin_inf(), __builtin_inf());
+    CAPE_POLY_SYNC();
+    for (int size = 2; size <= np; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1)
+        {
+            for (int t = lane; t < np / 2; t += 64)
+            {
+                const int lo = (t / stride) * (2 * stride) + (t % stride), hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const double2 a = L.pts[lo], b = L.pts[hi];
+                const bool aGreater = (b.x < a.x) || (b.x == a.x && b.y < a.y);
+                if (aGreater == up)
+                {
+                    L.pts[lo] = b;
+                    L.pts[hi] = a;
+                }
+            }
+            CAPE_POLY_SYNC();
+        }
+}
+
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * kPolyWavesPerGroup + wave; // (frame, slot): slot s of a frame = planes s, s + kPolySlots, ...
+    const int frame = task / kPolySlots, slot = task - frame * kPolySlots;
+    if (frame >= nFrames)
+        return;
+    unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
+    PolyLds L;
+    L.pts = reinterpret_cast<double2*>(smem);
+    L.hull = reinterpret_cast<unsigned short*>(L.pts + kPolyMaxPoints);
+    L.ring = L.hull + kPolyMaxPoints + 2;
+    L.stack = reinterpret_cast<unsigned int*>(L.ring + kPolyMaxPoints + 2);
+    L.used = reinterpret_cast<unsigned char*>(L.stack + kPolyMaxPoints);
+    L.keep = L.used + kPolyMaxPoints;
+
+    const cape_frame_record& rec = p.records[frame];
+    const int nSeg = rec.header.n_plane_segments;
+    // the slot's planes: the s-th, (s + kPolySlots)-th, ... segment with is_output (lane j looks at segment j)
+    const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
+    const unsigned long long outMask = __ballot(isOut);
+    // segments that are not planes carry an empty polygon record
+    if (slot == 0 && lane < CAPE_MAX_PLANES && !isOut)
+    {
+        cape_polygon* o = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + lane];
+        o->vertex_count = 0;
+        o->flags = 0;
+        o->segment = (uint32_t)lane;
+        o->area = 0.0;
+    }
+    int ordinal = 0;
+    for (unsigned long long m = outMask; m; m &= m - 1, ++ordinal)
+    {
+        if (ordinal % kPolySlots != slot)
+            continue;
+        const int seg = __ffsll((long long)m) - 1;
+        const cape_plane_segment& S = rec.segments[seg];
+        cape_polygon* out = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + seg];
+        double2* vout = p.vertices + (size_t)frame * p.boundaryCapacity + S.boundary_offset;
+        const int nPts = (int)S.boundary_count;
+        uint32_t flags = 0;
+        // ---- plane frame: get_plane_coordinate_system (polygon.cpp:74-115 with select_correct_transform :50-68)
+        const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
+        const double cx = S.centroid[0], cy = S.centroid[1], cz = S.centroid[2];
+        double xax, xay, xaz, yax, yay, yaz;
+        {
+            const double distX = fabs(nx), distY = fabs(ny), distZ = fabs(nz);
+            const double res = pmin(distX, pmin(distY, distZ));
+            double rx, ry, rz;
+            if (fabs(res - distX) <= 0.1)
+                rx = 1, ry = 0, rz = 0;
+            else if (fabs(res - distY) <= 0.1)
+                rx = 0, ry = 1, rz = 0;
+            else if (fabs(res - distZ) <= 0.1)
+                rx = 0, ry = 0, rz = 1;
+            else
+            {
+                rx = nz, ry = nx, rz = ny;
+                const double nn = sqrt((rx * rx + ry * ry) + rz * rz);
+                if (nn > 0)
+                    rx /= nn, ry /= nn, rz /= nn;
+            }
+            // xAxis = normalized(cross(normal, r)) ; yAxis = normalized(cross(normal, xAxis))
+            double ax = ny * rz - nz * ry, ay = nz * rx - nx * rz, az = nx * ry - ny * rx;
+            const double an = sqrt((ax * ax + ay * ay) + az * az);
+            if (an > 0)
+                ax /= an, ay /= an, az /= an;
+            double bx = ny * az - nz * ay, by = nz * ax - nx * az, bz = nx * ay - ny * ax;
+            const double bn = sqrt((bx * bx + by * by) + bz * bz);
+            if (bn > 0)
+                bx /= bn, by /= bn, bz /= bn;
+            xax = ax, xay = ay, xaz = az, yax = bx, yay = by, yaz = bz;
+        }
+        const double normalNorm = sqrt((nx * nx + ny * ny) + nz * nz);
+        int count = 0;
+        double area = 0.0;
+        if (!(fabs(normalNorm - 1.0) <= 1e-9) || nPts < 3)
+            flags |= CAPE_POLY_REJECTED; // the host constructor throws (normal not unit / fewer than 3 points)
+        else if (nPts > kPolyMaxPoints)
+            flags |= CAPE_POLY_OVERFLOW; // left to the host class
+        else
+        {
+            // ---- projection (polygon.cpp:125-144) and the hull's RemoveDuplicates: sort by (x, y), drop equal neighbours
+            const double* bnd = p.boundary + ((size_t)frame * p.boundaryCapacity + S.boundary_offset) * 3;
+            for (int i = lane; i < nPts; i += 64)
+            {
+                const double dx = bnd[3 * i] - cx, dy = bnd[3 * i + 1] - cy, dz = bnd[3 * i + 2] - cz;
+                L.pts[i] = make_double2((xax * dx + xay * dy) + xaz * dz, (yax * dx + yay * dy) + yaz * dz);
+            }
+            CAPE_POLY_SYNC();
+            sort_points(L, nPts, lane);
+            int n = 0;
+            for (int base = 0; base < nPts; base += 64)
+            {
+                const int i = base + lane;
+                double2 q = make_double2(0, 0);
+                bool keepIt = false;
+                if (i < nPts)
+                {
+                    q = L.pts[i];
+                    keepIt = true;
+                    if (i > 0)
+                    {
+                        const double2 prev = L.pts[i - 1];
+                        keepIt = !(prev.x == q.x && prev.y == q.y);
+                    }
+                }
+                const unsigned long long kb = __ballot(keepIt);
+                CAPE_POLY_SYNC(); // every lane has read its point (and its left neighbour) before the chunk is compacted
+                if (keepIt)
+                    L.pts[n + __popcll(kb & ((1ull << lane) - 1ull))] = q;
+                n += __popcll(kb);
+                CAPE_POLY_SYNC();
+            }
+            // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
+            int hs = 0;
+            bool haveRing = false;
+            if (n >= 3)
+            {
+                const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
+                for (int a = 0; a < 8 && !haveRing; ++a)
+                {
+                    const int k = ladder[a];
+                    if (concave_hull_k(L, n, k, lane, hs) && ring_is_simple(L.pts, L.hull, hs, lane))
+                        haveRing = true;
+                    else if (k > n)
+                        break;
+                }
+            }
+            unsigned short* ring = L.ring;
+            int rn = 0;
+            if (haveRing)
+            {
+                // clockwise like the reference's polygons: reversed if the signed area is positive
+                const bool rev = ring_area_signed(L.pts, L.hull, hs) > 0;
+                for (int i = lane; i < hs; i += 64)
+                    ring[i] = L.hull[rev ? hs - 1 - i : i];
+                rn = hs;
+                CAPE_POLY_SYNC();
+                // Polygon's constructor asks is_valid() of the ORIENTED ring once more: on a near-degenerate sliver the
+                // intersection predicates of the reversed edges can round the other way, and the convex hull takes over
+                if (!ring_is_simple(L.pts, ring, rn, lane))
+                    haveRing = false;
+            }
+            if (!haveRing)
+            {
+                // ---- compute_convex_hull (monotone chain over the sorted, deduplicated points), reversed to clockwise.
+                //      Sequential by nature; every lane runs it on the same values, lane 0 writes.
+                flags |= CAPE_POLY_CONVEX_FALLBACK;
+                if (n < 3)
+                {
+                    if (lane < n)
+                        ring[lane] = (unsigned short)lane;
+                    rn = n;
+                }
+                else
+                {
+                    unsigned short* hstk = L.hull; // 2 n entries at most: hull + ring areas are contiguous
+                    int kx = 0;
+                    for (int i = 0; i < n; ++i)
+                    {
+                        while (kx >= 2 && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i]) <= 0)
+                            kx--;
+                        if (lane == 0)
+                            hstk[kx] = (unsigned short)i;
+                        kx++;
+                        CAPE_POLY_SYNC();
+                    }
+                    for (int i = n - 1, t = kx + 1; i > 0; --i)
+                    {
+                        while (kx >= t && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i - 1]) <= 0)
+                            kx--;
+                        if (lane == 0)
+                            hstk[kx] = (unsigned short)(i - 1);
+                        kx++;
+                        CAPE_POLY_SYNC();
+                    }
+                    const int hn = kx - 1;
+                    // reversed into registers first: hull and ring share LDS when the chain ran past kPolyMaxPoints entries
+                    unsigned short tmp[kPolyPerLane];
+#pragma unroll
+                    for (int j = 0; j < kPolyPerLane; ++j)
+                    {
+                        const int i = lane + 64 * j;
+                        tmp[j] = i < hn ? hstk[hn - 1 - i] : (unsigned short)0;
+                    }
+                    CAPE_POLY_SYNC();
+#pragma unroll
+                    for (int j = 0; j < kPolyPerLane; ++j)
+                    {
+                        const int i = lane + 64 * j;
+                        if (i < hn)
+                            ring[i] = tmp[j];
+                    }
+                    rn = hn;
+                }
+                CAPE_POLY_SYNC();
+            }
+            area = rn >= 3 ? fabs(ring_area_signed(L.pts, ring, rn)) : 0.0;
+            // ---- simplify (polygon.cpp:578-601): Douglas-Peucker on the closed ring, threshold max(area / 1e5, 10); kept if the
+            //      result is a simple ring whose area stays above 75 %
+            if (rn >= 4)
+            {
+                const double eps = pmax(area / 1e5, 10.0);
+                unsigned short* closed = L.hull; // rn + 1 entries
+                for (int i = lane; i <= rn; i += 64)
+                {
+                    closed[i] = ring[i < rn ? i : 0];
+                    L.keep[i] = (i == 0 || i == rn) ? 1 : 0;
+                }
+                CAPE_POLY_SYNC();
+                int sp = 0;
+                if (lane == 0)
+                    L.stack[0] = (unsigned)rn; // (a << 16) | b with a = 0
+                sp = 1;
+                CAPE_POLY_SYNC();
+                while (sp > 0)
+                {
+                    const unsigned ab = L.stack[--sp];
+                    const int a = (int)(ab >> 16), b = (int)(ab & 0xFFFFu);
+                    if (b <= a + 1)
+                        continue;
+                    const double2 pa = L.pts[closed[a]], pb = L.pts[closed[b]];
+                    const double dx = pb.x - pa.x, dy = pb.y - pa.y;
+                    const double len = sqrt(dx * dx + dy * dy);
+                    unsigned long long best = 0ull; // distance bits (>= +0); the first index wins a tie, like the host's strict >
+                    int bestI = 0x7FFFFFFF;
+                    for (int i = a + 1 + lane; i < b; i += 64)
+                    {
+                        const double2 q = L.pts[closed[i]];
+                        double d;
+                        if (len == 0)
+                        {
+                            const double ex = q.x - pa.x, ey = q.y - pa.y;
+                            d = sqrt(ex * ex + ey * ey);
+                        }
+                        else
+                            d = fabs(dx * (pa.y - q.y) - (pa.x - q.x) * dy) / len;
+                        const unsigned long long db = (unsigned long long)__double_as_longlong(d);
+                        if (bestI == 0x7FFFFFFF || db > best)
+                        {
+                            best = db;
+                            bestI = i;
+                        }
+                    }
+                    // wave maximum of the distance, smallest index among the equal ones
+                    unsigned long long mx = best;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+                    {
+                        const unsigned long long ob = (unsigned long long)__shfl_xor((long long)mx, o);
+                        mx = ob > mx ? ob : mx;
+                    }
+                    const unsigned mineKey = (bestI != 0x7FFFFFFF && best == mx) ? (unsigned)(0x7FFFFFFF - bestI) : 0u;
+                    const int idx = 0x7FFFFFFF - (int)wave_max_u32(mineKey);
+                    const double dmax = __longlong_as_double((long long)mx);
+                    if (dmax > eps)
+                    {
+                        if (lane == 0)
+                        {
+                            L.keep[idx] = 1;
+                            L.stack[sp] = ((unsigned)a << 16) | (unsigned)idx;
+                            L.stack[sp + 1] = ((unsigned)idx << 16) | (unsigned)b;
+                        }
+                        sp += 2;
+                        CAPE_POLY_SYNC();
+                    }
+                }
+                // candidate ring = the kept vertices of closed[0, rn) ; built in the stack area (as u16), then tested
+                unsigned short* cand = reinterpret_cast<unsigned short*>(L.stack);
+                int cn = 0;
+                for (int base = 0; base < rn; base += 64)
+                {
+                    const int i = base + lane;
+                    const bool k = i < rn && L.keep[i];
+                    const unsigned long long kb = __ballot(k);
+                    if (k)
+                        cand[cn + __popcll(kb & ((1ull << lane) - 1ull))] = closed[i];
+                    cn += __popcll(kb);
+                }
+                CAPE_POLY_SYNC();
+                if (cn >= 3 && ring_is_simple(L.pts, cand, cn, lane))
+                {
+                    const double newArea = fabs(ring_area_signed(L.pts, cand, cn));
+                    if (newArea > area * 0.75)
+                    {
+                        for (int i = lane; i < cn; i += 64)
+                            ring[i] = cand[i];
+                        rn = cn;
+                        area = newArea;
+                        flags |= CAPE_POLY_SIMPLIFIED;
+                        CAPE_POLY_SYNC();
+                    }
+                }
+            }
+            // ---- what Primitive_Detection keeps: a valid polygon of at least three vertices (primitive_detection.cpp:623-631)
+            if (rn >= 3 && ring_is_simple(L.pts, ring, rn, lane))
+                flags |= CAPE_POLY_VALID;
+            for (int i = lane; i < rn; i += 64)
+                vout[i] = L.pts[ring[i]];
+            count = rn;
+        }
+        if (lane == 0)
+        {
+            out->x_axis[0] = xax; out->x_axis[1] = xay; out->x_axis[2] = xaz;
+            out->y_axis[0] = yax; out->y_axis[1] = yay; out->y_axis[2] = yaz;
+            out->center[0] = cx; out->center[1] = cy; out->center[2] = cz;
+            out->area = area;
+            out->vertex_offset = S.boundary_offset;
+            out->vertex_count = (uint32_t)count;
+            out->flags = flags;
+            out->segment = (uint32_t)seg;
+        }
+        CAPE_POLY_SYNC();
+    }
+}
+
+size_t polygon_lds_bytes()
+{
+    size_t b = (size_t)kPolyMaxPoints * 16;            // pts
+    b += 2 * ((size_t)kPolyMaxPoints + 2) * 2;         // hull, ring
+    b += (size_t)kPolyMaxPoints * 4;                   // stack
+    b += (size_t)kPolyMaxPoints + kPolyMaxPoints + 2;  // used, keep
+    return (b + 15) & ~(size_t)15;
+}
+
+hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
+{
+    const int ldsPerWave = (int)polygon_lds_bytes();
+    const int tasks = nFrames * kPolySlots;
+    hipLaunchKernelGGL(cape_polygon_kernel, dim3((tasks + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup), dim3(64 * kPolyWavesPerGroup),
+                       (size_t)ldsPerWave * kPolyWavesPerGroup, stream, p, nFrames, ldsPerWave);
+    return hipGetLastError();
+}
+
+} // namespace cape

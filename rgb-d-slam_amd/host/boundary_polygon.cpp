@@ -112,12 +112,11 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
     std::vector<size_t> h {first};
     used[first] = 1;
     size_t current = first;
-    double prevAngle = M_PI; // walking direction so far: pointing west, the first turn is taken clockwise from it
+    double prevX = -1.0, prevY = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
     size_t step = 1;
     size_t remaining = n - 1;
-    std::vector<std::pair<double, size_t>> cand, byTurn; // reused from step to step
+    std::vector<std::pair<double, size_t>> cand; // reused from step to step
     cand.reserve(n);
-    byTurn.reserve(k);
     while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
     {
         if (step == 4)
@@ -135,22 +134,56 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
         const size_t kk = std::min(k, cand.size());
         std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
         cand.resize(kk);
-        // order by the largest right-hand turn relative to the previous edge
-        byTurn.clear();
-        for (const auto& c : cand)
+        // Candidates by decreasing clockwise turn from the previous edge, the first whose edge crosses no hull edge wins.  The
+        // turn is never computed as an angle: a class (same direction / less than half a turn / opposite / more) from the
+        // signs of one cross and one dot product, and inside a class one more cross product.  Additions, multiplications and
+        // comparisons only, scanned in nearest-first order -- so the device hull (csrc/cape_polygon.hip), which runs the very
+        // same statements, picks the same vertex even when two candidates are a rounding error apart (an atan2 from glibc
+        // and one from ocml need not agree there).
+        auto turn_class = [&](double vx, double vy) {
+            const double cr = prevX * vy - prevY * vx, dt = prevX * vx + prevY * vy;
+            if (cr < 0)
+                return 1;
+            if (cr > 0)
+                return 3;
+            return dt > 0 ? 0 : 2;
+        };
+        struct Cand
         {
-            const double ang = std::atan2(pts[c.second][1] - pts[current][1], pts[c.second][0] - pts[current][0]);
-            double turn = prevAngle - ang; // clockwise turn from the direction we came from
-            while (turn < 0) turn += 2 * M_PI;
-            while (turn >= 2 * M_PI) turn -= 2 * M_PI;
-            byTurn.emplace_back(turn, c.second);
+            size_t idx;
+            double vx, vy;
+            int cls;
+        };
+        Cand cs[32];
+        const size_t kc = cand.size();
+        for (size_t c = 0; c < kc; ++c)
+        {
+            const size_t i = cand[c].second;
+            cs[c] = {i, pts[i][0] - pts[current][0], pts[i][1] - pts[current][1], 0};
+            cs[c].cls = turn_class(cs[c].vx, cs[c].vy);
         }
-        std::sort(byTurn.begin(), byTurn.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        auto turns_further = [](const Cand& a, const Cand& b) {
+            if (a.cls != b.cls)
+                return a.cls > b.cls;
+            if (a.cls == 0 || a.cls == 2)
+                return false;
+            return (b.vx * a.vy - b.vy * a.vx) < 0; // a lies clockwise of b inside the same open half turn
+        };
+        unsigned tried = 0;
         bool found = false;
         size_t next = 0;
-        for (const auto& c : byTurn)
+        for (size_t t = 0; t < kc && !found; ++t)
         {
-            const size_t cnd = c.second;
+            int best = -1;
+            for (size_t c = 0; c < kc; ++c)
+            {
+                if ((tried >> c) & 1u)
+                    continue;
+                if (best < 0 || turns_further(cs[c], cs[best]))
+                    best = static_cast<int>(c);
+            }
+            tried |= 1u << best;
+            const size_t cnd = cs[best].idx;
             bool its = false;
             const size_t last = (cnd == first) ? 1 : 0;
             for (size_t j = last; j + 2 < h.size() + 1 && !its; ++j)
@@ -165,7 +198,6 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
             {
                 found = true;
                 next = cnd;
-                break;
             }
         }
         if (!found)
@@ -175,7 +207,8 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
             current = first;
             break;
         }
-        prevAngle = std::atan2(pts[current][1] - pts[next][1], pts[current][0] - pts[next][0]); // looking back
+        prevX = pts[current][0] - pts[next][0]; // looking back along the new edge
+        prevY = pts[current][1] - pts[next][1];
         current = next;
         h.push_back(current);
         used[current] = 1;
@@ -206,7 +239,10 @@ void douglas_peucker(const std::vector<vector2>& in, size_t a, size_t b, double 
     {
         double d;
         if (len == 0)
-            d = std::hypot(in[i][0] - in[a][0], in[i][1] - in[a][1]);
+        {
+            const double ex = in[i][0] - in[a][0], ey = in[i][1] - in[a][1];
+            d = std::sqrt(ex * ex + ey * ey); // (not std::hypot: its rounding is the library's business, sqrt's is IEEE's)
+        }
         else
             d = std::abs(dx * (in[a][1] - in[i][1]) - (in[a][0] - in[i][0]) * dy) / len;
         if (d > dmax)

@@ -126,6 +126,28 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
             orderedBoundary.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
         try
         {
+            // device polygon of this segment, if the batch built them: the ring goes through the reference's
+            // Polygon(ring, xAxis, yAxis, center) constructor (polygon.cpp:236-266) -- no hull on the host.  A plane with more
+            // boundary points than the device kernel takes (CAPE_POLY_OVERFLOW) falls through to the host class.
+            const cape_polygon* dp = shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i] : nullptr;
+            if (dp && !(dp->flags & CAPE_POLY_OVERFLOW))
+            {
+                if (!(dp->flags & CAPE_POLY_VALID) || dp->vertex_count < 3)
+                {
+                    outputs::log_error("Polyfit error: Geometry has invalid self-intersections or too few points");
+                    continue;
+                }
+                const double* v = shard.vertexCopy.data() + (static_cast<size_t>(f) * _boundaryCapacity + dp->vertex_offset) * 2;
+                std::vector<vector2> ring;
+                ring.reserve(dp->vertex_count);
+                for (uint32_t k = 0; k < dp->vertex_count; ++k)
+                    ring.emplace_back(v[2 * k], v[2 * k + 1]);
+                const CameraPolygon polygon(ring, vector3(dp->x_axis[0], dp->x_axis[1], dp->x_axis[2]),
+                                            vector3(dp->y_axis[0], dp->y_axis[1], dp->y_axis[2]),
+                                            vector3(dp->center[0], dp->center[1], dp->center[2]));
+                planes.emplace_back(planeSegment, polygon);
+                continue;
+            }
             // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
             const CameraPolygon polygon(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center());
             std::string debug;
@@ -149,6 +171,17 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
 bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, int m) const
 {
     bool ok = cape_extract_host(shard.handle, depth, m, nullptr) == CAPE_OK;
+    shard.devicePolygons = false;
+    if (ok && _devicePolygons && shard.maxBatch > 8)
+    {
+        // one wavefront per output plane builds the boundary polygons behind the extraction: the host class
+        // costs ~12 us per plane, one core keeps up with ~80 k planes/s while a GPU emits millions
+        shard.polygonCopy.resize(static_cast<size_t>(shard.maxBatch) * CAPE_MAX_PLANES);
+        shard.vertexCopy.resize(static_cast<size_t>(shard.maxBatch) * _boundaryCapacity * 2);
+        ok = cape_build_polygons(shard.handle, m, nullptr) == CAPE_OK &&
+             cape_copy_polygons(shard.handle, m, shard.polygonCopy.data(), shard.vertexCopy.data()) == CAPE_OK;
+        shard.devicePolygons = ok;
+    }
     if (ok && shard.maxBatch <= 8)
         ok = cape_host_results(shard.handle, &shard.records, nullptr, nullptr, &shard.boundary) == CAPE_OK; // in place
     else if (ok)

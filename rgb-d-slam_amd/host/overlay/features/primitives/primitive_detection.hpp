@@ -50,6 +50,8 @@ class Primitive_Detection
     // 0 (default): one shard per visible device.  k > 0: k shards, shard i on device i % device_count -- more shards than
     // devices are legal (used by the tests to exercise the sharding on a one-GPU box).  Takes effect at the next batch.
     void set_shard_count(int shards) noexcept { _requestedShards = shards; }
+    // batches: boundary polygons on the device (default) or with the host class, plane by plane (A/B runs, tests)
+    void set_device_polygons(bool on) noexcept { _devicePolygons = on; }
     [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
 
     // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
@@ -75,6 +77,11 @@ class Primitive_Detection
         const double* boundary = nullptr;
         std::vector<cape_frame_record> recordCopy;
         std::vector<double> boundaryCopy;
+        // boundary polygons built on the device (batch shards: cape_build_polygons; empty for the one-frame handle, whose few
+        // polygons are cheaper on the host than one more kernel on the latency path)
+        std::vector<cape_polygon> polygonCopy;
+        std::vector<double> vertexCopy;
+        bool devicePolygons = false;
         std::string error;
     };
     bool make_shard(Shard& s, int device, int maxBatch) noexcept;
@@ -93,6 +100,7 @@ class Primitive_Detection
     int _cells = 0, _boundaryCapacity = 0;
     int _maxBatch = 64;
     int _requestedShards = 0;
+    bool _devicePolygons = true;
     int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
     int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place

@@ -94,6 +94,12 @@ class cape_gather_layout(C.Structure):
                 ("cells", C.c_int32)]
 
 
+POLYGON_DTYPE = np.dtype([
+    ("x_axis", "<f8", 3), ("y_axis", "<f8", 3), ("center", "<f8", 3), ("area", "<f8"),
+    ("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("flags", "<u4"), ("segment", "<u4")], align=True)
+POLY_VALID, POLY_CONVEX_FALLBACK, POLY_SIMPLIFIED, POLY_OVERFLOW, POLY_REJECTED = 1, 2, 4, 8, 16
+assert POLYGON_DTYPE.itemsize == 96
+
 MATCH_DTYPE = np.dtype([
     ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", CAPE_MAX_PLANES), ("area_prev", "<u2", CAPE_MAX_PLANES),
     ("area_cur", "<u2", CAPE_MAX_PLANES), ("inter", "<u2", (CAPE_MAX_PLANES, CAPE_MAX_PLANES))], align=True)
@@ -111,6 +117,7 @@ EXPORTED_SYMBOLS = [
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
+    "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
@@ -168,6 +175,10 @@ def load_library():
     L.cape_match_consecutive.argtypes = [vp, C.c_int32, C.c_uint32, vp]
     L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
     L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
+    L.cape_build_polygons.argtypes = [vp, C.c_int32, vp]
+    L.cape_device_polygons.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.cape_copy_polygons.argtypes = [vp, C.c_int32, vp, vp]
+    L.cape_debug_polygon.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp]
     L.cape_debug_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int]
     L.cape_debug_cycles.argtypes = [vp, C.c_int32, vp]
     L.cape_copy_seed_sequence.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -295,6 +306,30 @@ class Extractor:
                                                 bd.ctypes.data_as(C.c_void_p) if with_boundary else None),
                "cape_copy_results")
         return FrameResults(rec, pl, cl, bd)
+
+    # ---- N1 on the device: boundary polygons of the last batch ---------------------------------------
+    def build_polygons(self, n_frames, stream=0):
+        _check(self.L, self.L.cape_build_polygons(self.h, n_frames, C.c_void_p(stream)), "cape_build_polygons")
+
+    def polygons(self, n_frames):
+        """(polygons[n_frames, 64] structured, vertices[n_frames, boundary_capacity, 2]) of the last build_polygons."""
+        pol = np.zeros((n_frames, CAPE_MAX_PLANES), POLYGON_DTYPE)
+        ver = np.zeros((n_frames, self.boundary_capacity, 2), np.float64)
+        _check(self.L, self.L.cape_copy_polygons(self.h, n_frames, pol.ctypes.data_as(C.c_void_p), ver.ctypes.data_as(C.c_void_p)),
+               "cape_copy_polygons")
+        return pol, ver
+
+    def debug_polygon(self, points3, normal, center):
+        """Device polygon of an arbitrary 3-D point set: (record, vertices[count, 2])."""
+        pts = np.ascontiguousarray(points3, np.float64).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normal, np.float64)
+        ctr = np.ascontiguousarray(center, np.float64)
+        pol = np.zeros(1, POLYGON_DTYPE)
+        ver = np.zeros((max(1, len(pts)), 2), np.float64)
+        _check(self.L, self.L.cape_debug_polygon(self.h, pts.ctypes.data_as(C.c_void_p), len(pts), nrm.ctypes.data_as(C.c_void_p),
+                                                 ctr.ctypes.data_as(C.c_void_p), pol.ctypes.data_as(C.c_void_p),
+                                                 ver.ctypes.data_as(C.c_void_p)), "cape_debug_polygon")
+        return pol[0], ver[: int(pol[0]["vertex_count"])]
 
     # ---- N2: cell-mask plane matching between consecutive frames of the last batch -----------------
     def match_consecutive(self, n_frames, flags=0, stream=0):

@@ -93,6 +93,30 @@ int main(int argc, char** argv)
             std::snprintf(tag, sizeof tag, "B%zu ", k);
             print_frame(tag, bp[k], bc[k]);
         }
+        // the same batch with the boundary polygons built by the host class, plane by plane: identical lines expected
+        // (the device kernel and the host class run the same statements)
+        std::vector<plane_container> hp;
+        std::vector<cylinder_container> hc;
+        detector->set_device_polygons(false);
+        detector->find_primitives_batch(depth.data(), 1 + batchFrames, hp, hc);
+        detector->set_device_polygons(true);
+        for (size_t k = 0; k < hp.size(); ++k)
+        {
+            char tag[16];
+            std::snprintf(tag, sizeof tag, "H%zu ", k);
+            print_frame(tag, hp[k], hc[k]);
+            // and vertex for vertex
+            bool same = hp[k].size() == bp[k].size();
+            for (size_t i = 0; same && i < hp[k].size(); ++i)
+            {
+                const auto& a = hp[k][i].get_boundary_polygon().boundary();
+                const auto& b = bp[k][i].get_boundary_polygon().boundary();
+                same = a.size() == b.size();
+                for (size_t v = 0; same && v < a.size(); ++v)
+                    same = a[v][0] == b[v][0] && a[v][1] == b[v][1];
+            }
+            std::printf("V%zu %d\n", k, same ? 1 : 0);
+        }
     }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
     depth_image rect;

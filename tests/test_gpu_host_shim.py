@@ -92,3 +92,8 @@ def test_sharded_batch_matches_oracle(oracle_mod, host_binaries, tmp_path, shard
     for k in range(len(frames)):
         tag = f"B{k} "
         _check_frame([ln for ln in lines if ln.startswith(tag)], tag, orc.run(frames[k]))
+        # boundary polygons: built on the device (B lines) == built by the host class (H lines), summary and every vertex
+        dev = [ln[len(tag):] for ln in lines if ln.startswith(tag)]
+        host = [ln[len(tag):] for ln in lines if ln.startswith(f"H{k} ")]
+        assert dev == host and len(dev) > 0
+        assert f"V{k} 1" in lines
