@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--gather-root", action="store_true",
                     help="N>1: gather the packed lists to rank 0 only (cape_gather_primitives_root) instead of all-gathering them")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the in-run comparison of the last step's results with the CPU oracle")
+    ap.add_argument("--no-polygons", action="store_true", help="skip the extra boundary-polygon leg (cape_build_polygons)")
     ap.add_argument("--no-cylinders-on", action="store_true",
                     help="N=1 default workload: skip the extra 'cylinders_on' leg (same stream with the reference's unconditional cylinder branch)")
     args = ap.parse_args()
@@ -560,6 +561,24 @@ def main():
     else:
         out = None
 
+    polygons_leg = None
+    if rank == 0 and not args.no_polygons:
+        # "Next" row N1 on the device, outside the main timed region: boundary polygons of every output plane of the last
+        # batch (one wavefront per plane), timed with events on the launch stream
+        ex.build_polygons(B, stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kp = 5
+        e0.record()
+        for _ in range(kp):
+            ex.build_polygons(B, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        n_pl, _, _ = ex.count_primitives(B)
+        ms = e0.elapsed_time(e1) / kp
+        polygons_leg = {"ms_per_batch": ms, "planes": n_pl, "planes_per_s": n_pl / (ms * 1e-3), "frames_per_s": B / (ms * 1e-3),
+                        "note": "cape_build_polygons over the batch's output planes; vertices bit-identical to the host class "
+                                "(tests/test_gpu_polygon.py), which builds ~80 k polygons/s on one core"}
     if gather == "native":
         ex.comm_destroy()
     ex.close()
@@ -597,6 +616,8 @@ def main():
                 raise SystemExit(3)
         ex2.close()
         out["cylinders_on"] = cyl
+    if out is not None and polygons_leg is not None:
+        out["boundary_polygons"] = polygons_leg
     result_line = json.dumps(out) if out is not None else None
     if multi:
         dist.destroy_process_group()

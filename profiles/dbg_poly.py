@@ -1,16 +1,37 @@
-import sys, os, ctypes as C
+import sys, time
 sys.path.insert(0, "rgb-d-slam_amd/python")
-import numpy as np
+import numpy as np, torch
 import cape_amd
-from cape_amd import Extractor, synth
-cape_amd.load_library()
-ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
-xy = np.stack([np.linspace(0, 900, 30), np.linspace(0, 900, 30) * 0.5], 1)
-for nrm in [(0, 0, 1.0), (0, 0.6, 0.8), (0.48, 0.6, 0.64), (1.0, 0, 0)]:
-    nrm = np.asarray(nrm) / np.linalg.norm(nrm)
-    center = np.array([120.0, -340.0, 2100.0])
-    a = np.cross(nrm, [0.3, -0.5, 0.8]); a /= np.linalg.norm(a); b = np.cross(nrm, a)
-    pts = center + xy[:, :1] * a + xy[:, 1:] * b
-    pol, verts = ex.debug_polygon(pts, nrm, center)
-    print(nrm, "count", pol["vertex_count"], "flags", pol["flags"], "area", pol["area"])
-    print(verts[:8])
+from cape_amd import Extractor, synth, synth_gpu
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+scene = sys.argv[2] if len(sys.argv) > 2 else "room"
+intr = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+dev = synth_gpu.stream(scene, 100, B, device="cuda")
+ex = Extractor(640, 480, max_batch=B, **intr)
+st = torch.cuda.current_stream().cuda_stream
+ex.extract_device(dev.data_ptr(), B, st)
+ex.build_polygons(B, st)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); ex.build_polygons(B, st); torch.cuda.synchronize(); print("ms", 1e3 * (time.perf_counter() - t0))
+res = ex.results(B, with_boundary=False)
+pol, _ = ex.polygons(B)
+segs = res.records["segments"]
+out = segs["is_output"] == 1
+bc = segs["boundary_count"][out]
+fl = pol["flags"][out]
+vc = pol["vertex_count"][out]
+print("planes", out.sum(), "boundary points: mean %.1f p50 %d p90 %d p99 %d max %d" % (bc.mean(), *np.percentile(bc, [50, 90, 99]), bc.max()))
+print("flags: valid %.3f convex_fallback %.3f simplified %.3f overflow %d" % ((fl & 1).astype(bool).mean(), (fl & 2).astype(bool).mean(), (fl & 4).astype(bool).mean(), (fl & 8).astype(bool).sum()))
+print("vertices: mean %.1f max %d" % (vc.mean(), vc.max()))
+# latency of a lone plane-wave: one frame
+for nb in (1, 64, 512):
+    ex1 = Extractor(640, 480, max_batch=max(nb, 16), **intr)
+    ex1.extract_device(dev.data_ptr(), nb, st)
+    ex1.build_polygons(nb, st); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ex1.build_polygons(nb, st)
+    e1.record(); torch.cuda.synchronize()
+    print("frames", nb, "polygon pass ms", e0.elapsed_time(e1) / 10)
+    ex1.close()

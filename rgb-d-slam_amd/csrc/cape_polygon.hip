@@ -25,7 +25,11 @@
 namespace cape {
 
 constexpr int kPolyWavesPerGroup = 4;
-constexpr int kPolyPerLane = kPolyMaxPoints / 64; // points a lane owns in the lane-parallel passes
+// Two instances: planes of up to kPolySmallPoints boundary candidates (every plane of the 640x480 test streams: at most 175)
+// are built by waves that hold 7 KB of LDS each, twenty to a CU; a plane with more is DEFERRED to the kPolyMaxPoints
+// instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
+constexpr int kPolySmallPoints = 256;
+constexpr uint32_t kPolyDeferred = 1u << 31; // internal: left by the small instance for the large one, never returned
 
 #define CAPE_POLY_SYNC()                                                                                      \
     do                                                                                                       \
@@ -112,8 +116,13 @@ __device__ __forceinline__ bool ring_is_simple(const double2* pts, const unsigne
     if (n < 3)
         return false;
     bool bad = false;
-    for (int i = lane; i < n; i += 64)
+    // edge i meets the edges j > i: the first edges have the longest lists, so a lane takes edge t from the front on even
+    // rounds and from the back on odd ones
+    for (int base = 0, round = 0; base < n; base += 64, ++round)
     {
+        const int i = base + ((round & 1) ? 63 - lane : lane);
+        if (i >= n)
+            continue;
         const double2 a1 = pts[ring[i]], a2 = pts[ring[(i + 1) % n]];
         for (int j = i + 1; j < n && !bad; ++j)
         {
@@ -169,8 +178,9 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 }
 
 // One run of the k-nearest-neighbours hull (host: concave_hull_k).  On success the hull's point indices are in L.hull[0, hs).
-__device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut)
+template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut)
 {
+    constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
     const double2* pts = L.pts;
     if (n < 3)
         return false;
@@ -233,6 +243,8 @@ __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, 
         {
             const int i = lane + 64 * j;
             d2bits[j] = ~0ull;
+            if (64 * j >= n)
+                continue; // (uniform: a plane of 150 points uses three of the sixteen slots)
             if (i < n && !L.used[i] && i != current)
             {
                 const double2 q = pts[i];
@@ -255,7 +267,7 @@ __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, 
             int bestJ = -1;
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
-                if (((avail >> j) & 1u) && d2bits[j] < best) // ascending j = ascending index inside the lane
+                if (64 * j < n && ((avail >> j) & 1u) && d2bits[j] < best) // ascending j = ascending index inside the lane
                 {
                     best = d2bits[j];
                     bestJ = j;
@@ -373,8 +385,11 @@ __device__ inline void sort_points(const PolyLds& L, int n, int lane)
         }
 }
 
-__global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+template <int CAP>
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kernel(PolygonParams p, int nFrames, int ldsPerWave)
 {
+    constexpr int kPolyPerLane = CAP / 64;
+    constexpr bool kSecondPass = CAP > kPolySmallPoints;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int task = blockIdx.x * kPolyWavesPerGroup + wave; // (frame, slot): slot s of a frame = planes s, s + kPolySlots, ...
@@ -384,11 +399,11 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(P
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
-    L.hull = reinterpret_cast<unsigned short*>(L.pts + kPolyMaxPoints);
-    L.ring = L.hull + kPolyMaxPoints + 2;
-    L.stack = reinterpret_cast<unsigned int*>(L.ring + kPolyMaxPoints + 2);
-    L.used = reinterpret_cast<unsigned char*>(L.stack + kPolyMaxPoints);
-    L.keep = L.used + kPolyMaxPoints;
+    L.hull = reinterpret_cast<unsigned short*>(L.pts + CAP);
+    L.ring = L.hull + CAP + 2;
+    L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2);
+    L.used = reinterpret_cast<unsigned char*>(L.stack + CAP);
+    L.keep = L.used + CAP;
 
     const cape_frame_record& rec = p.records[frame];
     const int nSeg = rec.header.n_plane_segments;
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(P
     const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
     const unsigned long long outMask = __ballot(isOut);
     // segments that are not planes carry an empty polygon record
-    if (slot == 0 && lane < CAPE_MAX_PLANES && !isOut)
+    if (!kSecondPass && slot == 0 && lane < CAPE_MAX_PLANES && !isOut)
     {
         cape_polygon* o = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + lane];
         o->vertex_count = 0;
@@ -415,6 +430,14 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(P
         double2* vout = p.vertices + (size_t)frame * p.boundaryCapacity + S.boundary_offset;
         const int nPts = (int)S.boundary_count;
         uint32_t flags = 0;
+        if (kSecondPass && !(out->flags & kPolyDeferred))
+            continue; // built by the small instance
+        if (!kSecondPass && nPts > CAP && nPts <= kPolyMaxPoints)
+        {
+            if (lane == 0)
+                out->flags = kPolyDeferred;
+            continue;
+        }
         // ---- plane frame: get_plane_coordinate_system (polygon.cpp:74-115 with select_correct_transform :50-68)
         const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
         const double cx = S.centroid[0], cy = S.centroid[1], cz = S.centroid[2];
@@ -497,7 +520,11 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(P
                 for (int a = 0; a < 8 && !haveRing; ++a)
                 {
                     const int k = ladder[a];
-                    if (concave_hull_k(L, n, k, lane, hs) && ring_is_simple(L.pts, L.hull, hs, lane))
+                    // (the ladder's second rung repeats the first: the run is a pure function of the points and k, so a
+                    //  failed k = 3 fails again -- the host class runs it twice, the result is the same)
+                    if (a == 1)
+                        continue;
+                    if (concave_hull_k<CAP>(L, n, k, lane, hs) && ring_is_simple(L.pts, L.hull, hs, lane))
                         haveRing = true;
                     else if (k > n)
                         break;
@@ -691,21 +718,25 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup) void cape_polygon_kernel(P
     }
 }
 
-size_t polygon_lds_bytes()
+size_t polygon_lds_bytes(int cap)
 {
-    size_t b = (size_t)kPolyMaxPoints * 16;            // pts
-    b += 2 * ((size_t)kPolyMaxPoints + 2) * 2;         // hull, ring
-    b += (size_t)kPolyMaxPoints * 4;                   // stack
-    b += (size_t)kPolyMaxPoints + kPolyMaxPoints + 2;  // used, keep
+    size_t b = (size_t)cap * 16;            // pts
+    b += 2 * ((size_t)cap + 2) * 2;         // hull, ring
+    b += (size_t)cap * 4;                   // stack
+    b += (size_t)cap + cap + 2;             // used, keep
     return (b + 15) & ~(size_t)15;
 }
 
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    const int ldsPerWave = (int)polygon_lds_bytes();
     const int tasks = nFrames * kPolySlots;
-    hipLaunchKernelGGL(cape_polygon_kernel, dim3((tasks + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup), dim3(64 * kPolyWavesPerGroup),
-                       (size_t)ldsPerWave * kPolyWavesPerGroup, stream, p, nFrames, ldsPerWave);
+    const dim3 grid((tasks + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup), block(64 * kPolyWavesPerGroup);
+    const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
+    hipLaunchKernelGGL(cape_polygon_kernel<kPolySmallPoints>, grid, block, (size_t)ldsSmall * kPolyWavesPerGroup, stream, p, nFrames, ldsSmall);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
+    if (p.boundaryCapacity > kPolySmallPoints) // a plane cannot hold more boundary points than the frame
+        hipLaunchKernelGGL(cape_polygon_kernel<kPolyMaxPoints>, grid, block, (size_t)ldsLarge * kPolyWavesPerGroup, stream, p, nFrames, ldsLarge);
     return hipGetLastError();
 }
 
