@@ -175,3 +175,37 @@ def test_polygon_random_point_sets_property(host_poly):
         pol, verts = ex.debug_polygon(pts, nrm, center)
         _same(pol, verts, ref, f"trial {trial} ({n} points, kind {kind})")
     ex.close()
+
+
+def test_polygons_1280x960_and_one_frame_handle(host_poly):
+    """The 64x48 grid (planes with several hundred boundary candidates: the 1 024-point instance on real data) and a
+    one-frame handle, whose records, boundary points and polygons live in pinned host memory."""
+    import torch
+    import cape_amd
+    from cape_amd import Extractor, synth, synth_gpu
+
+    intr = {k: v * 2.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
+    n = 6
+    dev = synth_gpu.stream("room", 91, n, width=1280, height=960, start=40, device="cuda", chunk=2)
+    st = torch.cuda.current_stream().cuda_stream
+    big = 0
+    for max_batch, frames in ((n, n), (1, 1)):
+        ex = Extractor(1280, 960, cylinders=True, max_batch=max_batch, **intr)
+        ex.extract_device(dev.data_ptr(), frames, st)
+        ex.build_polygons(frames, st)
+        res = ex.results(frames)
+        pol, ver = ex.polygons(frames)
+        for f in range(frames):
+            for i, s in enumerate(res.segments(f)):
+                if not s["is_output"]:
+                    continue
+                p = pol[f, i]
+                pts = res.boundary_points(f, s)
+                if len(pts) > 1024:
+                    assert p["flags"] & cape_amd.POLY_OVERFLOW
+                    continue
+                big += int(len(pts) > 256)
+                o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+                _same(p, ver[f, o:o + c], host_poly(pts, s["normal"], s["centroid"]), f"1280x960 frame {f} segment {i} ({len(pts)} points)")
+        ex.close()
+    assert big > 0, "the wide grid must produce planes beyond the small instance's 256 points"
