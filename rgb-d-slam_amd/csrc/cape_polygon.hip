@@ -221,6 +221,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     }
     CAPE_POLY_SYNC();
     int hs = 1;
+    int usedCount = 1;
     int current = first;
     double Px = -1.0, Py = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
     int step = 1;
@@ -231,30 +232,31 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         {
             if (lane == 0)
                 L.used[first] = 0; // the start point becomes reachable again once the hull has three edges
+            --usedCount;
             CAPE_POLY_SYNC();
         }
         const double2 cur = pts[current];
         // ---- k nearest unused neighbours of the current point, ascending (squared distance, index)
-        unsigned long long d2bits[kPolyPerLane];
-        unsigned avail = 0; // bit j: the lane's point lane + 64 j is a candidate that has not been taken yet
-        int cnt = 0;
+        // key = the squared distance's bit pattern (>= +0: the bits order like the value) with its ten lowest mantissa bits
+        // replaced by the point index: ONE 64-bit wave minimum per neighbour yields the nearest point and breaks ties (and
+        // distances within 2^-42 of each other) by index.  The host class sorts by the very same key.
+        unsigned long long key[kPolyPerLane];
 #pragma unroll
         for (int j = 0; j < kPolyPerLane; ++j)
         {
             const int i = lane + 64 * j;
-            d2bits[j] = ~0ull;
+            key[j] = ~0ull;
             if (64 * j >= n)
                 continue; // (uniform: a plane of 150 points uses three of the sixteen slots)
             if (i < n && !L.used[i] && i != current)
             {
                 const double2 q = pts[i];
                 const double dx = q.x - cur.x, dy = q.y - cur.y;
-                d2bits[j] = (unsigned long long)__double_as_longlong(dx * dx + dy * dy); // >= +0: the bits order like the value
-                avail |= 1u << j;
-                ++cnt;
+                key[j] = ((unsigned long long)__double_as_longlong(dx * dx + dy * dy) & ~1023ull) | (unsigned long long)i;
             }
         }
-        cnt = wave_sum_i32(cnt);
+        // every used point is on the hull and the current point is one of them
+        const int cnt = n - usedCount;
         if (cnt == 0)
             break;
         const int kk = k < cnt ? k : cnt;
@@ -264,19 +266,16 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         for (int c = 0; c < kk; ++c)
         {
             unsigned long long best = ~0ull;
-            int bestJ = -1;
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
-                if (64 * j < n && ((avail >> j) & 1u) && d2bits[j] < best) // ascending j = ascending index inside the lane
-                {
-                    best = d2bits[j];
-                    bestJ = j;
-                }
+                if (64 * j < n && key[j] < best)
+                    best = key[j];
             const unsigned long long m = wave_min_u64(best);
-            const unsigned mine = (bestJ >= 0 && best == m) ? (unsigned)(0x7FFFFFFF - (lane + 64 * bestJ)) : 0u;
-            const int idx = 0x7FFFFFFF - (int)wave_max_u32(mine); // smallest index among the equal distances
-            if (bestJ >= 0 && lane + 64 * bestJ == idx)
-                avail &= ~(1u << bestJ);
+            const int idx = (int)(m & 1023ull);
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+                if (64 * j < n && key[j] == m)
+                    key[j] = ~0ull; // taken (keys are unique: they carry the index)
             if (lane == c)
             {
                 const double2 q = pts[idx];
@@ -340,6 +339,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             L.used[current] = 1;
         }
         ++hs;
+        ++usedCount;
         --remaining;
         ++step;
         CAPE_POLY_SYNC();

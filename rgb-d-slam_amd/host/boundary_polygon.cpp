@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <limits>
 #include <stdexcept>
 
@@ -115,7 +117,11 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
     double prevX = -1.0, prevY = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
     size_t step = 1;
     size_t remaining = n - 1;
-    std::vector<std::pair<double, size_t>> cand; // reused from step to step
+    // nearest-first order of the candidates: by the squared distance's bit pattern (>= +0: the bits order like the value)
+    // with its ten lowest mantissa bits replaced by the point index -- a single 64-bit key, which is what lets the device
+    // hull (csrc/cape_polygon.hip) pick a neighbour with ONE wave-wide minimum; ties and distances within 2^-42 of each other
+    // go to the smaller index.  (Point sets beyond the device's 1 024 points keep the plain (distance, index) order.)
+    std::vector<std::pair<uint64_t, size_t>> cand; // reused from step to step
     cand.reserve(n);
     while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
     {
@@ -127,7 +133,10 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
             if (!used[i] && i != current)
             {
                 const double dx = pts[i][0] - pts[current][0], dy = pts[i][1] - pts[current][1];
-                cand.emplace_back(dx * dx + dy * dy, i);
+                const double d2 = dx * dx + dy * dy;
+                uint64_t bits;
+                std::memcpy(&bits, &d2, sizeof bits);
+                cand.emplace_back(n <= 1024 ? ((bits & ~uint64_t(1023)) | static_cast<uint64_t>(i)) : bits, i);
             }
         if (cand.empty())
             break;
