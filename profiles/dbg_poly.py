@@ -1,4 +1,4 @@
-import sys, time
+import sys, time, os
 sys.path.insert(0, "rgb-d-slam_amd/python")
 import numpy as np, torch
 import cape_amd
@@ -35,3 +35,12 @@ for nb in (1, 64, 512):
     e1.record(); torch.cuda.synchronize()
     print("frames", nb, "polygon pass ms", e0.elapsed_time(e1) / 10)
     ex1.close()
+if os.environ.get("CAPE_POLY_PHASES"):
+    ex.build_polygons(B, st); torch.cuda.synchronize()
+    cyc = ex.debug_cycles(B).astype(np.float64).sum(0)
+    planes = cyc[11]
+    names = ["projection + sort + dedupe", "hull walks", "simple-ring test of hulls", "orientation + re-check (+ convex fallback)", "area + simplify", "final validity + stores"]
+    tot = cyc[:6].sum()
+    print("per plane: %.0f ticks; attempts %.2f; vertices before simplify %.1f; distinct points %.1f" % (tot / planes, cyc[8] / planes, cyc[9] / planes, cyc[10] / planes))
+    for k, nm in enumerate(names):
+        print("  %-45s %8.0f ticks  %5.1f %%" % (nm, cyc[k] / planes, 100 * cyc[k] / tot))

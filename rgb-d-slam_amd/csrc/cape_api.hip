@@ -1665,6 +1665,10 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     p.polygons = h->polygons;
     p.vertices = reinterpret_cast<double2*>(h->polyVertices);
     p.boundaryCapacity = h->boundaryCap;
+    p.prof = h->debugCycles;
+#ifdef CAPE_POLY_PROFILE
+    CAPE_HIP_TRY(hipMemsetAsync(h->debugCycles, 0, (size_t)n_frames * cape::kProfileSlots * 8, stream));
+#endif
     h->doneArmed = false; // the chain's completion word was written before this kernel: results are waited for the slow way
     CAPE_HIP_TRY(cape::launch_polygons(p, n_frames, stream));
     return CAPE_OK;
@@ -1746,6 +1750,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         p.polygons = poly;
         p.vertices = reinterpret_cast<double2*>(verts);
         p.boundaryCapacity = h->boundaryCap;
+        p.prof = nullptr;
         if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
             step(hipMemcpy(polygon_out, poly, sizeof(cape_polygon), hipMemcpyDeviceToHost), "hipMemcpy"))
         {

@@ -171,6 +171,7 @@ struct PolygonParams
     cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
     double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
     int boundaryCapacity;
+    unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
 
 struct RcclUniqueId

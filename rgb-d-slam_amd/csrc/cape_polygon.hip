@@ -31,6 +31,26 @@ constexpr int kPolyWavesPerGroup = 4;
 constexpr int kPolySmallPoints = 256;
 constexpr uint32_t kPolyDeferred = 1u << 31; // internal: left by the small instance for the large one, never returned
 
+#ifdef CAPE_POLY_PROFILE
+#define CAPE_PTICK(k)                                                                     \
+    do                                                                                    \
+    {                                                                                     \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                       \
+        if (lane == 0 && p.prof)                                                          \
+            atomicAdd(&p.prof[(size_t)frame * kProfileSlots + (k)], _n - _pt);            \
+        _pt = _n;                                                                         \
+    } while (0)
+#define CAPE_PCOUNT(k, v)                                                                 \
+    do                                                                                    \
+    {                                                                                     \
+        if (lane == 0 && p.prof)                                                          \
+            atomicAdd(&p.prof[(size_t)frame * kProfileSlots + (k)], (unsigned long long)(v)); \
+    } while (0)
+#else
+#define CAPE_PTICK(k)
+#define CAPE_PCOUNT(k, v)
+#endif
+
 #define CAPE_POLY_SYNC()                                                                                      \
     do                                                                                                       \
     {                                                                                                        \
@@ -430,6 +450,9 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
         double2* vout = p.vertices + (size_t)frame * p.boundaryCapacity + S.boundary_offset;
         const int nPts = (int)S.boundary_count;
         uint32_t flags = 0;
+#ifdef CAPE_POLY_PROFILE
+        unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#endif
         if (kSecondPass && !(out->flags & kPolyDeferred))
             continue; // built by the small instance
         if (!kSecondPass && nPts > CAP && nPts <= kPolyMaxPoints)
@@ -511,6 +534,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
                 n += __popcll(kb);
                 CAPE_POLY_SYNC();
             }
+            CAPE_PTICK(0); // projection, sort, duplicate removal
             // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
             int hs = 0;
             bool haveRing = false;
@@ -524,9 +548,13 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
                     //  failed k = 3 fails again -- the host class runs it twice, the result is the same)
                     if (a == 1)
                         continue;
-                    if (concave_hull_k<CAP>(L, n, k, lane, hs) && ring_is_simple(L.pts, L.hull, hs, lane))
+                    CAPE_PCOUNT(8, 1); // hull attempts
+                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs);
+                    CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
+                    if (hullOk && ring_is_simple(L.pts, L.hull, hs, lane))
                         haveRing = true;
-                    else if (k > n)
+                    CAPE_PTICK(2); // simple-ring test of a hull
+                    if (!haveRing && k > n)
                         break;
                 }
             }
@@ -599,6 +627,9 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
                 }
                 CAPE_POLY_SYNC();
             }
+            CAPE_PTICK(3); // orientation, validity of the oriented ring, convex fallback
+            CAPE_PCOUNT(9, rn); // vertices before simplification
+            CAPE_PCOUNT(10, n); // distinct points
             area = rn >= 3 ? fabs(ring_area_signed(L.pts, ring, rn)) : 0.0;
             // ---- simplify (polygon.cpp:578-601): Douglas-Peucker on the closed ring, threshold max(area / 1e5, 10); kept if the
             //      result is a simple ring whose area stays above 75 %
@@ -696,12 +727,15 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
                     }
                 }
             }
+            CAPE_PTICK(4); // area + simplify
             // ---- what Primitive_Detection keeps: a valid polygon of at least three vertices (primitive_detection.cpp:623-631)
             if (rn >= 3 && ring_is_simple(L.pts, ring, rn, lane))
                 flags |= CAPE_POLY_VALID;
             for (int i = lane; i < rn; i += 64)
                 vout[i] = L.pts[ring[i]];
             count = rn;
+            CAPE_PTICK(5); // final validity, vertex stores
+            CAPE_PCOUNT(11, 1); // planes
         }
         if (lane == 0)
         {
