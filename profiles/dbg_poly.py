@@ -44,3 +44,10 @@ if os.environ.get("CAPE_POLY_PHASES"):
     print("per plane: %.0f ticks; attempts %.2f; vertices before simplify %.1f; distinct points %.1f" % (tot / planes, cyc[8] / planes, cyc[9] / planes, cyc[10] / planes))
     for k, nm in enumerate(names):
         print("  %-45s %8.0f ticks  %5.1f %%" % (nm, cyc[k] / planes, 100 * cyc[k] / tot))
+if os.environ.get("CAPE_POLY_PHASES"):
+    per = ex.debug_cycles(B).astype(np.float64)
+    t = per[:, :6].sum(1)
+    print("per-frame ticks percentiles:", {q: int(np.percentile(t, q)) for q in (50, 90, 99, 99.9, 100)})
+    w = np.argsort(t)[-5:]
+    for f in w:
+        print("  frame", f, "ticks", int(t[f]), "planes", int(per[f, 11]), "attempts", int(per[f, 8]), "hull ticks", int(per[f, 1]), "points", int(per[f, 10]))

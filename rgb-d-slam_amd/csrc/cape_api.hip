@@ -208,6 +208,7 @@ struct cape_handle_s
     // N1 on the device: polygons of the last batch (allocated on first use)
     cape_polygon* polygons = nullptr;
     double* polyVertices = nullptr;
+    uint32_t* polyLadder = nullptr; // planes deferred to the ladder kernel
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
     cape::StageBParams pb{};
@@ -254,6 +255,7 @@ void free_all(cape_handle_s* h)
         (void)hipEventDestroy(h->handedOverReady);
     (void)hipFree(h->debugCycles);
     (void)hipFree(h->countScratch);
+    (void)hipFree(h->polyLadder);
     if (h->resultsOnHost)
     {
         if (h->polygons)
@@ -1655,11 +1657,14 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
             CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyVertices), B * (size_t)h->boundaryCap * 2 * sizeof(double)));
         }
     }
+    if (!h->polyLadder)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), (B * CAPE_MAX_PLANES + 1) * sizeof(uint32_t)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
     cape::PolygonParams p;
+    p.ladderList = h->polyLadder;
     p.records = h->records;
     p.boundary = h->boundary;
     p.polygons = h->polygons;
@@ -1714,6 +1719,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
     double* bnd = nullptr;
     cape_polygon* poly = nullptr;
     double* verts = nullptr;
+    uint32_t* ladder = nullptr;
     cape_frame_record* hostRec = new (std::nothrow) cape_frame_record();
     if (!hostRec)
         return fail(CAPE_ERR_HIP, "out of host memory");
@@ -1741,6 +1747,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         step(hipMalloc(reinterpret_cast<void**>(&bnd), cap * 3 * sizeof(double)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&poly), CAPE_MAX_PLANES * sizeof(cape_polygon)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&verts), cap * 2 * sizeof(double)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&ladder), (CAPE_MAX_PLANES + 1) * sizeof(uint32_t)), "hipMalloc") &&
         step(hipMemcpy(rec, hostRec, sizeof(cape_frame_record), hipMemcpyHostToDevice), "hipMemcpy") &&
         step(n ? hipMemcpy(bnd, points3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice) : hipSuccess, "hipMemcpy"))
     {
@@ -1751,6 +1758,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         p.vertices = reinterpret_cast<double2*>(verts);
         p.boundaryCapacity = h->boundaryCap;
         p.prof = nullptr;
+        p.ladderList = ladder;
         if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
             step(hipMemcpy(polygon_out, poly, sizeof(cape_polygon), hipMemcpyDeviceToHost), "hipMemcpy"))
         {
@@ -1762,6 +1770,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
     (void)hipFree(bnd);
     (void)hipFree(poly);
     (void)hipFree(verts);
+    (void)hipFree(ladder);
     delete hostRec;
     return rc;
 }

@@ -30,6 +30,20 @@ constexpr int kPolyWavesPerGroup = 4;
 // instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
 constexpr int kPolySmallPoints = 256;
 constexpr uint32_t kPolyDeferred = 1u << 31; // internal: left by the small instance for the large one, never returned
+// The k ladder.  Nearly every plane gets its hull on the first rung (1.13 attempts on average), but a plane that climbs to
+// k = 21 spends ~3 ms in one wave, and a kernel lasts as long as its slowest wave (4.2 ms per 4 096 room frames, one plane in
+// a thousand).  So the small instance runs the FIRST rung only and defers a plane that fails it (kPolyDeferredLadder) to the
+// ladder kernel: a workgroup of six waves per such plane, wave w on rung w + 2 (k = 5, 7, 11, 13, 17, 21), all at once; the
+// lowest rung that yields a simple hull wins, exactly as if they had run one after the other (a run is a pure function of
+// the points and k).
+constexpr uint32_t kPolyDeferredLadder = 1u << 30;
+constexpr int kLadderWaves = 6;
+enum PolyMode
+{
+    kPolyFirstRung = 0, // small instance: rung 0, defer on failure
+    kPolyLadder = 1,    // small instance, six waves per plane: rungs 2 .. 7 in parallel
+    kPolyFull = 2       // large instance: the whole ladder in one wave (rare twice over)
+};
 
 #ifdef CAPE_POLY_PROFILE
 #define CAPE_PTICK(k)                                                                     \
@@ -198,7 +212,10 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 }
 
 // One run of the k-nearest-neighbours hull (host: concave_hull_k).  On success the hull's point indices are in L.hull[0, hs).
-template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut)
+// `lowestDone` (ladder kernel only, else null): LDS word holding the lowest rung that already has its hull; a higher rung gives
+// up as soon as it sees one below it succeed -- it can no longer win.
+template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut, const volatile int* lowestDone = nullptr,
+                                                        int myRung = 0)
 {
     constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
     const double2* pts = L.pts;
@@ -248,6 +265,8 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     int remaining = n - 1;
     while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
     {
+        if (lowestDone && __builtin_amdgcn_readfirstlane(*lowestDone) < myRung)
+            return false;
         if (step == 4)
         {
             if (lane == 0)
@@ -405,17 +424,36 @@ __device__ inline void sort_points(const PolyLds& L, int n, int lane)
         }
 }
 
-template <int CAP>
-__global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+template <int CAP, int MODE>
+__global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup), MODE == kPolyLadder ? 2 : 4) void cape_polygon_kernel(
+        PolygonParams p, int nFrames, int ldsPerWave)
 {
     constexpr int kPolyPerLane = CAP / 64;
-    constexpr bool kSecondPass = CAP > kPolySmallPoints;
+    constexpr bool kSecondPass = MODE != kPolyFirstRung;
+    constexpr int kWaves = MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int task = blockIdx.x * kPolyWavesPerGroup + wave; // (frame, slot): slot s of a frame = planes s, s + kPolySlots, ...
-    const int frame = task / kPolySlots, slot = task - frame * kPolySlots;
-    if (frame >= nFrames)
-        return;
+    // (frame, slot): slot s of a frame = planes s, s + kPolySlots, ... ; one wave per task.  The ladder kernel walks the list
+    // of deferred planes instead, one WORKGROUP per entry, a fixed number of workgroups striding over it.
+    int* s_ok = reinterpret_cast<int*>(smem_all + (size_t)kWaves * ldsPerWave); // ladder kernel: verdict of every rung
+    const unsigned nDeferred = MODE == kPolyLadder ? p.ladderList[0] : 1u;
+  for (unsigned entryNo = MODE == kPolyLadder ? blockIdx.x : 0u; entryNo < nDeferred; entryNo += MODE == kPolyLadder ? gridDim.x : 1u)
+  {
+    int frame, slot = 0, onlySeg = -1;
+    if (MODE == kPolyLadder)
+    {
+        const unsigned e = p.ladderList[1 + entryNo];
+        frame = (int)(e >> 8);
+        onlySeg = (int)(e & 255u);
+    }
+    else
+    {
+        const int task = (int)blockIdx.x * kPolyWavesPerGroup + wave;
+        frame = task / kPolySlots;
+        slot = task - frame * kPolySlots;
+        if (frame >= nFrames)
+            return;
+    }
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
     const int nSeg = rec.header.n_plane_segments;
     // the slot's planes: the s-th, (s + kPolySlots)-th, ... segment with is_output (lane j looks at segment j)
     const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
-    const unsigned long long outMask = __ballot(isOut);
+    const unsigned long long outMask = MODE == kPolyLadder ? (1ull << onlySeg) : __ballot(isOut);
     // segments that are not planes carry an empty polygon record
     if (!kSecondPass && slot == 0 && lane < CAPE_MAX_PLANES && !isOut)
     {
@@ -442,7 +480,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
     int ordinal = 0;
     for (unsigned long long m = outMask; m; m &= m - 1, ++ordinal)
     {
-        if (ordinal % kPolySlots != slot)
+        if (MODE != kPolyLadder && ordinal % kPolySlots != slot)
             continue;
         const int seg = __ffsll((long long)m) - 1;
         const cape_plane_segment& S = rec.segments[seg];
@@ -453,9 +491,11 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
 #ifdef CAPE_POLY_PROFILE
         unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #endif
-        if (kSecondPass && !(out->flags & kPolyDeferred))
+        if (MODE == kPolyFull && !(out->flags & kPolyDeferred))
             continue; // built by the small instance
-        if (!kSecondPass && nPts > CAP && nPts <= kPolyMaxPoints)
+        if (MODE == kPolyLadder && !(out->flags & kPolyDeferredLadder))
+            continue; // got its hull on the first rung (the verdict is the same for all six waves: uniform)
+        if (MODE == kPolyFirstRung && nPts > CAP && nPts <= kPolyMaxPoints)
         {
             if (lane == 0)
                 out->flags = kPolyDeferred;
@@ -538,10 +578,17 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
             // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
             int hs = 0;
             bool haveRing = false;
+            if (MODE == kPolyLadder)
+            {
+                if (threadIdx.x == 0)
+                    s_ok[8] = kLadderWaves; // no rung has a hull yet
+                __syncthreads();
+            }
             if (n >= 3)
             {
                 const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
-                for (int a = 0; a < 8 && !haveRing; ++a)
+                const int aFirst = MODE == kPolyLadder ? 2 + wave : 0, aLast = MODE == kPolyFull ? 7 : aFirst;
+                for (int a = aFirst; a <= aLast && !haveRing; ++a)
                 {
                     const int k = ladder[a];
                     // (the ladder's second rung repeats the first: the run is a pure function of the points and k, so a
@@ -549,14 +596,43 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
                     if (a == 1)
                         continue;
                     CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs);
+                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs, MODE == kPolyLadder ? s_ok + 8 : nullptr, wave);
                     CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
                     if (hullOk && ring_is_simple(L.pts, L.hull, hs, lane))
+                    {
                         haveRing = true;
+                        if (MODE == kPolyLadder && lane == 0)
+                            atomicMin(s_ok + 8, wave);
+                    }
                     CAPE_PTICK(2); // simple-ring test of a hull
                     if (!haveRing && k > n)
                         break;
                 }
+                if (MODE == kPolyFirstRung && !haveRing)
+                {
+                    // the first rung failed: the ladder kernel takes the plane
+                    if (lane == 0)
+                    {
+                        out->flags = kPolyDeferredLadder;
+                        p.ladderList[1 + atomicAdd(&p.ladderList[0], 1u)] = ((unsigned)frame << 8) | (unsigned)seg;
+                    }
+                    continue;
+                }
+            }
+            if (MODE == kPolyLadder)
+            {
+                // the lowest rung with a simple hull wins and finishes the polygon; if none has one, wave 0 takes the convex
+                // fallback (every wave holds the same sorted points)
+                if (lane == 0)
+                    s_ok[wave] = haveRing ? 1 : 0;
+                __syncthreads();
+                int winner = -1;
+                for (int w = kLadderWaves - 1; w >= 0; --w)
+                    if (s_ok[w])
+                        winner = w;
+                __syncthreads(); // s_ok is rewritten for the next deferred plane of this slot
+                if (wave != (winner < 0 ? 0 : winner))
+                    continue;
             }
             unsigned short* ring = L.ring;
             int rn = 0;
@@ -750,6 +826,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_kerne
         }
         CAPE_POLY_SYNC();
     }
+  } // entries of the ladder list (one pass for the other instances)
 }
 
 size_t polygon_lds_bytes(int cap)
@@ -764,13 +841,22 @@ size_t polygon_lds_bytes(int cap)
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
     const int tasks = nFrames * kPolySlots;
+    if (const hipError_t e = hipMemsetAsync(p.ladderList, 0, sizeof(uint32_t), stream); e != hipSuccess)
+        return e;
     const dim3 grid((tasks + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup), block(64 * kPolyWavesPerGroup);
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
-    hipLaunchKernelGGL(cape_polygon_kernel<kPolySmallPoints>, grid, block, (size_t)ldsSmall * kPolyWavesPerGroup, stream, p, nFrames, ldsSmall);
+    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyFirstRung>), grid, block, (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,
+                       nFrames, ldsSmall);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
+    // planes that failed the first rung: one workgroup of six waves each (a workgroup whose slot holds none leaves at once)
+    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyLadder>), dim3(tasks < 768 ? tasks : 768), dim3(64 * kLadderWaves),
+                       (size_t)ldsSmall * kLadderWaves + 64, stream, p, nFrames, ldsSmall);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     if (p.boundaryCapacity > kPolySmallPoints) // a plane cannot hold more boundary points than the frame
-        hipLaunchKernelGGL(cape_polygon_kernel<kPolyMaxPoints>, grid, block, (size_t)ldsLarge * kPolyWavesPerGroup, stream, p, nFrames, ldsLarge);
+        hipLaunchKernelGGL((cape_polygon_kernel<kPolyMaxPoints, kPolyFull>), grid, block, (size_t)ldsLarge * kPolyWavesPerGroup + 64, stream, p,
+                           nFrames, ldsLarge);
     return hipGetLastError();
 }
 
