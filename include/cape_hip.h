@@ -49,6 +49,12 @@ enum
 {
     CAPE_FLAG_CYLINDERS = 1u << 0, /* run cylinder RANSAC on low-score regions (primitive_detection.cpp:385-388);
                                       cleared = "plane-only" mode of BASELINE.json configs[0..1] */
+    CAPE_FLAG_ASYNC_SECOND_PASS = 1u << 1, /* batches with cylinders: the second pass of stage B (the frames that reach a cylinder
+                                      candidate; it lasts as long as its slowest frame) runs on a stream of the handle's own and
+                                      cape_extract's caller stream does NOT wait for it.  Every later entry point on the handle
+                                      (the next cape_extract, cape_copy_results, cape_pack_primitives, ...) orders itself behind
+                                      it; a consumer of the raw cape_device_results pointers calls cape_sync_results first.
+                                      Meant for TWO handles fed alternately: one's streaming kernels run under the other's tail */
 };
 
 /* per-frame status bits (cape_frame_header.status) */
@@ -402,6 +408,10 @@ int cape_count_primitives(cape_handle h, int32_t n_frames, int32_t* n_planes, in
 /* Orders after the last cape_gather_primitives: with host_sync != 0 the call returns when the gather has landed,
  * otherwise `stream` is made to wait for it (hipStreamWaitEvent). */
 int cape_gather_wait(cape_handle h, void* stream, int32_t host_sync);
+
+/* Makes `stream` wait for whatever the handle still has in flight for the last cape_extract (the asynchronous second pass of
+ * CAPE_FLAG_ASYNC_SECOND_PASS; a no-op otherwise): after it, work enqueued on `stream` may read cape_device_results. */
+int cape_sync_results(cape_handle h, void* stream);
 
 /* Synchronous D2H of the results of the last cape_extract.  Any pointer may be NULL. */
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,

@@ -20,7 +20,8 @@ namespace cape {
 hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
-hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side = nullptr, hipEvent_t fork = nullptr,
+                       hipEvent_t done = nullptr);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 size_t grow_state_bytes(int cells);
 bool resume_group_fits(const StageBParams& p);
@@ -189,6 +190,11 @@ struct cape_handle_s
     hipStream_t lastStream = nullptr;
     bool hasLastStream = false;
     int scopeDepth = 0;             // nesting of entry points (StreamScope)
+    // CAPE_FLAG_ASYNC_SECOND_PASS: the cylinder second pass runs on the handle's own stream; whoever touches the handle next
+    // (any entry point, cape_destroy) first waits for sideDone
+    hipStream_t sideStream = nullptr;
+    hipEvent_t sideFork = nullptr, sideDone = nullptr;
+    bool sidePending = false;
     hipEvent_t workDone = nullptr;  // recorded behind the last enqueued work of this handle
     bool workRecorded = false;
     // multi-GPU gather: two packed staging slots, the RCCL communicator and its stream
@@ -330,6 +336,12 @@ void free_all(cape_handle_s* h)
         (void)hipEventDestroy(h->pipeFork);
     if (h->workDone)
         (void)hipEventDestroy(h->workDone);
+    if (h->sideStream)
+        (void)hipStreamDestroy(h->sideStream);
+    if (h->sideFork)
+        (void)hipEventDestroy(h->sideFork);
+    if (h->sideDone)
+        (void)hipEventDestroy(h->sideDone);
     for (auto& e : h->pipeJoin)
         if (e)
             (void)hipEventDestroy(e);
@@ -421,12 +433,25 @@ int enter_stream(cape_handle_s* h, hipStream_t st)
     h->hasLastStream = true;
     if (other && h->workRecorded)
         CAPE_HIP_TRY(hipStreamWaitEvent(st, h->workDone, 0));
+    if (h->sidePending)
+    {
+        // the previous call's second pass is still on the handle's side stream: this call (and the caller's stream from here
+        // on) is ordered behind it
+        CAPE_HIP_TRY(hipStreamWaitEvent(st, h->sideDone, 0));
+        h->sidePending = false;
+    }
     return CAPE_OK;
 }
 
 // everything this handle has enqueued so far is done (host side)
 hipError_t drain_handle(cape_handle_s* h)
 {
+    if (h->sidePending)
+    {
+        if (const hipError_t e = hipEventSynchronize(h->sideDone); e != hipSuccess)
+            return e;
+        h->sidePending = false;
+    }
     if (h->workRecorded)
         return hipEventSynchronize(h->workDone);
     return hipSuccess;
@@ -518,7 +543,9 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         if (probe)
             h->callsSinceProbe = 0;
     }
-    CAPE_HIP_TRY(cape::launch_grow(bb, frames, st));
+    CAPE_HIP_TRY(cape::launch_grow(bb, frames, st, h->sideStream, h->sideFork, h->sideDone));
+    if (h->sideStream && bb.needCylinder)
+        h->sidePending = true;
     if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0)
     {
         CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost, bb.needCylinder, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -528,7 +555,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         h->handedOverFrames = frames;
     }
     if (t)
-        CAPE_HIP_TRY(hipEventRecord(t->e[3], st));
+        CAPE_HIP_TRY(hipEventRecord(t->e[3], h->sidePending ? h->sideStream : st));
     if (h->resultsOnHost && h->doneFlag)
     {
         hipLaunchKernelGGL(cape_signal_kernel, dim3(1), dim3(1), 0, st, h->doneFlag, ++h->doneSeq);
@@ -689,6 +716,13 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     }
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
     CAPE_ALLOC(hipEventCreateWithFlags(&h->workDone, hipEventDisableTiming));
+    if ((cfg->flags & CAPE_FLAG_ASYNC_SECOND_PASS) && (cfg->flags & CAPE_FLAG_CYLINDERS) && cfg->max_batch > kHostResultFrames &&
+        cfg->sub_batches <= 1)
+    {
+        CAPE_ALLOC(hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking));
+        CAPE_ALLOC(hipEventCreateWithFlags(&h->sideFork, hipEventDisableTiming));
+        CAPE_ALLOC(hipEventCreateWithFlags(&h->sideDone, hipEventDisableTiming));
+    }
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
     h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
@@ -1042,6 +1076,15 @@ int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, i
     if (boundary)
         *boundary = h->boundary;
     return CAPE_OK;
+}
+
+int cape_sync_results(cape_handle h, void* stream_)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    CAPE_ON_DEVICE(h);
+    StreamScope streamScope(h, static_cast<hipStream_t>(stream_)); // enter_stream does the waiting
+    return streamScope.rc();
 }
 
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,

@@ -841,9 +841,15 @@ hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t s
 // frames from the start (densely packed: a workgroup of the cylinder kernel owns 60 % of a CU's LDS, so idle waves in
 // it would cost real occupancy).  A frame that never
 // takes the branch is bit-identical in both kernels (the branch is their only difference).
-hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
+// `side` (optional): the SECOND pass -- everything behind the plane-only kernel, or the cylinder kernel alone -- is enqueued on
+// this stream, forked from `stream` through `fork` and closed by `done`; `stream` itself does not wait for it (the caller of
+// the next entry point on this handle does).  A second handle's streaming kernels then run under this one's slow tail.
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done)
 {
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    if (!cyl)
+        side = nullptr;
+    hipStream_t second = side ? side : stream;
 #define CAPE_LAUNCH_TRY(expr)              \
     do                                     \
     {                                      \
@@ -863,7 +869,12 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
     }
     if (!p.twoPass)
     {
-        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream))); // nearly every frame needs it anyway: skip the plane-only pass
+        if (side)
+        {
+            CAPE_LAUNCH_TRY(hipEventRecord(fork, stream));
+            CAPE_LAUNCH_TRY(hipStreamWaitEvent(side, fork, 0));
+        }
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, second))); // nearly every frame needs it anyway: skip the plane-only pass
     }
     else
     {
@@ -872,14 +883,21 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream)
         if (p.resumeList && !p.countersCleared)
             CAPE_LAUNCH_TRY(hipMemsetAsync(p.resumeList, 0, sizeof(uint32_t), stream));
         CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
+        if (side)
+        {
+            CAPE_LAUNCH_TRY(hipEventRecord(fork, stream));
+            CAPE_LAUNCH_TRY(hipStreamWaitEvent(side, fork, 0));
+        }
         if (p.resumeList && p.resumeMode == 2)
-            CAPE_LAUNCH_TRY(launch_resume_group(p, nFrames, stream)); // frames parked with their state: one workgroup each
+            CAPE_LAUNCH_TRY(launch_resume_group(p, nFrames, second)); // frames parked with their state: one workgroup each
         else if (p.resumeList)
-            CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes, true>(p, nFrames, stream))); // ... or one wavefront each
-        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, stream)));           // frames that start over (rare once parking is on)
+            CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes, true>(p, nFrames, second))); // ... or one wavefront each
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, kFastPlanes>(p, nFrames, second)));           // frames that start over (rare once parking is on)
     }
     if (p.redoList)
-        CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));
+        CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, second)));
+    if (side)
+        CAPE_LAUNCH_TRY(hipEventRecord(done, side));
     return hipSuccess;
 #undef CAPE_LAUNCH_TRY
 }

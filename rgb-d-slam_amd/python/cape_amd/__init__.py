@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("CAPE_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libc
 CAPE_MAX_PLANES = 64
 CAPE_MAX_CYLINDERS = 64
 CAPE_FLAG_CYLINDERS = 1
+CAPE_FLAG_ASYNC_SECOND_PASS = 2
 
 FRAME_PLANE_OVERFLOW = 1 << 0
 FRAME_BOUNDARY_OVERFLOW = 1 << 1
@@ -114,7 +115,7 @@ CELL_STATS_DTYPE = np.dtype([
 EXPORTED_SYMBOLS = [
     "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
-    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
+    "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_sync_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
@@ -153,6 +154,7 @@ def load_library():
     L.cape_rectify_depth.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    L.cape_sync_results.argtypes = [vp, vp]
     L.cape_host_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.cape_host_free.argtypes = [vp, vp]
@@ -219,10 +221,10 @@ class Extractor:
     """Thin owner of a cape_handle (mirrors the ctor pair of reference src/rgbd_slam.cpp:48-57)."""
 
     def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=False, device=0,
-                 max_batch=64, boundary_capacity=0, sub_batches=0):
+                 max_batch=64, boundary_capacity=0, sub_batches=0, async_second_pass=False):
         self.L = load_library()
-        cfg = cape_config(width, height, fx, fy, cx, cy, CAPE_FLAG_CYLINDERS if cylinders else 0, device, max_batch,
-                          boundary_capacity, sub_batches)
+        flags = (CAPE_FLAG_CYLINDERS if cylinders else 0) | (CAPE_FLAG_ASYNC_SECOND_PASS if async_second_pass else 0)
+        cfg = cape_config(width, height, fx, fy, cx, cy, flags, device, max_batch, boundary_capacity, sub_batches)
         self.h = C.c_void_p()
         _check(self.L, self.L.cape_create(C.byref(cfg), C.byref(self.h)), "cape_create")
         lay = cape_layout()
@@ -295,6 +297,10 @@ class Extractor:
         _check(self.L, self.L.cape_device_results(self.h, C.byref(rec), C.byref(pl), C.byref(cl), C.byref(bd)),
                "cape_device_results")
         return rec.value, pl.value, cl.value, bd.value
+
+    def sync_results(self, stream=0):
+        """Order `stream` behind the handle's asynchronous second pass (CAPE_FLAG_ASYNC_SECOND_PASS); no-op otherwise."""
+        _check(self.L, self.L.cape_sync_results(self.h, C.c_void_p(stream)), "cape_sync_results")
 
     def results(self, n_frames, with_boundary=True):
         rec = np.zeros(n_frames, FRAME_RECORD_DTYPE)

@@ -651,6 +651,46 @@ def test_cylinder_resume_modes(oracle_mod, monkeypatch, mode, w, h, n):
             assert cyl_frames >= n // 2, "the tunnel stream must exercise cylinder_fitting"
 
 
+def test_async_second_pass_two_handles(oracle_mod):
+    """CAPE_FLAG_ASYNC_SECOND_PASS: the cylinder second pass runs on a stream of the handle's own and the caller's stream
+    does not wait for it; two handles fed alternately overlap one batch's streaming kernels with the other's slow tail.
+    Whatever touches a handle next (the next extract, a results copy, the packing, the polygon pass) must find the
+    second pass done: results bit-exact for both handles, call after call."""
+    import torch
+    from cape_amd import Extractor, synth_gpu
+
+    n = 96
+    intr = _intr("room")
+    st = torch.cuda.current_stream().cuda_stream
+    streams = {sc: synth_gpu.stream(sc, 71, n, start=10, device="cuda", chunk=32) for sc in ("room", "tunnel")}
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    want = {sc: [orc.run(fr) for fr in streams[sc][::8].cpu().numpy()] for sc in streams}
+    pair = [Extractor(640, 480, cylinders=True, max_batch=n, async_second_pass=True, **intr) for _ in range(2)]
+    order = ["room", "tunnel", "tunnel", "room", "room", "tunnel"]
+    last = [None, None]
+    for i, sc in enumerate(order):
+        pair[i & 1].extract_device(streams[sc].data_ptr(), n, st)   # returns while the previous handle's tail is still running
+        last[i & 1] = sc
+        if i == 3:
+            pair[1].build_polygons(n, st)                            # an entry point right behind an asynchronous second pass
+    for k, ex in enumerate(pair):
+        res = ex.results(n)
+        for j, f in enumerate(range(0, n, 8)):
+            compare_frame(want[last[k]][j], ex, res, f, check_cells=False)
+    # raw device pointers: cape_sync_results orders a consumer stream behind the second pass
+    pair[0].extract_device(streams["room"].data_ptr(), n, st)
+    pair[0].sync_results(st)
+    rec_ptr, pl_ptr, _, _ = pair[0].device_pointers()
+    lab = torch.empty(n * pair[0].cells, dtype=torch.int32, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpyAsync(ctypes.c_void_p(lab.data_ptr()), ctypes.c_void_p(pl_ptr), ctypes.c_size_t(lab.numel() * 4), 3, ctypes.c_void_p(st)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(lab.cpu().numpy().reshape(n, -1)[0], want["room"][0].plane_labels)
+    for ex in pair:
+        ex.close()
+
+
 @pytest.mark.parametrize("cyl", [False, True])
 def test_sub_batch_pipeline_matches_single_chain(oracle_mod, cyl):
     """cape_config.sub_batches > 1 cuts a batch into sub-batches that alternate between two internal streams; results
