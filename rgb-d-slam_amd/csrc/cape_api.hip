@@ -214,7 +214,8 @@ struct cape_handle_s
     // N1 on the device: polygons of the last batch (allocated on first use)
     cape_polygon* polygons = nullptr;
     double* polyVertices = nullptr;
-    uint32_t* polyLadder = nullptr; // planes deferred to the ladder kernel
+    uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
+    int computeUnits = 0;           // CUs of the handle's device (queried on first use)
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
     cape::StageBParams pb{};
@@ -1701,13 +1702,20 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
         }
     }
     if (!h->polyLadder)
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), (B * CAPE_MAX_PLANES + 1) * sizeof(uint32_t)));
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), 3 * (B * CAPE_MAX_PLANES + 1) * sizeof(uint32_t)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
     cape::PolygonParams p;
-    p.ladderList = h->polyLadder;
+    p.lists = h->polyLadder;
+    p.listStride = (uint32_t)(B * CAPE_MAX_PLANES + 1);
+    if (h->computeUnits <= 0)
+    {
+        hipDeviceProp_t prop;
+        h->computeUnits = hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    p.computeUnits = h->computeUnits;
     p.records = h->records;
     p.boundary = h->boundary;
     p.polygons = h->polygons;
@@ -1790,7 +1798,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         step(hipMalloc(reinterpret_cast<void**>(&bnd), cap * 3 * sizeof(double)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&poly), CAPE_MAX_PLANES * sizeof(cape_polygon)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&verts), cap * 2 * sizeof(double)), "hipMalloc") &&
-        step(hipMalloc(reinterpret_cast<void**>(&ladder), (CAPE_MAX_PLANES + 1) * sizeof(uint32_t)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&ladder), 3 * (CAPE_MAX_PLANES + 1) * sizeof(uint32_t)), "hipMalloc") &&
         step(hipMemcpy(rec, hostRec, sizeof(cape_frame_record), hipMemcpyHostToDevice), "hipMemcpy") &&
         step(n ? hipMemcpy(bnd, points3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice) : hipSuccess, "hipMemcpy"))
     {
@@ -1801,7 +1809,9 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         p.vertices = reinterpret_cast<double2*>(verts);
         p.boundaryCapacity = h->boundaryCap;
         p.prof = nullptr;
-        p.ladderList = ladder;
+        p.lists = ladder;
+        p.listStride = CAPE_MAX_PLANES + 1;
+        p.computeUnits = 4;
         if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
             step(hipMemcpy(polygon_out, poly, sizeof(cape_polygon), hipMemcpyDeviceToHost), "hipMemcpy"))
         {

@@ -163,7 +163,6 @@ struct PackParams
 
 // N1 on the device: boundary polygons (cape_polygon.hip)
 constexpr int kPolyMaxPoints = 1024; // boundary candidates of one plane the device hull takes (more: CAPE_POLY_OVERFLOW, host class)
-constexpr int kPolySlots = 8;        // wavefronts per frame: wave s builds the polygons of the frame's planes s, s + 8, ...
 struct PolygonParams
 {
     const cape_frame_record* records;
@@ -171,7 +170,9 @@ struct PolygonParams
     cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
     double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
     int boundaryCapacity;
-    uint32_t* ladderList;     // [0] count, [1..] (frame << 8 | segment) of the planes whose first hull rung failed (frames x 64 + 1)
+    uint32_t* lists;          // three work lists of listStride words: [0] count, [1..] (frame << 8 | segment) -- planes of up to
+    uint32_t listStride;      // 256 candidates, planes whose first hull rung failed, planes of 257 .. 1 024 candidates
+    int computeUnits;
     unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
 

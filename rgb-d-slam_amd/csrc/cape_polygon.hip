@@ -22,22 +22,23 @@
 #include "cape_internal.h"
 #include "cape_wave.h"
 
+#include <algorithm>
+
 namespace cape {
 
 constexpr int kPolyWavesPerGroup = 4;
 // Two instances: planes of up to kPolySmallPoints boundary candidates (every plane of the 640x480 test streams: at most 175)
-// are built by waves that hold 7 KB of LDS each, twenty to a CU; a plane with more is DEFERRED to the kPolyMaxPoints
+// are built by waves that hold 7 KB of LDS each, twenty to a CU; a plane with more goes to the kPolyMaxPoints
 // instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
 constexpr int kPolySmallPoints = 256;
-constexpr uint32_t kPolyDeferred = 1u << 31; // internal: left by the small instance for the large one, never returned
 // The k ladder.  Nearly every plane gets its hull on the first rung (1.13 attempts on average), but a plane that climbs to
 // k = 21 spends ~3 ms in one wave, and a kernel lasts as long as its slowest wave (4.2 ms per 4 096 room frames, one plane in
-// a thousand).  So the small instance runs the FIRST rung only and defers a plane that fails it (kPolyDeferredLadder) to the
-// ladder kernel: a workgroup of six waves per such plane, wave w on rung w + 2 (k = 5, 7, 11, 13, 17, 21), all at once; the
+// a thousand).  So the small instance runs the FIRST rung only and defers a plane that fails it (work list 1) to the
+// ladder kernel: a workgroup of three waves per such plane, wave w on rung w + 2 (k = 5, 7, 11) all at once, then -- if none has
+// a hull -- on rung w + 5 (k = 13, 17, 21); the
 // lowest rung that yields a simple hull wins, exactly as if they had run one after the other (a run is a pure function of
 // the points and k).
-constexpr uint32_t kPolyDeferredLadder = 1u << 30;
-constexpr int kLadderWaves = 6;
+constexpr int kLadderWaves = 3;
 enum PolyMode
 {
     kPolyFirstRung = 0, // small instance: rung 0, defer on failure
@@ -425,35 +426,23 @@ __device__ inline void sort_points(const PolyLds& L, int n, int lane)
 }
 
 template <int CAP, int MODE>
-__global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup), MODE == kPolyLadder ? 2 : 4) void cape_polygon_kernel(
+__global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup), MODE == kPolyLadder ? 3 : 4) void cape_polygon_kernel(
         PolygonParams p, int nFrames, int ldsPerWave)
 {
     constexpr int kPolyPerLane = CAP / 64;
-    constexpr bool kSecondPass = MODE != kPolyFirstRung;
     constexpr int kWaves = MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (frame, slot): slot s of a frame = planes s, s + kPolySlots, ... ; one wave per task.  The ladder kernel walks the list
-    // of deferred planes instead, one WORKGROUP per entry, a fixed number of workgroups striding over it.
+    // Work comes as lists of (frame << 8 | segment) written on the device: list 0 = the output planes of up to 256 boundary
+    // candidates (cape_polygon_list_kernel), list 1 = planes whose first rung failed (written by the first-rung instance),
+    // list 2 = planes of 257 .. 1 024 candidates.  A fixed grid strides over its list -- one WAVE per entry, or one WORKGROUP
+    // per entry in the ladder kernel -- so every resident wave has a plane (the first version launched eight waves per frame
+    // for ~2.5 planes: two thirds of the resident waves had nothing to do).
     int* s_ok = reinterpret_cast<int*>(smem_all + (size_t)kWaves * ldsPerWave); // ladder kernel: verdict of every rung
-    const unsigned nDeferred = MODE == kPolyLadder ? p.ladderList[0] : 1u;
-  for (unsigned entryNo = MODE == kPolyLadder ? blockIdx.x : 0u; entryNo < nDeferred; entryNo += MODE == kPolyLadder ? gridDim.x : 1u)
-  {
-    int frame, slot = 0, onlySeg = -1;
-    if (MODE == kPolyLadder)
-    {
-        const unsigned e = p.ladderList[1 + entryNo];
-        frame = (int)(e >> 8);
-        onlySeg = (int)(e & 255u);
-    }
-    else
-    {
-        const int task = (int)blockIdx.x * kPolyWavesPerGroup + wave;
-        frame = task / kPolySlots;
-        slot = task - frame * kPolySlots;
-        if (frame >= nFrames)
-            return;
-    }
+    const uint32_t* list = p.lists + (size_t)MODE * p.listStride;
+    const unsigned nEntries = list[0];
+    const unsigned firstEntry = MODE == kPolyLadder ? blockIdx.x : blockIdx.x * kWaves + wave;
+    const unsigned entryStride = MODE == kPolyLadder ? gridDim.x : gridDim.x * kWaves;
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
@@ -462,28 +451,11 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
     L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2);
     L.used = reinterpret_cast<unsigned char*>(L.stack + CAP);
     L.keep = L.used + CAP;
-
-    const cape_frame_record& rec = p.records[frame];
-    const int nSeg = rec.header.n_plane_segments;
-    // the slot's planes: the s-th, (s + kPolySlots)-th, ... segment with is_output (lane j looks at segment j)
-    const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
-    const unsigned long long outMask = MODE == kPolyLadder ? (1ull << onlySeg) : __ballot(isOut);
-    // segments that are not planes carry an empty polygon record
-    if (!kSecondPass && slot == 0 && lane < CAPE_MAX_PLANES && !isOut)
+    for (unsigned entryNo = firstEntry; entryNo < nEntries; entryNo += entryStride)
     {
-        cape_polygon* o = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + lane];
-        o->vertex_count = 0;
-        o->flags = 0;
-        o->segment = (uint32_t)lane;
-        o->area = 0.0;
-    }
-    int ordinal = 0;
-    for (unsigned long long m = outMask; m; m &= m - 1, ++ordinal)
-    {
-        if (MODE != kPolyLadder && ordinal % kPolySlots != slot)
-            continue;
-        const int seg = __ffsll((long long)m) - 1;
-        const cape_plane_segment& S = rec.segments[seg];
+        const unsigned entry = list[1 + entryNo];
+        const int frame = (int)(entry >> 8), seg = (int)(entry & 255u);
+        const cape_plane_segment& S = p.records[frame].segments[seg];
         cape_polygon* out = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + seg];
         double2* vout = p.vertices + (size_t)frame * p.boundaryCapacity + S.boundary_offset;
         const int nPts = (int)S.boundary_count;
@@ -491,16 +463,6 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
 #ifdef CAPE_POLY_PROFILE
         unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #endif
-        if (MODE == kPolyFull && !(out->flags & kPolyDeferred))
-            continue; // built by the small instance
-        if (MODE == kPolyLadder && !(out->flags & kPolyDeferredLadder))
-            continue; // got its hull on the first rung (the verdict is the same for all six waves: uniform)
-        if (MODE == kPolyFirstRung && nPts > CAP && nPts <= kPolyMaxPoints)
-        {
-            if (lane == 0)
-                out->flags = kPolyDeferred;
-            continue;
-        }
         // ---- plane frame: get_plane_coordinate_system (polygon.cpp:74-115 with select_correct_transform :50-68)
         const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
         const double cx = S.centroid[0], cy = S.centroid[1], cz = S.centroid[2];
@@ -578,17 +540,40 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
             // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
             int hs = 0;
             bool haveRing = false;
-            if (MODE == kPolyLadder)
+            if (n >= 3 && MODE == kPolyLadder)
             {
-                if (threadIdx.x == 0)
-                    s_ok[8] = kLadderWaves; // no rung has a hull yet
-                __syncthreads();
+                // rungs 2, 3, 4 (k = 5, 7, 11) at once, one per wave; if none has a hull, rungs 5, 6, 7 (k = 13, 17, 21).  The
+                // lowest rung with a simple hull wins and finishes the polygon -- a higher rung gives up as soon as it sees a
+                // lower one succeed -- and if none has one, wave 0 takes the convex fallback (every wave holds the same points).
+                const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
+                int winner = -1;
+                for (int stage = 0; stage < 2 && winner < 0; ++stage)
+                {
+                    if (threadIdx.x == 0)
+                        s_ok[8] = kLadderWaves; // no rung of this stage has a hull yet
+                    __syncthreads();
+                    const int k = ladder[2 + stage * kLadderWaves + wave];
+                    CAPE_PCOUNT(8, 1); // hull attempts
+                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs, s_ok + 8, wave);
+                    CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
+                    haveRing = hullOk && ring_is_simple(L.pts, L.hull, hs, lane);
+                    if (haveRing && lane == 0)
+                        atomicMin(s_ok + 8, wave);
+                    CAPE_PTICK(2); // simple-ring test of a hull
+                    __syncthreads();
+                    winner = s_ok[8] < kLadderWaves ? s_ok[8] : -1;
+                    __syncthreads(); // the word is reset for the next stage / the next plane
+                }
+                if (wave != (winner < 0 ? 0 : winner))
+                    continue;
+                if (winner < 0)
+                    haveRing = false;
             }
-            if (n >= 3)
+            else if (n >= 3)
             {
                 const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
-                const int aFirst = MODE == kPolyLadder ? 2 + wave : 0, aLast = MODE == kPolyFull ? 7 : aFirst;
-                for (int a = aFirst; a <= aLast && !haveRing; ++a)
+                const int aLast = MODE == kPolyFull ? 7 : 0;
+                for (int a = 0; a <= aLast && !haveRing; ++a)
                 {
                     const int k = ladder[a];
                     // (the ladder's second rung repeats the first: the run is a pure function of the points and k, so a
@@ -596,14 +581,10 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     if (a == 1)
                         continue;
                     CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs, MODE == kPolyLadder ? s_ok + 8 : nullptr, wave);
+                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs);
                     CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
                     if (hullOk && ring_is_simple(L.pts, L.hull, hs, lane))
-                    {
                         haveRing = true;
-                        if (MODE == kPolyLadder && lane == 0)
-                            atomicMin(s_ok + 8, wave);
-                    }
                     CAPE_PTICK(2); // simple-ring test of a hull
                     if (!haveRing && k > n)
                         break;
@@ -613,26 +594,11 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     // the first rung failed: the ladder kernel takes the plane
                     if (lane == 0)
                     {
-                        out->flags = kPolyDeferredLadder;
-                        p.ladderList[1 + atomicAdd(&p.ladderList[0], 1u)] = ((unsigned)frame << 8) | (unsigned)seg;
+                        uint32_t* ladderList = p.lists + (size_t)kPolyLadder * p.listStride;
+                        ladderList[1 + atomicAdd(&ladderList[0], 1u)] = entry;
                     }
                     continue;
                 }
-            }
-            if (MODE == kPolyLadder)
-            {
-                // the lowest rung with a simple hull wins and finishes the polygon; if none has one, wave 0 takes the convex
-                // fallback (every wave holds the same sorted points)
-                if (lane == 0)
-                    s_ok[wave] = haveRing ? 1 : 0;
-                __syncthreads();
-                int winner = -1;
-                for (int w = kLadderWaves - 1; w >= 0; --w)
-                    if (s_ok[w])
-                        winner = w;
-                __syncthreads(); // s_ok is rewritten for the next deferred plane of this slot
-                if (wave != (winner < 0 ? 0 : winner))
-                    continue;
             }
             unsigned short* ring = L.ring;
             int rn = 0;
@@ -826,7 +792,48 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
         }
         CAPE_POLY_SYNC();
     }
-  } // entries of the ladder list (one pass for the other instances)
+}
+
+// one wavefront per frame, lane j <- segment j: the work lists of the three polygon kernels, and the records of the segments
+// that need no kernel (not an output plane: empty record)
+__global__ __launch_bounds__(256) void cape_polygon_list_kernel(PolygonParams p, int nFrames)
+{
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= nFrames)
+        return;
+    const cape_frame_record& rec = p.records[frame];
+    const bool isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
+    const int nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
+    if (!isOut)
+    {
+        cape_polygon* o = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + lane];
+        o->vertex_count = 0;
+        o->flags = 0;
+        o->segment = (uint32_t)lane;
+        o->area = 0.0;
+    }
+    // 257 .. 1 024 candidates: the large instance; everything else (incl. what it will only flag: too few / too many points)
+    // goes to the small one
+    const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
+    const bool small = isOut && !large;
+    const unsigned long long ms = __ballot(small), ml = __ballot(large);
+    unsigned baseS = 0, baseL = 0;
+    if (lane == 0)
+    {
+        if (ms)
+            baseS = atomicAdd(&p.lists[(size_t)kPolyFirstRung * p.listStride], (unsigned)__popcll(ms));
+        if (ml)
+            baseL = atomicAdd(&p.lists[(size_t)kPolyFull * p.listStride], (unsigned)__popcll(ml));
+    }
+    baseS = __shfl(baseS, 0);
+    baseL = __shfl(baseL, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned entry = ((unsigned)frame << 8) | (unsigned)lane;
+    if (small)
+        p.lists[(size_t)kPolyFirstRung * p.listStride + 1 + baseS + __popcll(ms & below)] = entry;
+    if (large)
+        p.lists[(size_t)kPolyFull * p.listStride + 1 + baseL + __popcll(ml & below)] = entry;
 }
 
 size_t polygon_lds_bytes(int cap)
@@ -840,23 +847,31 @@ size_t polygon_lds_bytes(int cap)
 
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    const int tasks = nFrames * kPolySlots;
-    if (const hipError_t e = hipMemsetAsync(p.ladderList, 0, sizeof(uint32_t), stream); e != hipSuccess)
-        return e;
-    const dim3 grid((tasks + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup), block(64 * kPolyWavesPerGroup);
-    const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
-    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyFirstRung>), grid, block, (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,
-                       nFrames, ldsSmall);
+    // the three work-list counters (list m at p.lists + m * listStride, [0] = count)
+    for (int m = 0; m < 3; ++m)
+        if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, sizeof(uint32_t), stream); e != hipSuccess)
+            return e;
+    hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + 3) / 4), dim3(256), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
-    // planes that failed the first rung: one workgroup of six waves each (a workgroup whose slot holds none leaves at once)
-    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyLadder>), dim3(tasks < 768 ? tasks : 768), dim3(64 * kLadderWaves),
+    const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
+    // fixed grids striding over their lists: enough workgroups to fill the device, never more than the list can hold
+    const int maxPlanes = nFrames * CAPE_MAX_PLANES;
+    const int gridSmall = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * 5);
+    const int gridLadder = std::min(maxPlanes, p.computeUnits * 6);
+    const int gridLarge = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits);
+    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyFirstRung>), dim3(gridSmall), dim3(64 * kPolyWavesPerGroup),
+                       (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p, nFrames, ldsSmall);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+        return e;
+    // planes that failed the first rung: one workgroup of three waves each
+    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyLadder>), dim3(gridLadder), dim3(64 * kLadderWaves),
                        (size_t)ldsSmall * kLadderWaves + 64, stream, p, nFrames, ldsSmall);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     if (p.boundaryCapacity > kPolySmallPoints) // a plane cannot hold more boundary points than the frame
-        hipLaunchKernelGGL((cape_polygon_kernel<kPolyMaxPoints, kPolyFull>), grid, block, (size_t)ldsLarge * kPolyWavesPerGroup + 64, stream, p,
-                           nFrames, ldsLarge);
+        hipLaunchKernelGGL((cape_polygon_kernel<kPolyMaxPoints, kPolyFull>), dim3(gridLarge), dim3(64 * kPolyWavesPerGroup),
+                           (size_t)ldsLarge * kPolyWavesPerGroup + 64, stream, p, nFrames, ldsLarge);
     return hipGetLastError();
 }
 
