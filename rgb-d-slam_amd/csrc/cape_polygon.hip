@@ -546,24 +546,36 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                 // lowest rung with a simple hull wins and finishes the polygon -- a higher rung gives up as soon as it sees a
                 // lower one succeed -- and if none has one, wave 0 takes the convex fallback (every wave holds the same points).
                 const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
-                int winner = -1;
-                for (int stage = 0; stage < 2 && winner < 0; ++stage)
+                constexpr int kNoRung = 99;
+                if (threadIdx.x == 0)
+                    s_ok[8] = kNoRung; // the lowest rung that has a hull so far
+                __syncthreads();
+                // wave w walks rung w + 2 and, if that fails, rung w + 5 -- without waiting for the others; it stops as soon as a
+                // rung below its own has a hull (it can no longer win)
+                int myRung = kNoRung;
+                for (int stage = 0; stage < 2; ++stage)
                 {
-                    if (threadIdx.x == 0)
-                        s_ok[8] = kLadderWaves; // no rung of this stage has a hull yet
-                    __syncthreads();
-                    const int k = ladder[2 + stage * kLadderWaves + wave];
+                    const int rung = 2 + wave + kLadderWaves * stage;
+                    if (__builtin_amdgcn_readfirstlane(*(volatile int*)(s_ok + 8)) < rung)
+                        break;
                     CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs, s_ok + 8, wave);
+                    const bool hullOk = concave_hull_k<CAP>(L, n, ladder[rung], lane, hs, s_ok + 8, rung);
                     CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
-                    haveRing = hullOk && ring_is_simple(L.pts, L.hull, hs, lane);
-                    if (haveRing && lane == 0)
-                        atomicMin(s_ok + 8, wave);
+                    const bool ok = hullOk && ring_is_simple(L.pts, L.hull, hs, lane);
                     CAPE_PTICK(2); // simple-ring test of a hull
-                    __syncthreads();
-                    winner = s_ok[8] < kLadderWaves ? s_ok[8] : -1;
-                    __syncthreads(); // the word is reset for the next stage / the next plane
+                    if (ok)
+                    {
+                        myRung = rung;
+                        if (lane == 0)
+                            atomicMin(s_ok + 8, rung);
+                        break;
+                    }
                 }
+                __syncthreads();
+                const int best = s_ok[8];
+                __syncthreads(); // the word is reset for the next plane
+                const int winner = best == kNoRung ? -1 : (best - 2) % kLadderWaves;
+                haveRing = winner >= 0 && myRung == best;
                 if (wave != (winner < 0 ? 0 : winner))
                     continue;
                 if (winner < 0)
