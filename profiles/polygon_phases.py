@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Boundary-polygon pass (cape_build_polygons) on a device-rendered stream: time per batch, statistics of the planes (boundary
+points, flags, vertices), the latency of small batches and -- with CAPE_POLY_PHASES=1 and a -DCAPE_POLY_PROFILE library
+(profiles/build_variant.sh polyprof -DCAPE_POLY_PROFILE; CAPE_HIP_LIB=.../libcape_polyprof.so) -- the phase ticks per plane.
+usage: polygon_phases.py [frames=1024] [scene=room]"""
 import sys, time, os
 sys.path.insert(0, "rgb-d-slam_amd/python")
 import numpy as np, torch
