@@ -366,6 +366,35 @@ int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, 
 int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const double* normal, const double* center,
                        cape_polygon* polygon_out, double* vertices_out);
 
+/* Row N2 with the reference's own area measure: the selection of MapPlane::find_matches (map_primitive.cpp:91-161) between
+ * consecutive frames on the boundary polygons of cape_build_polygons -- `detectedPolygon.inter_area(projectedPolygon)` in mm^2
+ * (map_primitive.cpp:137; the previous frame's polygon projected into the detected plane's frame, Polygon::project,
+ * polygon.cpp:338-382) divided by the detected polygon's area -- instead of the shared cells cape_match_consecutive counts.
+ * Plane indices count the planes Primitive_Detection KEEPS (output plane with a valid polygon of >= 3 vertices,
+ * primitive_detection.cpp:623-631), i.e. the indices of the reference's plane_container.  Needs cape_build_polygons of the
+ * same batch first.  The areas are bit-identical to this repo's host class (Polygon::inter_area). */
+#define CAPE_MATCH_MAX_PLANES 16
+enum
+{
+    CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, or a polygon pair beyond the
+                                           kernel's capacities (128 vertices per ring, 1 024 slab boundaries, 8 edges of a
+                                           ring over one slab): no match is reported for the frame -- use the host class */
+};
+typedef struct cape_frame_match_exact
+{
+    int32_t n_prev, n_cur;                    /* kept planes of frame f-1 / f */
+    int32_t match[CAPE_MATCH_MAX_PLANES];     /* per previous plane j: matched plane of this frame, or -1 */
+    int32_t seg_prev[CAPE_MATCH_MAX_PLANES];  /* segment index of previous plane j (-1 beyond n_prev) */
+    int32_t seg_cur[CAPE_MATCH_MAX_PLANES];
+    uint32_t flags;                           /* CAPE_MATCH_EXACT_* */
+    uint32_t pad;
+    double inter_area[CAPE_MATCH_MAX_PLANES][CAPE_MATCH_MAX_PLANES]; /* [j][i] mm^2 ; -1 where the distance / normal gates
+                                                 failed (the reference does not intersect those), NaN: capacity exceeded */
+} cape_frame_match_exact;
+/* flags: CAPE_MATCH_ADVANCED, CAPE_MATCH_ALLOW_INDEX0 as for cape_match_consecutive.  Asynchronous on `stream`. */
+int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* stream);
+int cape_copy_polygon_matches(cape_handle h, int32_t n_frames, cape_frame_match_exact* out);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -8,5 +8,5 @@ mkdir -p "$ROOT/rgb-d-slam_amd/lib/exp"
 cd "$ROOT/rgb-d-slam_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function \
     "$@" -shared -o ../lib/exp/libcape_$NAME.so \
-    cape_api.hip cape_cell_fit.hip cape_grow.hip cape_resume.hip cape_polygon.hip cape_debug.hip cape_rectify.hip cape_match.hip cape_gather.hip -ldl
+    cape_api.hip cape_cell_fit.hip cape_grow.hip cape_resume.hip cape_polygon.hip cape_debug.hip cape_rectify.hip cape_match.hip cape_match_polygon.hip cape_gather.hip -ldl
 echo built lib/exp/libcape_$NAME.so "$@"

@@ -29,6 +29,7 @@ hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t strea
 hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_pack(const PackParams& p, hipStream_t stream);
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipStream_t stream);
 const char* rccl_load(); // nullptr on success, else the reason
 int rccl_unique_id(RcclUniqueId* id);
 int rccl_comm_init(void** comm, int world, const RcclUniqueId& id, int rank);
@@ -215,6 +216,9 @@ struct cape_handle_s
     cape_polygon* polygons = nullptr;
     double* polyVertices = nullptr;
     uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
+    int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
+    cape_frame_match_exact* matchesExact = nullptr;
+    unsigned* matchLists = nullptr; // 2 counters (padded to 64 entries) + 2 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
@@ -263,6 +267,8 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->debugCycles);
     (void)hipFree(h->countScratch);
     (void)hipFree(h->polyLadder);
+    (void)hipFree(h->matchesExact);
+    (void)hipFree(h->matchLists);
     if (h->resultsOnHost)
     {
         if (h->polygons)
@@ -966,6 +972,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     if ((depth_dev && reinterpret_cast<uintptr_t>(depth_dev) % 16 != 0) || (depth_u16 && reinterpret_cast<uintptr_t>(depth_u16) % 8 != 0))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "depth must be aligned to four pixels (16 bytes of float32, 8 bytes of uint16)");
     h->lastFrames = n_frames;
+    h->polygonFrames = 0; // the polygons on the device belong to the previous batch
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h); // the handle's device, whatever the calling thread had current
@@ -1727,6 +1734,58 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
 #endif
     h->doneArmed = false; // the chain's completion word was written before this kernel: results are waited for the slow way
     CAPE_HIP_TRY(cape::launch_polygons(p, n_frames, stream));
+    h->polygonFrames = n_frames;
+    return CAPE_OK;
+}
+
+int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* stream_)
+{
+    if (!h || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
+    if (n_frames > h->polygonFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the frames of the last cape_build_polygons (build the polygons of the batch first)");
+    if (flags & ~(uint32_t)(CAPE_MATCH_ADVANCED | CAPE_MATCH_ALLOW_INDEX0))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "unknown match flag");
+    if (n_frames == 0)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    const size_t pairCapacity = (size_t)h->cfg.max_batch * CAPE_MATCH_MAX_PLANES * CAPE_MATCH_MAX_PLANES;
+    if (!h->matchesExact)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchesExact), (size_t)h->cfg.max_batch * sizeof(cape_frame_match_exact)));
+    if (!h->matchLists)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchLists), (64 + 2 * pairCapacity) * sizeof(unsigned)));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
+    cape::MatchPolygonParams p;
+    p.records = h->records;
+    p.polygons = h->polygons;
+    p.vertices = reinterpret_cast<const double2*>(h->polyVertices);
+    p.matches = h->matchesExact;
+    p.listCounts = h->matchLists;
+    p.pairList = h->matchLists + 64;
+    p.retryList = p.pairList + pairCapacity;
+    p.computeUnits = h->computeUnits;
+    p.boundaryCapacity = h->boundaryCap;
+    p.flags = flags;
+    p.minCosAngle = std::abs(std::cos(20.0 * M_PI / 180.0));
+    p.maxDistance = 100.0;
+    const double planeMinimalOverlap = static_cast<double>(0.4f);
+    p.minOverlap = (flags & CAPE_MATCH_ADVANCED) ? planeMinimalOverlap / 2 : planeMinimalOverlap;
+    CAPE_HIP_TRY(cape::launch_match_polygons(p, n_frames, stream));
+    return CAPE_OK;
+}
+
+int cape_copy_polygon_matches(cape_handle h, int32_t n_frames, cape_frame_match_exact* out)
+{
+    if (!h || !out || n_frames < 0 || n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!h->matchesExact)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_polygons has not run");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h));
+    CAPE_HIP_TRY(hipMemcpy(out, h->matchesExact, (size_t)n_frames * sizeof(cape_frame_match_exact), hipMemcpyDeviceToHost));
     return CAPE_OK;
 }
 

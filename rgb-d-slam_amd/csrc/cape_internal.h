@@ -145,6 +145,22 @@ struct MatchParams
     double minOverlap;      // (double)0.4f, halved for the advanced search (map_primitive.cpp:106-107)
 };
 
+// N2 with polygon areas (cape_match_polygon.hip)
+struct MatchPolygonParams
+{
+    const cape_frame_record* records;
+    const cape_polygon* polygons; // frames x CAPE_MAX_PLANES
+    const double2* vertices;      // frames x boundaryCapacity
+    cape_frame_match_exact* matches;
+    unsigned* listCounts; // [0] gated pairs, [1] pairs to retry with the deeper edge stacks
+    unsigned* pairList;   // frames x 256: (frame << 8) | (j << 4) | i
+    unsigned* retryList;  // frames x 256
+    int boundaryCapacity;
+    int computeUnits;
+    uint32_t flags;
+    double minCosAngle, maxDistance, minOverlap; // as MatchParams
+};
+
 // multi-GPU gather: device-side packing of the ragged primitive lists (cape_gather.hip)
 struct PackParams
 {

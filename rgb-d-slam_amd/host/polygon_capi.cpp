@@ -40,3 +40,26 @@ extern "C" int cape_host_polygon(const double* points3, int n, const double* nor
         return 1; // the constructor threw: fewer than 3 points / normal not unit
     }
 }
+
+// Polygon::inter_area of two polygons given by their rings and frames (the public explicit-ring constructor, like the overlay
+// builds its CameraPolygons from the device's vertices): `a` is the detected polygon, `b` the projected one
+// (map_primitive.cpp:137).  tests/test_gpu_match_polygon.py compares cape_match_polygons with it bit for bit.
+extern "C" double cape_host_polygon_inter_area(const double* ring_a, int na, const double* x_a, const double* y_a, const double* c_a,
+                                               const double* ring_b, int nb, const double* x_b, const double* y_b, const double* c_b,
+                                               double* area_a_out, double* area_b_out)
+{
+    using rgbd_slam::vector2;
+    using rgbd_slam::vector3;
+    std::vector<vector2> ra, rb;
+    for (int i = 0; i < na; ++i)
+        ra.emplace_back(ring_a[2 * i], ring_a[2 * i + 1]);
+    for (int i = 0; i < nb; ++i)
+        rb.emplace_back(ring_b[2 * i], ring_b[2 * i + 1]);
+    const rgbd_slam::utils::Polygon a(ra, vector3(x_a[0], x_a[1], x_a[2]), vector3(y_a[0], y_a[1], y_a[2]), vector3(c_a[0], c_a[1], c_a[2]));
+    const rgbd_slam::utils::Polygon b(rb, vector3(x_b[0], x_b[1], x_b[2]), vector3(y_b[0], y_b[1], y_b[2]), vector3(c_b[0], c_b[1], c_b[2]));
+    if (area_a_out)
+        *area_a_out = a.get_area();
+    if (area_b_out)
+        *area_b_out = b.get_area();
+    return a.inter_area(b);
+}

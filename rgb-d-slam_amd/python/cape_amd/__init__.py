@@ -107,6 +107,14 @@ MATCH_DTYPE = np.dtype([
 MATCH_ADVANCED = 1
 MATCH_ALLOW_INDEX0 = 2
 
+MATCH_MAX_PLANES = 16
+MATCH_EXACT_DTYPE = np.dtype([
+    ("n_prev", "<i4"), ("n_cur", "<i4"), ("match", "<i4", MATCH_MAX_PLANES), ("seg_prev", "<i4", MATCH_MAX_PLANES),
+    ("seg_cur", "<i4", MATCH_MAX_PLANES), ("flags", "<u4"), ("pad", "<u4"),
+    ("inter_area", "<f8", (MATCH_MAX_PLANES, MATCH_MAX_PLANES))], align=True)
+MATCH_EXACT_OVERFLOW = 1
+assert MATCH_EXACT_DTYPE.itemsize == 8 + 3 * 64 + 8 + 8 * 256
+
 CELL_STATS_DTYPE = np.dtype([
     ("sums", "<f8", 9), ("normal", "<f8", 3), ("d", "<f8"), ("centroid", "<f8", 3), ("mse", "<f8"),
     ("score", "<f8"), ("tol", "<f4"), ("point_count", "<u4"), ("bin", "<i4"), ("planar", "<u4"),
@@ -118,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_sync_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
+    "cape_match_polygons", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
 ]
@@ -177,6 +186,8 @@ def load_library():
     L.cape_match_consecutive.argtypes = [vp, C.c_int32, C.c_uint32, vp]
     L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
     L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
+    L.cape_match_polygons.argtypes = [vp, C.c_int32, C.c_uint32, vp]
+    L.cape_copy_polygon_matches.argtypes = [vp, C.c_int32, vp]
     L.cape_build_polygons.argtypes = [vp, C.c_int32, vp]
     L.cape_device_polygons.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_polygons.argtypes = [vp, C.c_int32, vp, vp]
@@ -344,6 +355,15 @@ class Extractor:
     def matches(self, n_frames):
         out = np.zeros(n_frames, MATCH_DTYPE)
         _check(self.L, self.L.cape_copy_matches(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_copy_matches")
+        return out
+
+    # ---- N2 on the boundary polygons (exact intersection areas; needs build_polygons of the batch first) ----
+    def match_polygons(self, n_frames, flags=0, stream=0):
+        _check(self.L, self.L.cape_match_polygons(self.h, n_frames, flags, C.c_void_p(stream)), "cape_match_polygons")
+
+    def polygon_matches(self, n_frames):
+        out = np.zeros(n_frames, MATCH_EXACT_DTYPE)
+        _check(self.L, self.L.cape_copy_polygon_matches(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_copy_polygon_matches")
         return out
 
     def cell_stats(self, frame):
