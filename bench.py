@@ -585,6 +585,21 @@ def main():
         polygons_leg = {"ms_per_batch": ms, "planes": n_pl, "planes_per_s": n_pl / (ms * 1e-3), "frames_per_s": B / (ms * 1e-3),
                         "note": "cape_build_polygons over the batch's output planes; vertices bit-identical to the host class "
                                 "(tests/test_gpu_polygon.py), which builds ~80 k polygons/s on one core"}
+        # "Next" row N2 on those polygons: the reference's intersection areas between consecutive frames (cape_match_polygons)
+        ex.match_polygons(B, 0, stream)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(kp):
+            ex.match_polygons(B, 0, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        pm = ex.polygon_matches(B)
+        ms = e0.elapsed_time(e1) / kp
+        polygons_leg["match_polygons"] = {"ms_per_batch": ms, "intersected_pairs": int((pm["inter_area"] >= 0).sum()),
+                                          "matches": int((pm["match"] >= 0).sum()),
+                                          "frames_beyond_capacity": int((pm["flags"] & 1).astype(bool).sum()),
+                                          "note": "MapPlane::find_matches between consecutive frames on polygon intersection areas, "
+                                                  "bit-identical to the host class (tests/test_gpu_match_polygon.py)"}
     if gather == "native":
         ex.comm_destroy()
     ex.close()

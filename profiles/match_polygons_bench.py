@@ -51,13 +51,13 @@ if "--ticks" in sys.argv:  # a -DCAPE_MP_PROFILE library (profiles/build_variant
                     continue
                 tot, na_, nb_, nx0 = a % 1e6, (a // 1e6) % 1e3, (a // 1e9) % 1e3, a // 1e12
                 cross, sort = b % 1e6, b // 1e6
-                slabs, nx1 = c % 1e6, c // 1e6
-                rows.append((tot, na_, nb_, nx0, nx1, cross, sort, slabs))
+                slabs, nx1, tier = c % 1e6, (c // 1e6) % 1e6, c // 1e12
+                rows.append((tot, na_, nb_, nx0, nx1, cross, sort, slabs, tier))
     r = np.array(rows)
-    print("  pairs with ticks", len(r), "(100 MHz ticks: 1 tick = 10 ns)")
+    print("  pairs with ticks", len(r), "(units of 16 s_memtime ticks); last tier that ran the pair:", {int(t): int((r[:, 8] == t).sum()) for t in np.unique(r[:, 8])})
     for q in (50, 90, 99, 100):
         k = np.argsort(r[:, 0])[min(len(r) - 1, int(len(r) * q / 100))]
-        print("   p%-3d total %6d ticks: na %3d nb %3d boundaries %4d -> %4d slabs; crossings %6d sort+unique %6d slabs %6d" % (q, *r[k]))
+        print("   p%-3d total %6d ticks: na %3d nb %3d boundaries %4d -> %4d slabs; crossings %6d sort+unique %6d slabs %6d (tier %d)" % (q, *r[k]))
     print("   sum of ticks %.0f ; mean %.0f" % (r[:, 0].sum(), r[:, 0].mean()))
     sys.exit(0)
 # agreement with the cell-mask matcher (its indices count OUTPUT planes; map through the segment lists)

@@ -218,7 +218,7 @@ struct cape_handle_s
     uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
     cape_frame_match_exact* matchesExact = nullptr;
-    unsigned* matchLists = nullptr; // 2 counters (padded to 64 entries) + 2 lists of max_batch x 256 pairs
+    unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 2 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
@@ -1764,8 +1764,8 @@ int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* s
     p.vertices = reinterpret_cast<const double2*>(h->polyVertices);
     p.matches = h->matchesExact;
     p.listCounts = h->matchLists;
-    p.pairList = h->matchLists + 64;
-    p.retryList = p.pairList + pairCapacity;
+    p.pairLists = h->matchLists + 64;
+    p.pairCapacity = pairCapacity;
     p.computeUnits = h->computeUnits;
     p.boundaryCapacity = h->boundaryCap;
     p.flags = flags;

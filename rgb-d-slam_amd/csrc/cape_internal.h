@@ -152,9 +152,9 @@ struct MatchPolygonParams
     const cape_polygon* polygons; // frames x CAPE_MAX_PLANES
     const double2* vertices;      // frames x boundaryCapacity
     cape_frame_match_exact* matches;
-    unsigned* listCounts; // [0] gated pairs, [1] pairs to retry with the deeper edge stacks
-    unsigned* pairList;   // frames x 256: (frame << 8) | (j << 4) | i
-    unsigned* retryList;  // frames x 256
+    unsigned* listCounts; // pairs on the work list of each capacity tier of the intersection kernel
+    unsigned* pairLists;  // 2 lists of pairCapacity entries: (frame << 8) | (j << 4) | i
+    size_t pairCapacity;  // max_batch x 256
     int boundaryCapacity;
     int computeUnits;
     uint32_t flags;

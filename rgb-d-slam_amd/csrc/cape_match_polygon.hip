@@ -17,7 +17,6 @@
 // computed side by side, then added to the running area in order: the sum's rounding is observable).  + - x / and
 // comparisons only: the areas are compared BIT FOR BIT with the host class (tests/test_gpu_match_polygon.py).
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 
 #include "cape_internal.h"
 #include "cape_wave.h"
@@ -26,11 +25,23 @@ namespace cape {
 
 namespace {
 
-constexpr int kWaves = 2;          // independent waves per workgroup
-constexpr int kRingCap = 128;      // vertices of one ring (simplified polygons: 13 on average, 90 at most on the test streams)
-constexpr int kXsCap = 1024;       // slab boundaries: vertices of both rings + edge crossings
-constexpr int kStackCap = 8;       // edges of one ring over one slab: first attempt (register arrays)
-constexpr int kStackCapRetry = 16; // second attempt of the pairs that exceeded it (a lone wave per workgroup, 1 wave / SIMD)
+constexpr int kWaves = 2; // frames per workgroup of the gate / select kernels
+
+// Two instances of the intersection kernel, by capacity: vertices of one ring (simplified polygons: 13 on average, 90 at
+// most on the test streams), slab boundaries (vertices of both rings + edge crossings), edges of one ring over one slab,
+// independent waves per workgroup.  The capacities only size the LDS carve, i.e. how many waves a CU holds: the work is one
+// wave's dependent LDS round trips and only other waves fill the gaps.  The small instance takes ~95 % of the pairs; a pair
+// that exceeds one of its capacities moves to the large instance's work list.
+template <int TIER> struct Tier;
+template <> struct Tier<0>
+{
+    static constexpr int kRing = 32, kXs = 256, kStack = 6, kWavesPerGroup = 2, kGroupsPerCu = 4;
+};
+template <> struct Tier<1>
+{
+    static constexpr int kRing = 128, kXs = 1024, kStack = 16, kWavesPerGroup = 1, kGroupsPerCu = 2;
+};
+constexpr int kTiers = 2;
 constexpr int MP = CAPE_MATCH_MAX_PLANES;
 
 #define CAPE_MP_SYNC()                                                                                        \
@@ -48,13 +59,22 @@ struct Edge // a.x < b.x
 
 struct MpLds
 {
-    double2* ringA; // kRingCap
-    double2* ringB; // kRingCap
-    Edge* ea;       // kRingCap
-    Edge* eb;       // kRingCap
-    double* xs;     // kXsCap
-    double* terms;  // 64 x (CAP/2)^2
-    int* cand;      // 2 x kRingCap: the edges of either ring that reach into the current window of 64 slabs
+    int ringCap;
+    double2* ringA; // ringCap
+    double2* ringB; // ringCap
+    Edge* ea;       // ringCap
+    Edge* eb;       // ringCap
+    double* xs;     // the tier's kXs
+    double* terms;  // 64 x CAP (the intervals of a ring over a slab are disjoint: two sorted families of CAP/2 overlap in < CAP pairs)
+    // the edges of both rings as ONE list: ring A's at [0, nea), ring B's at [ringCap, ringCap + neb)
+    int* elo;             // 2 x ringCap: first slab an edge spans (index of a.x among the boundaries)
+    int* ehi;             // 2 x ringCap: one past the last (index of b.x)
+    int* pre;             // 2 x ringCap + 1: exclusive prefix of the edges' slab counts inside the current window
+    int* cnt;             // 2 x 64: edges over each slab of the window, per ring
+    double* by;           // 2 x 64 x CAP: their heights at the middle of the slab, in arrival order
+    unsigned short* bk;   // 2 x 64 x CAP: their edge indices
+    unsigned short* inc;  // 2 x 64 x CAP: where each (edge, slab) incidence of the window went: bucket << 8 | position
+    unsigned char* sidx;  // 2 x 64 x CAP: positions in sorted order
 };
 
 __device__ __forceinline__ double y_at(const Edge& e, double x) { return e.a.y + (e.b.y - e.a.y) * ((x - e.a.x) / (e.b.x - e.a.x)); }
@@ -128,67 +148,19 @@ __device__ inline void sort_xs(double* xs, int n, int lane)
         }
 }
 
-// indices of the edges with a.x <= whi and b.x >= wlo, ascending
-__device__ __forceinline__ int window_edges(const Edge* es, int ne, double wlo, double whi, int* out, int lane)
+// index of the value v among the sorted, distinct boundaries xs[0, n) (v is one of them)
+__device__ __forceinline__ int boundary_index(const double* xs, int n, double v)
 {
-    int cnt = 0;
-    for (int base = 0; base < ne; base += 64)
+    int lo = 0, hi = n - 1;
+    while (lo < hi)
     {
-        const int k = base + lane;
-        const bool keep = k < ne && es[k].a.x <= whi && es[k].b.x >= wlo;
-        const unsigned long long kb = __ballot(keep);
-        if (keep)
-            out[cnt + __popcll(kb & ((1ull << lane) - 1ull))] = k;
-        cnt += __popcll(kb);
+        const int mid = (lo + hi) >> 1;
+        if (xs[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
     }
-    return cnt;
-}
-
-// the stack of one ring over the slab (x0, x1): its edges that span the slab, sorted by their height at the middle -- a
-// STABLE insertion in edge order, like the insertion sort std::sort runs on so few elements.  Returns the count, or -1 if
-// more than kStackCap edges span the slab.
-template <int kStackCap>
-__device__ __forceinline__ int build_stack(const Edge* es, const int* cand, int nc, double x0, double x1, double xm, double (&sy)[kStackCap],
-                                           int (&se)[kStackCap])
-{
-    int cnt = 0;
-    for (int c = 0; c < nc; ++c)
-    {
-        const int k = cand[c];
-        const Edge e = es[k];
-        if (!(e.a.x <= x0 && e.b.x >= x1))
-            continue;
-        if (cnt == kStackCap)
-            return -1;
-        double y = y_at(e, xm);
-        int id = k;
-        // placed in front of the first strictly greater height (equal ones stay in edge order: stable), the rest shifts up
-        bool carrying = false;
-#pragma unroll
-        for (int q = 0; q < kStackCap; ++q)
-        {
-            if (q < cnt)
-            {
-                if (carrying || y < sy[q])
-                {
-                    const double ty = sy[q];
-                    const int te = se[q];
-                    sy[q] = y;
-                    se[q] = id;
-                    y = ty;
-                    id = te;
-                    carrying = true;
-                }
-            }
-            else if (q == cnt)
-            {
-                sy[q] = y;
-                se[q] = id;
-            }
-        }
-        ++cnt;
-    }
-    return cnt;
+    return lo;
 }
 
 // why a pair has no area (quiet NaNs told apart by their payload)
@@ -203,10 +175,10 @@ __device__ __forceinline__ bool is_nan_code(double v, int code) { return __doubl
 #else
 #define CAPE_MP_TICK(k)
 #endif
-template <int kStackCap>
+template <int kStackCap, int kXsCap>
 __device__ inline double rings_inter_area(const MpLds& L, int na, int nb, int lane, unsigned long long* prof = nullptr)
 {
-    constexpr int kTermsPerSlab = (kStackCap / 2) * (kStackCap / 2);
+    constexpr int kTermsPerSlab = kStackCap;
     CAPE_MP_TICK(0);
     if (na < 3 || nb < 3)
         return 0.0;
@@ -286,63 +258,146 @@ __device__ inline double rings_inter_area(const MpLds& L, int na, int nb, int la
 #ifdef CAPE_MP_PROFILE
     prof[6] = (unsigned long long)nx;
 #endif
-    // slabs, 64 at a time: lane l computes the trapezoids of slab base + l, then they are added in slab order
+    // Every boundary is a vertex abscissa or a crossing, so an edge spans exactly the slabs between the boundary at its left end
+    // and the one at its right end (`a.x <= x0 && b.x >= x1` of the host loop)
+    const int R = L.ringCap;
+    for (int k = lane; k < 2 * R; k += 64)
+    {
+        const bool isB = k >= R;
+        const int kk = isB ? k - R : k;
+        int lo = 0, hi = 0;
+        if (kk < (isB ? neb : nea))
+        {
+            const Edge e = isB ? L.eb[kk] : L.ea[kk];
+            lo = boundary_index(L.xs, nx, e.a.x);
+            hi = boundary_index(L.xs, nx, e.b.x);
+        }
+        L.elo[k] = lo;
+        L.ehi[k] = hi;
+    }
+    CAPE_MP_SYNC();
+    // slabs, 64 at a time.  The (edge, slab) incidences of the window are spread over the lanes: each computes the height of its
+    // edge at the middle of its slab and drops it into the slab's bucket; a second pass ranks every entry inside its bucket by
+    // (height, edge index) -- the order the host's stable sort by height leaves; then lane l computes the trapezoids of slab
+    // base + l from the sorted stacks and the terms are added in slab order.
     double area = 0.0;
     for (int base = 0; base + 1 < nx; base += 64)
     {
+        const int top = (base + 64 < nx - 1) ? base + 64 : nx - 1; // slabs [base, top)
+        // incidences per edge, exclusive prefix
+        int carry = 0;
+        for (int kb = 0; kb < 2 * R; kb += 64)
+        {
+            const int k = kb + lane;
+            int c = 0;
+            if (k < 2 * R)
+            {
+                const int lo = L.elo[k] > base ? L.elo[k] : base, hi = L.ehi[k] < top ? L.ehi[k] : top;
+                c = hi > lo ? hi - lo : 0;
+            }
+            const int incl = wave_scan_i32(c);
+            if (k < 2 * R)
+                L.pre[k] = carry + incl - c;
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        const int total = carry;
+        if (lane == 0)
+            L.pre[2 * R] = total;
+        for (int q = lane; q < 128; q += 64)
+            L.cnt[q] = 0;
+        CAPE_MP_SYNC();
+        if (total > 2 * 64 * kStackCap)
+            return nan_code(kNanStack); // (some bucket must overflow)
+        bool over = false;
+        for (int t = lane; t < total; t += 64)
+        {
+            // the edge of incidence t: the last k with pre[k] <= t
+            int lo = 0, hi = 2 * R;
+            while (hi - lo > 1)
+            {
+                const int mid = (lo + hi) >> 1;
+                if (L.pre[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int k = lo;
+            const bool isB = k >= R;
+            const int kk = isB ? k - R : k;
+            const int first = L.elo[k] > base ? L.elo[k] : base;
+            const int sl = first + (t - L.pre[k]) - base;
+            const Edge e = isB ? L.eb[kk] : L.ea[kk];
+            const double x0 = L.xs[base + sl], x1 = L.xs[base + sl + 1], xm = 0.5 * (x0 + x1);
+            const double y = y_at(e, xm);
+            const int bucket = (isB ? 64 : 0) + sl;
+            const int pos = atomicAdd(&L.cnt[bucket], 1);
+            if (pos < kStackCap)
+            {
+                L.by[bucket * kStackCap + pos] = y;
+                L.bk[bucket * kStackCap + pos] = (unsigned short)kk;
+                L.inc[t] = (unsigned short)((bucket << 8) | pos);
+            }
+            else
+                over = true;
+        }
+        CAPE_MP_SYNC();
+        if (__any(over))
+            return nan_code(kNanStack);
+        for (int t = lane; t < total; t += 64)
+        {
+            const int bucket = L.inc[t] >> 8, pos = L.inc[t] & 255;
+            const double y = L.by[bucket * kStackCap + pos];
+            const int kk = L.bk[bucket * kStackCap + pos];
+            const int c = L.cnt[bucket];
+            int rank = 0;
+            for (int m = 0; m < c; ++m)
+            {
+                const double y2 = L.by[bucket * kStackCap + m];
+                const int k2 = L.bk[bucket * kStackCap + m];
+                rank += (y2 < y || (y2 == y && k2 < kk)) ? 1 : 0;
+            }
+            L.sidx[bucket * kStackCap + rank] = (unsigned char)pos;
+        }
+        CAPE_MP_SYNC();
         const int s = base + lane;
         int myTerms = 0;
-        // the edges that can span a slab of this window, in edge order (a superset: the stacks test every slab themselves)
-        const int last = (base + 64 < nx - 1) ? base + 64 : nx - 1;
-        const double wlo = L.xs[base], whi = L.xs[last];
-        const int nca = window_edges(L.ea, nea, wlo, whi, L.cand, lane);
-        const int ncb = window_edges(L.eb, neb, wlo, whi, L.cand + kRingCap, lane);
-        CAPE_MP_SYNC();
-        if (s + 1 < nx)
+        if (s < top)
         {
-            const double x0 = L.xs[s], x1 = L.xs[s + 1], xm = 0.5 * (x0 + x1);
-            if (x1 > x0)
+            const double x0 = L.xs[s], x1 = L.xs[s + 1];
+            const int ca = L.cnt[lane], cb = L.cnt[64 + lane];
+            const int oa = lane * kStackCap, ob = (64 + lane) * kStackCap;
+            for (int i = 0; i + 1 < ca; i += 2)
             {
-                double ya[kStackCap], yb[kStackCap];
-                int ia[kStackCap], ib[kStackCap];
-                const int ca = build_stack<kStackCap>(L.ea, L.cand, nca, x0, x1, xm, ya, ia);
-                const int cb = build_stack<kStackCap>(L.eb, L.cand + kRingCap, ncb, x0, x1, xm, yb, ib);
-                if (ca < 0 || cb < 0)
-                    myTerms = -1;
-                else
+                const int pa0 = L.sidx[oa + i], pa1 = L.sidx[oa + i + 1];
+                const double ya0 = L.by[oa + pa0], ya1 = L.by[oa + pa1];
+                for (int j = 0; j + 1 < cb; j += 2)
                 {
-#pragma unroll
-                    for (int i = 0; i + 1 < kStackCap; i += 2)
-#pragma unroll
-                        for (int j = 0; j + 1 < kStackCap; j += 2)
-                        {
-                            if (i + 1 < ca && j + 1 < cb)
-                            {
-                                const bool loA = ya[i] > yb[j];
-                                const double loY = loA ? ya[i] : yb[j];
-                                const Edge lo = loA ? L.ea[ia[i]] : L.eb[ib[j]];
-                                const bool hiA = ya[i + 1] < yb[j + 1];
-                                const double hiY = hiA ? ya[i + 1] : yb[j + 1];
-                                const Edge hi = hiA ? L.ea[ia[i + 1]] : L.eb[ib[j + 1]];
-                                if (!(hiY <= loY))
-                                {
-                                    const double h0 = y_at(hi, x0) - y_at(lo, x0);
-                                    const double h1 = y_at(hi, x1) - y_at(lo, x1);
-                                    L.terms[lane * kTermsPerSlab + myTerms] = 0.5 * (h0 + h1) * (x1 - x0);
-                                    ++myTerms;
-                                }
-                            }
-                        }
+                    const int pb0 = L.sidx[ob + j], pb1 = L.sidx[ob + j + 1];
+                    const double yb0 = L.by[ob + pb0], yb1 = L.by[ob + pb1];
+                    const bool loA = ya0 > yb0;
+                    const double loY = loA ? ya0 : yb0;
+                    const bool hiA = ya1 < yb1;
+                    const double hiY = hiA ? ya1 : yb1;
+                    if (!(hiY <= loY))
+                    {
+                        const Edge lo = loA ? L.ea[L.bk[oa + pa0]] : L.eb[L.bk[ob + pb0]];
+                        const Edge hi = hiA ? L.ea[L.bk[oa + pa1]] : L.eb[L.bk[ob + pb1]];
+                        const double h0 = y_at(hi, x0) - y_at(lo, x0);
+                        const double h1 = y_at(hi, x1) - y_at(lo, x1);
+                        if (myTerms < kTermsPerSlab)
+                            L.terms[lane * kTermsPerSlab + myTerms] = 0.5 * (h0 + h1) * (x1 - x0);
+                        ++myTerms;
+                    }
                 }
             }
         }
         CAPE_MP_SYNC();
-        if (__any(myTerms < 0))
-            return nan_code(kNanStack);
+        if (__any(myTerms > kTermsPerSlab))
+            return nan_code(kNanStack); // (cannot happen with simple rings)
         // the ordered sum: slab by slab, term by term.  The first two terms of a slab travel through registers (a slab of two
         // convex-ish outlines has one), the rest through LDS
         const double t0 = myTerms > 0 ? L.terms[lane * kTermsPerSlab] : 0.0, t1 = myTerms > 1 ? L.terms[lane * kTermsPerSlab + 1] : 0.0;
-        const int slabs = (nx - 1 - base) < 64 ? (nx - 1 - base) : 64;
+        const int slabs = top - base;
         for (int l = 0; l < slabs; ++l)
         {
             const int c = __builtin_amdgcn_readlane(myTerms, l);
@@ -443,31 +498,40 @@ __global__ __launch_bounds__(64 * kWaves) void cape_polygon_gate_kernel(MatchPol
                 base = atomicAdd(&p.listCounts[0], (unsigned)__popcll(gb));
             base = __builtin_amdgcn_readfirstlane(base);
             if (gated)
-                p.pairList[base + __popcll(gb & ((1ull << lane) - 1ull))] = pack_pair(frame, j, i);
+                p.pairLists[base + __popcll(gb & ((1ull << lane) - 1ull))] = pack_pair(frame, j, i);
         }
     }
 }
 
-// Persistent waves over a work list of pairs.  CAP = kStackCap: the gated pairs; CAP = kStackCapRetry: the pairs the first attempt
-// left with kNanStack (it lists them).
-template <int CAP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void cape_polygon_inter_kernel(MatchPolygonParams p, int ldsPerWave)
+// Persistent waves over the work list of tier TIER.  A pair beyond this tier's capacities moves to the next tier's list when
+// that one is larger in the resource that ran out; otherwise its area stays a NaN that names the resource.
+template <int TIER>
+__global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_inter_kernel(MatchPolygonParams p, int ldsPerWave)
 {
-    constexpr bool kRetry = CAP != kStackCap;
+    using T = Tier<TIER>;
+    constexpr bool kHasNext = TIER + 1 < kTiers;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     MpLds L;
+    L.ringCap = T::kRing;
     L.ringA = reinterpret_cast<double2*>(smem);
-    L.ringB = L.ringA + kRingCap;
-    L.ea = reinterpret_cast<Edge*>(L.ringB + kRingCap);
-    L.eb = L.ea + kRingCap;
-    L.xs = reinterpret_cast<double*>(L.eb + kRingCap);
-    L.terms = L.xs + kXsCap;
-    L.cand = reinterpret_cast<int*>(L.terms + 64 * (CAP / 2) * (CAP / 2));
-    const unsigned* list = kRetry ? p.retryList : p.pairList;
-    const unsigned count = p.listCounts[kRetry ? 1 : 0];
-    for (unsigned t = blockIdx.x * WAVES + wave; t < count; t += gridDim.x * WAVES)
+    L.ringB = L.ringA + T::kRing;
+    L.ea = reinterpret_cast<Edge*>(L.ringB + T::kRing);
+    L.eb = L.ea + T::kRing;
+    L.xs = reinterpret_cast<double*>(L.eb + T::kRing);
+    L.terms = L.xs + T::kXs;
+    L.by = L.terms + 64 * T::kStack;
+    L.elo = reinterpret_cast<int*>(L.by + 128 * T::kStack);
+    L.ehi = L.elo + 2 * T::kRing;
+    L.pre = L.ehi + 2 * T::kRing;
+    L.cnt = L.pre + 2 * T::kRing + 2;
+    L.bk = reinterpret_cast<unsigned short*>(L.cnt + 128);
+    L.inc = L.bk + 128 * T::kStack;
+    L.sidx = reinterpret_cast<unsigned char*>(L.inc + 128 * T::kStack);
+    const unsigned* list = p.pairLists + (size_t)TIER * p.pairCapacity;
+    const unsigned count = p.listCounts[TIER];
+    for (unsigned t = blockIdx.x * T::kWavesPerGroup + wave; t < count; t += gridDim.x * T::kWavesPerGroup)
     {
         const unsigned pair = list[t];
         const int frame = (int)(pair >> 8), j = (int)((pair >> 4) & 15u), i = (int)(pair & 15u);
@@ -477,7 +541,7 @@ __global__ __launch_bounds__(64 * WAVES) void cape_polygon_inter_kernel(MatchPol
         const cape_polygon& PQ = p.polygons[(size_t)(frame - 1) * CAPE_MAX_PLANES + sj]; // projected polygon (identity pose)
         const int na = (int)PS.vertex_count, nb = (int)PQ.vertex_count;
         double result;
-        if (na > kRingCap || nb > kRingCap)
+        if (na > T::kRing || nb > T::kRing)
             result = nan_code(kNanRing);
         else
         {
@@ -512,24 +576,29 @@ __global__ __launch_bounds__(64 * WAVES) void cape_polygon_inter_kernel(MatchPol
 #ifdef CAPE_MP_PROFILE
             unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const unsigned long long tStart = __builtin_amdgcn_s_memtime();
-            result = rings_inter_area<CAP>(L, na, nb, lane, prof);
-            if (lane == 0 && !kRetry && i < 8 && j < 8)
+            result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane, prof);
+            if (lane == 0 && i < 8 && j < 8)
             {
                 // unused slots of the area matrix carry the ticks of this pair (profiles/match_polygons_bench.py decodes them)
-                out.inter_area[j + 8][i + 8] = (double)(prof[3] - tStart) + 1e6 * na + 1e9 * nb + 1e12 * (double)prof[5];
-                out.inter_area[j + 8][i] = (double)(prof[1] - prof[0]) + 1e6 * (double)(prof[2] - prof[1]);
-                out.inter_area[j][i + 8] = (double)(prof[3] - prof[2]) + 1e6 * (double)prof[6];
+                out.inter_area[j + 8][i + 8] = (double)((prof[3] - tStart) >> 4) + 1e6 * na + 1e9 * nb + 1e12 * (double)prof[5];
+                out.inter_area[j + 8][i] = (double)((prof[1] - prof[0]) >> 4) + 1e6 * (double)((prof[2] - prof[1]) >> 4);
+                out.inter_area[j][i + 8] = (double)((prof[3] - prof[2]) >> 4) + 1e6 * (double)prof[6] + 1e12 * TIER;
             }
 #else
-            result = rings_inter_area<CAP>(L, na, nb, lane);
+            result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane);
 #endif
             CAPE_MP_SYNC();
         }
         if (lane == 0)
         {
-            out.inter_area[j][i] = result;
-            if (!kRetry && is_nan_code(result, kNanStack))
-                p.retryList[atomicAdd(&p.listCounts[1], 1u)] = pair;
+            bool again = false;
+            if (kHasNext)
+                again = is_nan_code(result, kNanStack) || (is_nan_code(result, kNanSlabs) && Tier<kHasNext ? TIER + 1 : TIER>::kXs > T::kXs) ||
+                        (is_nan_code(result, kNanRing) && Tier<kHasNext ? TIER + 1 : TIER>::kRing > T::kRing);
+            if (again)
+                p.pairLists[(size_t)(TIER + 1) * p.pairCapacity + atomicAdd(&p.listCounts[TIER + 1], 1u)] = pair;
+            else
+                out.inter_area[j][i] = result;
         }
     }
 }
@@ -582,35 +651,38 @@ __global__ __launch_bounds__(64 * kWaves) void cape_polygon_select_kernel(MatchP
         out.match[lane] = (lane < npv && !(flags & CAPE_MATCH_EXACT_OVERFLOW)) ? myMatch : -1;
 }
 
-size_t match_polygon_lds_bytes(int cap)
+template <int TIER> static size_t tier_lds_bytes()
 {
-    size_t b = (size_t)2 * kRingCap * sizeof(double2) + (size_t)2 * kRingCap * sizeof(Edge) + (size_t)kXsCap * 8 + (size_t)64 * (cap / 2) * (cap / 2) * 8 + (size_t)2 * kRingCap * 4;
+    using T = Tier<TIER>;
+    const size_t b = (size_t)2 * T::kRing * sizeof(double2) + (size_t)2 * T::kRing * sizeof(Edge) + (size_t)T::kXs * 8 +
+                     (size_t)64 * T::kStack * 8 + (size_t)128 * T::kStack * (8 + 2 + 2 + 1) + (size_t)(6 * T::kRing + 2 + 128) * 4;
     return (b + 15) & ~(size_t)15;
+}
+
+template <int TIER> static hipError_t launch_tier(const MatchPolygonParams& p, int blocks, hipStream_t stream)
+{
+    const int lds = (int)tier_lds_bytes<TIER>();
+    hipLaunchKernelGGL(cape_polygon_inter_kernel<TIER>, dim3(blocks), dim3(64 * Tier<TIER>::kWavesPerGroup), (size_t)lds * Tier<TIER>::kWavesPerGroup, stream, p, lds);
+    return hipGetLastError();
 }
 
 hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipStream_t stream)
 {
-    const int lds = (int)match_polygon_lds_bytes(kStackCap), ldsRetry = (int)match_polygon_lds_bytes(kStackCapRetry);
-    if (const hipError_t e = hipMemsetAsync(p.listCounts, 0, 2 * sizeof(unsigned), stream); e != hipSuccess)
+    if (const hipError_t e = hipMemsetAsync(p.listCounts, 0, kTiers * sizeof(unsigned), stream); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(cape_polygon_gate_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
-    // persistent grids: as many workgroups as fit the chip at once (LDS: 2 of the first kind, 3 of the retry kind per CU)
+    // persistent grids: as many workgroups as the chip holds at once
     const int cus = p.computeUnits > 0 ? p.computeUnits : 256;
-    int blocks = cus * 2;
-    const int maxBlocks = (nFrames * MP * MP + kWaves - 1) / kWaves;
-    blocks = blocks < maxBlocks ? blocks : maxBlocks;
-    hipLaunchKernelGGL((cape_polygon_inter_kernel<kStackCap, kWaves>), dim3(blocks), dim3(64 * kWaves), (size_t)lds * kWaves, stream, p, lds);
-    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+    const int maxPairs = nFrames * MP * MP;
+    auto blocks_for = [&](int perCu, int wavesPerGroup) {
+        const int need = (maxPairs + wavesPerGroup - 1) / wavesPerGroup;
+        return need < cus * perCu ? need : cus * perCu;
+    };
+    if (const hipError_t e = launch_tier<0>(p, blocks_for(Tier<0>::kGroupsPerCu, Tier<0>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
-    {
-        const char* eb = getenv("CAPE_MP_RETRY_BLOCKS");
-        const char* el = getenv("CAPE_MP_RETRY_LDS");
-        if (!(eb && atoi(eb) == 0))
-            hipLaunchKernelGGL((cape_polygon_inter_kernel<kStackCapRetry, 1>), dim3(eb ? atoi(eb) : cus), dim3(64), (size_t)(el ? atoi(el) : ldsRetry), stream, p, ldsRetry);
-    }
-    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+    if (const hipError_t e = launch_tier<1>(p, blocks_for(Tier<1>::kGroupsPerCu, Tier<1>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(cape_polygon_select_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
     return hipGetLastError();

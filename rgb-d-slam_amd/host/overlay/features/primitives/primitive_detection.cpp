@@ -363,6 +363,36 @@ bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame
     }
 }
 
+bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<cape_frame_match_exact>& matches, bool useAdvancedSearch,
+                                                     bool allowIndexZero) noexcept
+{
+    try
+    {
+        matches.clear();
+        if (_shards.empty() || n_frames < 0 || _lastBatchShards != 1 || n_frames > _lastBatchResident || !_devicePolygons)
+        {
+            outputs::log_error("match_consecutive_polygons: needs a find_primitives_batch on ONE shard with device polygons, and at "
+                               "most the frames of its last chunk");
+            return false;
+        }
+        const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
+                               (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
+        matches.resize(n_frames);
+        if (cape_match_polygons(_shards[0].handle, n_frames, flags, nullptr) != CAPE_OK ||
+            cape_copy_polygon_matches(_shards[0].handle, n_frames, matches.data()) != CAPE_OK)
+        {
+            outputs::log_error(std::string("match_consecutive_polygons: ") + cape_last_error());
+            matches.clear();
+            return false;
+        }
+        return true;
+    }
+    catch (const std::exception&)
+    {
+        return false;
+    }
+}
+
 void Primitive_Detection::show_statistics(const double meanFrameTreatmentDuration, const uint frameCount,
                                           const bool shouldDisplayDetails) const noexcept
 {

@@ -8,7 +8,8 @@
 //   find_primitives_batch : frames are independent, so a batch is cut in contiguous blocks over every visible GPU
 //                           (one handle + one host thread per device) and the lists come back in frame
 //                           order;
-//   match_consecutive     : device pre-filter for MapPlane::find_matches.
+//   match_consecutive     : device pre-filter for MapPlane::find_matches;
+//   match_consecutive_polygons : find_matches itself between consecutive frames, on the device polygons.
 #ifndef RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
 #define RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
 
@@ -62,6 +63,15 @@ class Primitive_Detection
                            std::vector<cape_frame_match>& matches,
                            bool useAdvancedSearch = false,
                            bool allowIndexZero = false) noexcept;
+
+    // the same between the boundary polygons of the batch, with the reference's own measure (intersection area over the
+    // detected polygon's area, map_primitive.cpp:137): see cape_match_polygons.  Same residency rules; needs the device
+    // polygons of the batch (set_device_polygons(true), the default).  Plane indices are those of the plane_containers
+    // find_primitives_batch returned.
+    bool match_consecutive_polygons(int n_frames,
+                                    std::vector<cape_frame_match_exact>& matches,
+                                    bool useAdvancedSearch = false,
+                                    bool allowIndexZero = false) noexcept;
 
     [[nodiscard]] bool is_ready() const noexcept { return _single.handle != nullptr; }
 

@@ -118,6 +118,41 @@ int main(int argc, char** argv)
             std::printf("V%zu %d\n", k, same ? 1 : 0);
         }
     }
+    // N2 on the polygons: the device's find_matches between consecutive frames of a one-shard batch against find_plane_match
+    // on the containers the batch returned (same planes, same polygons, same order)
+    if (batchFrames > 0)
+    {
+        std::vector<plane_container> bp;
+        std::vector<cylinder_container> bc;
+        detector->set_shard_count(1);
+        const int n = 1 + batchFrames;
+        detector->find_primitives_batch(depth.data(), n, bp, bc);
+        std::vector<cape_frame_match_exact> pm;
+        if (!detector->match_consecutive_polygons(n, pm) || pm.size() != static_cast<size_t>(n))
+            return 8;
+        int previous = 0, mismatches = 0, matched = 0;
+        for (int f = 1; f < n; ++f)
+        {
+            if (pm[f].flags & CAPE_MATCH_EXACT_OVERFLOW)
+                continue;
+            if (pm[f].n_prev != static_cast<int>(bp[f - 1].size()) || pm[f].n_cur != static_cast<int>(bp[f].size()))
+            {
+                ++mismatches;
+                continue;
+            }
+            std::vector<bool> isMatched(bp[f].size(), false);
+            for (size_t j = 0; j < bp[f - 1].size(); ++j)
+            {
+                const int m = find_plane_match(bp[f], isMatched, bp[f - 1][j].get_parametrization(), bp[f - 1][j].get_boundary_polygon());
+                if (m >= 0)
+                    isMatched[m] = true;
+                ++previous;
+                matched += m >= 0;
+                mismatches += m != pm[f].match[j];
+            }
+        }
+        std::printf("X %d %d %d %d\n", n, previous, matched, mismatches);
+    }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
     depth_image rect;
     if (!depthOps->rectify_depth(img, rect))

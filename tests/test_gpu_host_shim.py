@@ -97,3 +97,23 @@ def test_sharded_batch_matches_oracle(oracle_mod, host_binaries, tmp_path, shard
         host = [ln[len(tag):] for ln in lines if ln.startswith(f"H{k} ")]
         assert dev == host and len(dev) > 0
         assert f"V{k} 1" in lines
+
+
+def test_polygon_matcher_equals_host_selection(host_binaries, tmp_path):
+    """Row N2 through the overlay: Primitive_Detection::match_consecutive_polygons (device, cape_match_polygons) between the
+    frames of a moving-camera batch == find_plane_match (host, MapPlane::find_matches on CameraPolygons) run on the
+    containers the same batch returned, previous plane by previous plane, matched flags carried along."""
+    from cape_amd import synth
+
+    exe = os.path.join(host_binaries, "test_shim.exe")
+    intr = synth.TUM_FR1_INTRINSICS
+    frames = np.stack([synth.SCENES["tumlike"](seed=21, frame=40 + i) for i in range(10)])
+    path = tmp_path / "stream.f32"
+    frames.tofile(path)
+    out = subprocess.run([exe, str(path), "640", "480", str(intr["fx"]), str(intr["fy"]), str(intr["cx"]), str(intr["cy"]),
+                          str(len(frames) - 1), "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    X = [int(v) for v in [ln for ln in out.stdout.splitlines() if ln.startswith("X ")][0].split()[1:]]
+    n, previous, matched, mismatches = X
+    assert n == len(frames) and previous >= 2 * (n - 1) and matched >= n - 1, X
+    assert mismatches == 0, X

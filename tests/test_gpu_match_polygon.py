@@ -114,7 +114,8 @@ def _check(ex, res, pol, ver, got, n, host_inter, flags):
     return pairs, matches
 
 
-@pytest.mark.parametrize("scene,cyl,n,flags", [("tumlike", False, 48, 0), ("tumlike", True, 24, 1), ("room", False, 32, 2), ("room", False, 16, 3)])
+@pytest.mark.parametrize("scene,cyl,n,flags", [("tumlike", False, 48, 0), ("tumlike", True, 24, 1), ("room", False, 32, 2), ("room", False, 16, 3),
+                                                  ("tumlike", False, 256, 0)])
 def test_polygon_matches_of_a_stream(host_inter, scene, cyl, n, flags):
     """A moving-camera stream: every gated pair's intersection area is bit-identical to the host class, the selection equals
     the reference's loop (including its never-returns-index-0 quirk unless ALLOW_INDEX0)."""
