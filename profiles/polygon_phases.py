@@ -56,3 +56,13 @@ if os.environ.get("CAPE_POLY_PHASES"):
     w = np.argsort(t)[-5:]
     for f in w:
         print("  frame", f, "ticks", int(t[f]), "planes", int(per[f, 11]), "attempts", int(per[f, 8]), "hull ticks", int(per[f, 1]), "points", int(per[f, 10]))
+if os.environ.get("CAPE_POLY_PHASES"):
+    lad = per[:, 12:23].sum(0)
+    nl = lad[0] + lad[2:8].sum()
+    if nl > 0:
+        print("ladder kernel: %d planes (%.1f %% of all); winning rung k=5: %d  k=7: %d  k=11: %d  k=13: %d  k=17: %d  k=21: %d  none (convex fallback): %d" % (
+            nl, 100 * nl / per[:, 11].sum(), *lad[2:8], lad[0]))
+        print("  points per ladder plane %.1f ; ticks per ladder plane (both stages, the three waves side by side) mean %.0f ; slowest plane %d ticks" % (
+            lad[8] / nl, lad[9] / nl, per[:, 22].max()))
+        sl = np.sort(per[:, 22])[::-1][:8]
+        print("  the eight slowest frames' slowest ladder plane:", [int(v) for v in sl])

@@ -550,6 +550,9 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                 if (threadIdx.x == 0)
                     s_ok[8] = kNoRung; // the lowest rung that has a hull so far
                 __syncthreads();
+#ifdef CAPE_POLY_PROFILE
+                const unsigned long long ladderStart = __builtin_amdgcn_s_memtime();
+#endif
                 // wave w walks rung w + 2 and, if that fails, rung w + 5 -- without waiting for the others; it stops as soon as a
                 // rung below its own has a hull (it can no longer win)
                 int myRung = kNoRung;
@@ -574,6 +577,18 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                 __syncthreads();
                 const int best = s_ok[8];
                 __syncthreads(); // the word is reset for the next plane
+#ifdef CAPE_POLY_PROFILE
+                if (wave == 0)
+                {
+                    // slots 12 (no rung: convex fallback), 14 .. 19 (winning rung 2 .. 7), 20 points, 21 ticks, 22 slowest plane of the frame
+                    const unsigned long long dt = __builtin_amdgcn_s_memtime() - ladderStart;
+                    CAPE_PCOUNT(12 + (best == kNoRung ? 0 : best), 1);
+                    CAPE_PCOUNT(20, n);
+                    CAPE_PCOUNT(21, dt);
+                    if (lane == 0 && p.prof)
+                        atomicMax(&p.prof[(size_t)frame * kProfileSlots + 22], dt);
+                }
+#endif
                 const int winner = best == kNoRung ? -1 : (best - 2) % kLadderWaves;
                 haveRing = winner >= 0 && myRung == best;
                 if (wave != (winner < 0 ? 0 : winner))

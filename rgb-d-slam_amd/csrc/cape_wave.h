@@ -73,10 +73,20 @@ __device__ __forceinline__ int wave_sum_i32(int vi)
     CAPE_ROW_REDUCE(unsigned, dpp_u32, op_add_u32)
     return (int)((readlane_u32(v, 0) + readlane_u32(v, 16)) + (readlane_u32(v, 32) + readlane_u32(v, 48)));
 }
+__device__ __forceinline__ unsigned op_min_u32(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    CAPE_ROW_REDUCE(unsigned, dpp_u32, op_min_u32)
+    return op_min_u32(op_min_u32(readlane_u32(v, 0), readlane_u32(v, 16)), op_min_u32(readlane_u32(v, 32), readlane_u32(v, 48)));
+}
+// lexicographic in (high word, low word): two 32-bit reductions (one v_min_u32 per DPP step) instead of one 64-bit one
+// (a 64-bit compare and two selects per step)
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-    CAPE_ROW_REDUCE(unsigned long long, dpp_u64, op_min_u64)
-    return op_min_u64(op_min_u64(readlane_u64(v, 0), readlane_u64(v, 16)), op_min_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 // sum of the 64 lanes' doubles in TREE order (not the order of any reference loop: only for quantities whose rounding is

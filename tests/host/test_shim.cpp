@@ -109,11 +109,20 @@ int main(int argc, char** argv)
             bool same = hp[k].size() == bp[k].size();
             for (size_t i = 0; same && i < hp[k].size(); ++i)
             {
-                const auto& a = hp[k][i].get_boundary_polygon().boundary();
-                const auto& b = bp[k][i].get_boundary_polygon().boundary();
+                // get_boundary_polygon() returns by value (like the reference's): keep the copies alive while their rings are read
+                const auto pa = hp[k][i].get_boundary_polygon(), pb = bp[k][i].get_boundary_polygon();
+                const auto& a = pa.boundary();
+                const auto& b = pb.boundary();
                 same = a.size() == b.size();
                 for (size_t v = 0; same && v < a.size(); ++v)
+                {
                     same = a[v][0] == b[v][0] && a[v][1] == b[v][1];
+                    if (!same)
+                        std::fprintf(stderr, "polygon vertex differs: frame %zu plane %zu vertex %zu of %zu: host %a %a device %a %a\n", k, i, v, a.size(),
+                                     a[v][0], a[v][1], b[v][0], b[v][1]);
+                }
+                if (a.size() != b.size())
+                    std::fprintf(stderr, "polygon size differs: frame %zu plane %zu: host %zu device %zu\n", k, i, a.size(), b.size());
             }
             std::printf("V%zu %d\n", k, same ? 1 : 0);
         }
