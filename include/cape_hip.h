@@ -345,7 +345,7 @@ enum
 typedef struct cape_polygon
 {
     double x_axis[3], y_axis[3]; /* get_plane_coordinate_system(segment normal) */
-    double center[3];            /* the segment's centroid */
+    double center[3];            /* Plane_Segment::get_center() = normal * (-d) (plane_coordinates.hpp:52), like primitive_detection.cpp:622 */
     double area;                 /* Polygon::_area after simplify */
     uint32_t vertex_offset;      /* first vertex in the frame's vertex array (= the segment's boundary_offset) */
     uint32_t vertex_count;

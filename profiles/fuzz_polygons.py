@@ -78,7 +78,7 @@ for scene, cyl in (("room", False), ("tumlike", False), ("tumlike", True), ("tun
                 if not s["is_output"]:
                     continue
                 p = pol[f, i]
-                ref = host_poly(res.boundary_points(f, s), s["normal"], s["centroid"])
+                ref = host_poly(res.boundary_points(f, s), s["normal"], TP._center(s))
                 o, c = int(p["vertex_offset"]), int(p["vertex_count"])
                 tot["planes"] += 1
                 tot["convex_fallbacks"] += int(bool(p["flags"] & 2))

@@ -1709,20 +1709,21 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
         }
     }
     if (!h->polyLadder)
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), 3 * (B * CAPE_MAX_PLANES + 1) * sizeof(uint32_t)));
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), 3 * (B * CAPE_MAX_PLANES + cape::kPolyListHeader) * sizeof(uint32_t)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
     cape::PolygonParams p;
     p.lists = h->polyLadder;
-    p.listStride = (uint32_t)(B * CAPE_MAX_PLANES + 1);
+    p.listStride = (uint32_t)(B * CAPE_MAX_PLANES + cape::kPolyListHeader);
     if (h->computeUnits <= 0)
     {
         hipDeviceProp_t prop;
         h->computeUnits = hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
     p.computeUnits = h->computeUnits;
+    p.originInCentroid = 0;
     p.records = h->records;
     p.boundary = h->boundary;
     p.polygons = h->polygons;
@@ -1857,7 +1858,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         step(hipMalloc(reinterpret_cast<void**>(&bnd), cap * 3 * sizeof(double)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&poly), CAPE_MAX_PLANES * sizeof(cape_polygon)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&verts), cap * 2 * sizeof(double)), "hipMalloc") &&
-        step(hipMalloc(reinterpret_cast<void**>(&ladder), 3 * (CAPE_MAX_PLANES + 1) * sizeof(uint32_t)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&ladder), 3 * (CAPE_MAX_PLANES + cape::kPolyListHeader) * sizeof(uint32_t)), "hipMalloc") &&
         step(hipMemcpy(rec, hostRec, sizeof(cape_frame_record), hipMemcpyHostToDevice), "hipMemcpy") &&
         step(n ? hipMemcpy(bnd, points3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice) : hipSuccess, "hipMemcpy"))
     {
@@ -1869,8 +1870,9 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         p.boundaryCapacity = h->boundaryCap;
         p.prof = nullptr;
         p.lists = ladder;
-        p.listStride = CAPE_MAX_PLANES + 1;
+        p.listStride = CAPE_MAX_PLANES + cape::kPolyListHeader;
         p.computeUnits = 4;
+        p.originInCentroid = 1; // an arbitrary origin, as the caller asked
         if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
             step(hipMemcpy(polygon_out, poly, sizeof(cape_polygon), hipMemcpyDeviceToHost), "hipMemcpy"))
         {

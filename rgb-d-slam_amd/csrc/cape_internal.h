@@ -178,6 +178,7 @@ struct PackParams
 };
 
 // N1 on the device: boundary polygons (cape_polygon.hip)
+constexpr int kPolyListHeader = 4; // words in front of a polygon work list: front count, back count, next entry, spare
 constexpr int kPolyMaxPoints = 1024; // boundary candidates of one plane the device hull takes (more: CAPE_POLY_OVERFLOW, host class)
 struct PolygonParams
 {
@@ -186,9 +187,10 @@ struct PolygonParams
     cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
     double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
     int boundaryCapacity;
-    uint32_t* lists;          // three work lists of listStride words: [0] count, [1..] (frame << 8 | segment) -- planes of up to
-    uint32_t listStride;      // 256 candidates, planes whose first hull rung failed, planes of 257 .. 1 024 candidates
+    uint32_t* lists;          // three work lists of listStride words: kPolyListHeader words, then (frame << 8 | segment) -- planes of
+    uint32_t listStride;      // up to 256 candidates, planes whose first hull rung failed, planes of 257 .. 1 024 candidates
     int computeUnits;
+    int originInCentroid;     // cape_debug_polygon only: the polygon's origin is read from the record's centroid field
     unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
 

@@ -39,6 +39,7 @@ constexpr int kPolySmallPoints = 256;
 // lowest rung that yields a simple hull wins, exactly as if they had run one after the other (a run is a pure function of
 // the points and k).
 constexpr int kLadderWaves = 3;
+constexpr int kPolyBigPoints = 100; // planes with at least as many boundary candidates are handed out first (longest first)
 enum PolyMode
 {
     kPolyFirstRung = 0, // small instance: rung 0, defer on failure
@@ -439,10 +440,12 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
     // per entry in the ladder kernel -- so every resident wave has a plane (the first version launched eight waves per frame
     // for ~2.5 planes: two thirds of the resident waves had nothing to do).
     int* s_ok = reinterpret_cast<int*>(smem_all + (size_t)kWaves * ldsPerWave); // ladder kernel: verdict of every rung
-    const uint32_t* list = p.lists + (size_t)MODE * p.listStride;
-    const unsigned nEntries = list[0];
-    const unsigned firstEntry = MODE == kPolyLadder ? blockIdx.x : blockIdx.x * kWaves + wave;
-    const unsigned entryStride = MODE == kPolyLadder ? gridDim.x : gridDim.x * kWaves;
+    // a list: [0] entries filled from the front (the big planes), [1] entries filled from the back, [2] the next entry to hand
+    // out, then the entries.  Waves (workgroups in the ladder kernel) take the next entry when they are done with theirs --
+    // big planes first, so that the longest walks start at once instead of at the end of somebody's queue.
+    uint32_t* list = p.lists + (size_t)MODE * p.listStride;
+    const unsigned nFront = list[0], nEntries = nFront + list[1];
+    const unsigned listCapacity = p.listStride - kPolyListHeader;
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
@@ -451,9 +454,25 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
     L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2);
     L.used = reinterpret_cast<unsigned char*>(L.stack + CAP);
     L.keep = L.used + CAP;
-    for (unsigned entryNo = firstEntry; entryNo < nEntries; entryNo += entryStride)
+    for (;;)
     {
-        const unsigned entry = list[1 + entryNo];
+        unsigned entryNo = 0;
+        if (MODE == kPolyLadder)
+        {
+            if (threadIdx.x == 0)
+                s_ok[9] = (int)atomicAdd(&list[2], 1u);
+            __syncthreads();
+            entryNo = (unsigned)s_ok[9];
+        }
+        else
+        {
+            if (lane == 0)
+                entryNo = atomicAdd(&list[2], 1u);
+            entryNo = (unsigned)__builtin_amdgcn_readfirstlane((int)entryNo);
+        }
+        if (entryNo >= nEntries)
+            break;
+        const unsigned entry = list[kPolyListHeader + (entryNo < nFront ? entryNo : listCapacity - 1 - (entryNo - nFront))];
         const int frame = (int)(entry >> 8), seg = (int)(entry & 255u);
         const cape_plane_segment& S = p.records[frame].segments[seg];
         cape_polygon* out = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + seg];
@@ -465,7 +484,10 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
 #endif
         // ---- plane frame: get_plane_coordinate_system (polygon.cpp:74-115 with select_correct_transform :50-68)
         const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
-        const double cx = S.centroid[0], cy = S.centroid[1], cz = S.centroid[2];
+        // the polygon's origin is Plane_Segment::get_center() = PlaneCoordinates::get_center() = normal * (-d), the point of the plane
+        // closest to the camera (primitive_detection.cpp:622, plane_segment.hpp:90, plane_coordinates.hpp:52) -- not the centroid
+        const double cx = p.originInCentroid ? S.centroid[0] : nx * (-S.d), cy = p.originInCentroid ? S.centroid[1] : ny * (-S.d),
+                     cz = p.originInCentroid ? S.centroid[2] : nz * (-S.d);
         double xax, xay, xaz, yax, yay, yaz;
         {
             const double distX = fabs(nx), distY = fabs(ny), distZ = fabs(nz);
@@ -622,7 +644,10 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     if (lane == 0)
                     {
                         uint32_t* ladderList = p.lists + (size_t)kPolyLadder * p.listStride;
-                        ladderList[1 + atomicAdd(&ladderList[0], 1u)] = entry;
+                        if (n >= kPolyBigPoints)
+                            ladderList[kPolyListHeader + atomicAdd(&ladderList[0], 1u)] = entry;
+                        else
+                            ladderList[kPolyListHeader + listCapacity - 1 - atomicAdd(&ladderList[1], 1u)] = entry;
                     }
                     continue;
                 }
@@ -844,23 +869,34 @@ __global__ __launch_bounds__(256) void cape_polygon_list_kernel(PolygonParams p,
     // goes to the small one
     const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
     const bool small = isOut && !large;
-    const unsigned long long ms = __ballot(small), ml = __ballot(large);
-    unsigned baseS = 0, baseL = 0;
+    // small-instance planes: the big ones from the front of the list, the others from its back (see cape_polygon_kernel)
+    const bool big = small && nPts >= kPolyBigPoints && nPts <= kPolySmallPoints;
+    const bool rest = small && !big;
+    const unsigned long long mb = __ballot(big), mr = __ballot(rest), ml = __ballot(large);
+    uint32_t* listS = p.lists + (size_t)kPolyFirstRung * p.listStride;
+    uint32_t* listL = p.lists + (size_t)kPolyFull * p.listStride;
+    const unsigned listCapacity = p.listStride - kPolyListHeader;
+    unsigned baseB = 0, baseR = 0, baseL = 0;
     if (lane == 0)
     {
-        if (ms)
-            baseS = atomicAdd(&p.lists[(size_t)kPolyFirstRung * p.listStride], (unsigned)__popcll(ms));
+        if (mb)
+            baseB = atomicAdd(&listS[0], (unsigned)__popcll(mb));
+        if (mr)
+            baseR = atomicAdd(&listS[1], (unsigned)__popcll(mr));
         if (ml)
-            baseL = atomicAdd(&p.lists[(size_t)kPolyFull * p.listStride], (unsigned)__popcll(ml));
+            baseL = atomicAdd(&listL[0], (unsigned)__popcll(ml));
     }
-    baseS = __shfl(baseS, 0);
+    baseB = __shfl(baseB, 0);
+    baseR = __shfl(baseR, 0);
     baseL = __shfl(baseL, 0);
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned entry = ((unsigned)frame << 8) | (unsigned)lane;
-    if (small)
-        p.lists[(size_t)kPolyFirstRung * p.listStride + 1 + baseS + __popcll(ms & below)] = entry;
+    if (big)
+        listS[kPolyListHeader + baseB + __popcll(mb & below)] = entry;
+    if (rest)
+        listS[kPolyListHeader + listCapacity - 1 - (baseR + __popcll(mr & below))] = entry;
     if (large)
-        p.lists[(size_t)kPolyFull * p.listStride + 1 + baseL + __popcll(ml & below)] = entry;
+        listL[kPolyListHeader + baseL + __popcll(ml & below)] = entry;
 }
 
 size_t polygon_lds_bytes(int cap)
@@ -874,9 +910,9 @@ size_t polygon_lds_bytes(int cap)
 
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    // the three work-list counters (list m at p.lists + m * listStride, [0] = count)
+    // the headers of the three work lists (list m at p.lists + m * listStride)
     for (int m = 0; m < 3; ++m)
-        if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, sizeof(uint32_t), stream); e != hipSuccess)
+        if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
             return e;
     hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + 3) / 4), dim3(256), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)

@@ -118,8 +118,15 @@ int main(int argc, char** argv)
                 {
                     same = a[v][0] == b[v][0] && a[v][1] == b[v][1];
                     if (!same)
+                    {
                         std::fprintf(stderr, "polygon vertex differs: frame %zu plane %zu vertex %zu of %zu: host %a %a device %a %a\n", k, i, v, a.size(),
                                      a[v][0], a[v][1], b[v][0], b[v][1]);
+                        for (size_t w = 0; w < a.size(); ++w)
+                            std::fprintf(stderr, "   %zu host %.3f %.3f device %.3f %.3f\n", w, a[w][0], a[w][1], b[w][0], b[w][1]);
+                        const auto ca = pa.get_center(), cb = pb.get_center(), xa = pa.get_x_axis(), xb = pb.get_x_axis();
+                        std::fprintf(stderr, "   centers %.3f %.3f %.3f | %.3f %.3f %.3f  x axes %.4f %.4f %.4f | %.4f %.4f %.4f\n", ca[0], ca[1], ca[2], cb[0], cb[1],
+                                     cb[2], xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]);
+                    }
                 }
                 if (a.size() != b.size())
                     std::fprintf(stderr, "polygon size differs: frame %zu plane %zu: host %zu device %zu\n", k, i, a.size(), b.size());

@@ -37,6 +37,12 @@ def host_poly(host_binaries):
     return run
 
 
+def _center(s):
+    """Plane_Segment::get_center() (plane_segment.hpp:90 -> plane_coordinates.hpp:52): normal * (-d), the origin the reference
+    gives its polygons (primitive_detection.cpp:622) -- NOT the centroid."""
+    return np.asarray(s["normal"], np.float64) * (-np.float64(s["d"]))
+
+
 def _bits(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 
@@ -78,11 +84,11 @@ def test_polygons_of_extracted_planes(host_poly, scene, cyl, n):
                 assert p["flags"] == 0 and p["vertex_count"] == 0
                 continue
             pts = res.boundary_points(f, s)
-            ref = host_poly(pts, s["normal"], s["centroid"])
+            ref = host_poly(pts, s["normal"], _center(s))
             o, c = int(p["vertex_offset"]), int(p["vertex_count"])
             assert o == int(s["boundary_offset"]) and p["segment"] == i
             _same(p, ver[f, o:o + c], ref, f"{scene} frame {f} segment {i} ({len(pts)} points)")
-            assert np.array_equal(_bits(p["center"]), _bits(s["centroid"]))
+            assert np.array_equal(_bits(p["center"]), _bits(_center(s)))
             planes += 1
             simplified += int(bool(p["flags"] & 4))
     assert planes >= n, "the streams show planes"
@@ -206,6 +212,6 @@ def test_polygons_1280x960_and_one_frame_handle(host_poly):
                     continue
                 big += int(len(pts) > 256)
                 o, c = int(p["vertex_offset"]), int(p["vertex_count"])
-                _same(p, ver[f, o:o + c], host_poly(pts, s["normal"], s["centroid"]), f"1280x960 frame {f} segment {i} ({len(pts)} points)")
+                _same(p, ver[f, o:o + c], host_poly(pts, s["normal"], _center(s)), f"1280x960 frame {f} segment {i} ({len(pts)} points)")
         ex.close()
     assert big > 0, "the wide grid must produce planes beyond the small instance's 256 points"
