@@ -39,6 +39,7 @@ constexpr int kPolySmallPoints = 256;
 // lowest rung that yields a simple hull wins, exactly as if they had run one after the other (a run is a pure function of
 // the points and k).
 constexpr int kLadderWaves = 3;
+constexpr int kPolySortSelect = 5;  // neighbours from which the k-nearest selection sorts the lanes' keys instead of taking k minima
 constexpr int kPolyBigPoints = 100; // planes with at least as many boundary candidates are handed out first (longest first)
 enum PolyMode
 {
@@ -304,7 +305,44 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         // candidate c lives in lane c (kk <= 21 < 64): index, edge vector, turn class
         int myCand = 0, myClass = 0;
         double myVx = 0.0, myVy = 0.0;
-        for (int c = 0; c < kk; ++c)
+        bool selected = false;
+        if (kk >= kPolySortSelect)
+        {
+            // Many neighbours: ONE sort instead of kk minima.  Every lane offers its smallest key; sorted across the wave, lane c
+            // holds the c-th smallest of them -- and these are the kk nearest points if no lane hides a second key below the
+            // kk-th (its points are 64 indices apart in a cloud sorted by x: near neighbours rarely share a lane).  Otherwise
+            // the minima below decide.
+            unsigned long long head = ~0ull, second = ~0ull;
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+                if (64 * j < n)
+                {
+                    const unsigned long long kj = key[j];
+                    if (kj < head)
+                    {
+                        second = head;
+                        head = kj;
+                    }
+                    else if (kj < second)
+                        second = kj;
+                }
+            const unsigned long long sorted = wave_sort_u64(head, lane);
+            const unsigned long long hidden = wave_min_u64(second);
+            if (__popcll(__ballot(sorted < hidden)) >= kk)
+            {
+                selected = true;
+                if (lane < kk)
+                {
+                    const int idx = (int)(sorted & 1023ull);
+                    const double2 q = pts[idx];
+                    myCand = idx;
+                    myVx = q.x - cur.x;
+                    myVy = q.y - cur.y;
+                    myClass = turn_class(Px, Py, myVx, myVy);
+                }
+            }
+        }
+        for (int c = 0; c < kk && !selected; ++c)
         {
             unsigned long long best = ~0ull;
 #pragma unroll

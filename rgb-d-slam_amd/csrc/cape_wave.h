@@ -89,6 +89,40 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ((unsigned long long)mh << 32) | ml;
 }
 
+// ---- the 64 lanes' keys in ascending order, lane i <- the i-th smallest: a bitonic network of 21 compare-exchange steps.
+// The partner lane ^ STRIDE comes through DPP (strides 1, 2), ds_swizzle (4, 8, 16: within each half) or ds_bpermute (32).
+template <int STRIDE> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane)
+{
+    if (STRIDE == 1)
+        return dpp_u32<kDppQuadXor1>(v);
+    if (STRIDE == 2)
+        return dpp_u32<kDppQuadXor2>(v);
+    if (STRIDE == 32)
+        return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v);
+    // BITMODE swizzle: offset = and_mask | or_mask << 5 | xor_mask << 10 over the lane's five low bits
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (STRIDE << 10));
+}
+template <int SIZE, int STRIDE> __device__ __forceinline__ unsigned long long sort_step_u64(unsigned long long v, int lane)
+{
+    const unsigned olo = xor_lane_u32<STRIDE>((unsigned)v, lane), ohi = xor_lane_u32<STRIDE>((unsigned)(v >> 32), lane);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    // the lower lane of the pair keeps the minimum where the block of SIZE sorts upwards, the maximum where it sorts downwards
+    const bool keepMin = ((lane & STRIDE) == 0) == ((lane & SIZE) == 0); // (SIZE = 64: every lane sorts upwards)
+    return (keepMin == (o < v)) ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long v, int lane)
+{
+#define CAPE_SORT_STEP(SIZE, STRIDE) v = sort_step_u64<SIZE, STRIDE>(v, lane);
+    CAPE_SORT_STEP(2, 1)
+    CAPE_SORT_STEP(4, 2) CAPE_SORT_STEP(4, 1)
+    CAPE_SORT_STEP(8, 4) CAPE_SORT_STEP(8, 2) CAPE_SORT_STEP(8, 1)
+    CAPE_SORT_STEP(16, 8) CAPE_SORT_STEP(16, 4) CAPE_SORT_STEP(16, 2) CAPE_SORT_STEP(16, 1)
+    CAPE_SORT_STEP(32, 16) CAPE_SORT_STEP(32, 8) CAPE_SORT_STEP(32, 4) CAPE_SORT_STEP(32, 2) CAPE_SORT_STEP(32, 1)
+    CAPE_SORT_STEP(64, 32) CAPE_SORT_STEP(64, 16) CAPE_SORT_STEP(64, 8) CAPE_SORT_STEP(64, 4) CAPE_SORT_STEP(64, 2) CAPE_SORT_STEP(64, 1)
+#undef CAPE_SORT_STEP
+    return v;
+}
+
 // sum of the 64 lanes' doubles in TREE order (not the order of any reference loop: only for quantities whose rounding is
 // not observable, e.g. a conservative bound); uniform result
 __device__ __forceinline__ double op_add_f64_bits(unsigned long long a, unsigned long long b)
