@@ -4,18 +4,22 @@
 // (map_primitive.cpp:137 -> src/utils/polygon.cpp:525-545) instead of the shared cells of the label grids that
 // cape_match_consecutive counts.  The planes of frame f-1 play the map planes, seen through the identity pose.
 //
-//   cape_polygon_inter_kernel  : one wavefront per (frame, previous plane j): for every plane i of the frame that passes
-//        is_distance_similar / is_normal_similar (shape_primitives.cpp:66-86), the polygon of j is projected into the frame of
-//        i (Polygon::project, polygon.cpp:338-382) and the area of the intersection of the two rings is computed.
+//   cape_polygon_gate_kernel   : one wavefront per frame: the kept planes of the frame and of its predecessor, the gates
+//        is_distance_similar / is_normal_similar (shape_primitives.cpp:66-86) of every (previous plane j, plane i) pair, and
+//        the work list of the pairs to intersect.
+//   cape_polygon_inter_kernel  : persistent wavefronts, one pair at a time: the polygon of j is projected into the frame of i
+//        (Polygon::project, polygon.cpp:338-382) and the area of the intersection of the two rings is computed.  Two
+//        instances by capacity (LDS carve); a pair beyond the small one's moves to the large one's list.
 //   cape_polygon_select_kernel : one wavefront per frame: the selection loop (greatest intersection above the overlap
 //        threshold, is-matched flags updated between previous planes, the `selectedIndex <= 0` quirk).
 //
 // The intersection is this repo's host algorithm (host/boundary_polygon.cpp: rings_inter_area), statement for statement: the
 // plane is cut into vertical slabs at every vertex and every edge crossing; inside a slab each ring is a stack of edges sorted
 // by height and the overlap of the two stacks is a sum of trapezoids, added in slab order.  Lanes take the edge pairs (for the
-// crossings), the compare-exchanges of a bitonic sort (slab boundaries) and one slab each (the trapezoids of 64 slabs are
-// computed side by side, then added to the running area in order: the sum's rounding is observable).  + - x / and
-// comparisons only: the areas are compared BIT FOR BIT with the host class (tests/test_gpu_match_polygon.py).
+// crossings), the compare-exchanges of a bitonic sort (slab boundaries), the (edge, slab) incidences of a window of 64 slabs
+// (heights into per-slab buckets, then their ranks) and one slab each for the trapezoids, which are then added to the running
+// area in order: the sum's rounding is observable.  + - x / and comparisons only: the areas are compared BIT FOR BIT with the
+// host class (tests/test_gpu_match_polygon.py).
 #include <hip/hip_runtime.h>
 
 #include "cape_internal.h"
