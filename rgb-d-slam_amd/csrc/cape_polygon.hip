@@ -613,12 +613,13 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
 #ifdef CAPE_POLY_PROFILE
                 const unsigned long long ladderStart = __builtin_amdgcn_s_memtime();
 #endif
-                // wave w walks rung w + 2 and, if that fails, rung w + 5 -- without waiting for the others; it stops as soon as a
+                // wave w walks rung w + 2 and, if that fails, rung 7 - w (the wave with the longest first walk, k = 11, takes the
+                // shortest second one, k = 13: 2-4 % on the whole pass) -- without waiting for the others; it stops as soon as a
                 // rung below its own has a hull (it can no longer win)
                 int myRung = kNoRung;
                 for (int stage = 0; stage < 2; ++stage)
                 {
-                    const int rung = 2 + wave + kLadderWaves * stage;
+                    const int rung = stage == 0 ? 2 + wave : 7 - wave; // (k = 5, 21), (7, 17), (11, 13): the long first walk is followed by the short second one
                     if (__builtin_amdgcn_readfirstlane(*(volatile int*)(s_ok + 8)) < rung)
                         break;
                     CAPE_PCOUNT(8, 1); // hull attempts
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                         atomicMax(&p.prof[(size_t)frame * kProfileSlots + 22], dt);
                 }
 #endif
-                const int winner = best == kNoRung ? -1 : (best - 2) % kLadderWaves;
+                const int winner = best == kNoRung ? -1 : (best <= 4 ? best - 2 : 7 - best);
                 haveRing = winner >= 0 && myRung == best;
                 if (wave != (winner < 0 ? 0 : winner))
                     continue;
