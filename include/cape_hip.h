@@ -490,6 +490,8 @@ int cape_debug_eval(int op, const double* a, const double* b, double* out, int n
 /* Debug: shader-clock ticks spent per phase of the grow kernel, n_frames x 32 (all zero unless the library was built
  * with -DCAPE_B_PROFILE).  Synchronises. */
 int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out);
+/* frames of the last cape_rectify_depth that its band kernel handed to the general kernels (tests; synchronises) */
+int cape_debug_rectify_flagged(cape_handle h, int32_t* count);
 
 const char* cape_last_error(void);
 const char* cape_version(void);

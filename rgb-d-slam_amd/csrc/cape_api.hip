@@ -25,7 +25,7 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 size_t grow_state_bytes(int cells);
 bool resume_group_fits(const StageBParams& p);
-hipError_t launch_rectify(const RectifyParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_rectify(const RectifyParams& p, int nFrames, int computeUnits, hipStream_t stream);
 hipError_t launch_match(const MatchParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_pack(const PackParams& p, hipStream_t stream);
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream);
@@ -135,8 +135,8 @@ struct cape_handle_s
     // rectify_depth (N3): float copies of the back-projection factors + collision keys (allocated on first use)
     float* xpre = nullptr;
     float* ypre = nullptr;
-    unsigned long long* rectKeys = nullptr;
-    size_t rectKeyFrames = 0;
+    unsigned* rectFlags = nullptr; // rectify_depth: a flag per frame, then the list of flagged frames
+    size_t rectFlagFrames = 0;
     // plane matching between consecutive frames (N2): max_batch x cape_frame_match, allocated on first use
     cape_frame_match* matches = nullptr;
     // per-frame scratch (stage A -> stage B)
@@ -283,7 +283,7 @@ void free_all(cape_handle_s* h)
     }
     (void)hipFree(h->xpre);
     (void)hipFree(h->ypre);
-    (void)hipFree(h->rectKeys);
+    (void)hipFree(h->rectFlags);
     (void)hipFree(h->matches);
     (void)hipFree(h->cellSums);
     (void)hipFree(h->cellPlane);
@@ -1262,21 +1262,29 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
-    const size_t frameSize = (size_t)h->cfg.width * h->cfg.height;
-    if (h->rectKeyFrames < (size_t)n_frames)
+    if (h->rectFlagFrames < (size_t)n_frames)
     {
         CAPE_HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(h->rectKeys);
-        h->rectKeys = nullptr;
-        h->rectKeyFrames = 0;
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rectKeys), (size_t)n_frames * frameSize * 8));
-        CAPE_HIP_TRY(hipMemset(h->rectKeys, 0, (size_t)n_frames * frameSize * 8));
-        h->rectKeyFrames = (size_t)n_frames;
+        (void)hipFree(h->rectFlags);
+        h->rectFlags = nullptr;
+        h->rectFlagFrames = 0;
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rectFlags), (2 * (size_t)n_frames + 1) * sizeof(unsigned)));
+        h->rectFlagFrames = (size_t)n_frames;
+    }
+    if (h->computeUnits <= 0)
+    {
+        hipDeviceProp_t prop;
+        h->computeUnits = hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess ? prop.multiProcessorCount : 256;
     }
     cape::RectifyParams p;
     p.in = depth_dev;
     p.out = rectified_dev;
-    p.keys = h->rectKeys;
+    p.frameFlag = h->rectFlags;
+    p.flagged = h->rectFlags + h->rectFlagFrames;
+    {
+        const char* eb = std::getenv("CAPE_RECTIFY_BAND");
+        p.bandRows = eb ? std::atoi(eb) : 0;
+    }
     p.W = h->cfg.width;
     p.H = h->cfg.height;
     p.xpre = h->xpre;
@@ -1287,7 +1295,33 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
     p.fy = h->cfg.fy;
     p.cx = h->cfg.cx;
     p.cy = h->cfg.cy;
-    CAPE_HIP_TRY(cape::launch_rectify(p, n_frames, stream));
+    {
+        // Which source rows can land in a band of target rows?  The row displacement of this rig, sampled over the image and over
+        // depths from 0.3 m to 10 m (plain doubles: a prediction, the kernel checks every pixel and flags what escapes it).
+        double lo = 0.0, hi = 0.0;
+        bool any = false;
+        const double zs[] = {300.0, 600.0, 1200.0, 2500.0, 5000.0, 10000.0};
+        for (int ry = 0; ry <= 4; ++ry)
+            for (int rx = 0; rx <= 4; ++rx)
+                for (double z : zs)
+                {
+                    const double row = (h->cfg.height - 1) * ry / 4.0, col = (h->cfg.width - 1) * rx / 4.0;
+                    const double x = (col - h->cfg.cx) / h->cfg.fx * z, y = (row - h->cfg.cy) / h->cfg.fy * z;
+                    const double q1 = p.T[4] * x + p.T[5] * y + p.T[6] * z + p.T[7], q2 = p.T[8] * x + p.T[9] * y + p.T[10] * z + p.T[11];
+                    if (!(q2 > 0))
+                        continue;
+                    const double d = (h->cfg.fy * q1 / q2 + h->cfg.cy) - row;
+                    lo = any ? std::min(lo, d) : d;
+                    hi = any ? std::max(hi, d) : d;
+                    any = true;
+                }
+        const char* em = std::getenv("CAPE_RECTIFY_MARGIN");
+        const int margin = em ? std::atoi(em) : 2;
+        const double cap = 4.0 * h->cfg.height; // (a degenerate rig: everything escapes, the general kernels take over)
+        p.shiftLo = (int)std::floor(std::max(-cap, std::min(cap, lo))) - margin;
+        p.shiftHi = (int)std::ceil(std::max(-cap, std::min(cap, hi))) + margin;
+    }
+    CAPE_HIP_TRY(cape::launch_rectify(p, n_frames, h->computeUnits, stream));
     return CAPE_OK;
 }
 
@@ -1896,6 +1930,21 @@ int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out)
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     CAPE_HIP_TRY(hipMemcpy(out, h->debugCycles, (size_t)n_frames * cape::kProfileSlots * 8, hipMemcpyDeviceToHost));
+    return CAPE_OK;
+}
+
+int cape_debug_rectify_flagged(cape_handle h, int32_t* count)
+{
+    if (!h || !count)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    *count = 0;
+    if (!h->rectFlags)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    unsigned n = 0;
+    CAPE_HIP_TRY(hipMemcpy(&n, h->rectFlags + h->rectFlagFrames, sizeof n, hipMemcpyDeviceToHost));
+    *count = (int32_t)n;
     return CAPE_OK;
 }
 

@@ -124,7 +124,10 @@ struct RectifyParams
 {
     const float* in;  // frames x H x W depth of camera 2
     float* out;       // frames x H x W depth registered to camera 1
-    unsigned long long* keys; // frames x H x W collision keys, all zero between calls
+    unsigned* frameFlag; // [frames] set by the tile kernel when a pixel of the frame lands outside the scanning bands' reach
+    unsigned* flagged;   // [1 + frames] count, then the flagged frames: redone by the general kernels
+    int bandRows;        // 0: chosen by launch_rectify (CAPE_RECTIFY_BAND overrides it)
+    int shiftLo, shiftHi; // predicted range of (target row - source row) for this rig, margin included (cape_rectify_depth)
     int W, H;
     const float* xpre; // [W] static_cast<float>(acol), ypre [H]
     const float* ypre;

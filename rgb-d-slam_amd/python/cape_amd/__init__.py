@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
     "cape_match_polygons", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
-    "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_copy_seed_sequence",
+    "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -383,6 +383,12 @@ class Extractor:
         out = np.zeros((n_frames, 32), np.uint64)
         _check(self.L, self.L.cape_debug_cycles(self.h, n_frames, out.ctypes.data_as(C.c_void_p)), "cape_debug_cycles")
         return out
+
+    def rectify_flagged(self):
+        """Frames of the last rectify_device that went to the general kernels."""
+        n = C.c_int32(0)
+        _check(self.L, self.L.cape_debug_rectify_flagged(self.h, C.byref(n)), "cape_debug_rectify_flagged")
+        return n.value
 
     # ---- timing --------------------------------------------------------------------------------
     def enable_timing(self, on=True):

@@ -539,6 +539,33 @@ def test_rectify_depth_parity(oracle_mod):
         # second call reuses the (cleared) key buffer
         ex.rectify_device(din.data_ptr(), dout.data_ptr(), 3, TT, s)
         assert np.array_equal(dout.cpu().numpy().view(np.uint32), got.view(np.uint32))
+    # rigs the band kernel's row-displacement prediction treats differently: a pitch (every row moves by ~19: the bands scan
+    # an offset window), a small roll (the displacement varies by ~17 rows over the image: wide windows), a big roll (more than
+    # the bands can afford: every frame goes to the general kernels), and a scene closer than the depths the prediction samples
+    # with a vertical baseline (its pixels escape the windows: that frame alone is flagged and redone)
+    def rot(axis, deg, t):
+        a = np.deg2rad(deg)
+        c, s_ = np.cos(a), np.sin(a)
+        R = {"x": [[1, 0, 0], [0, c, -s_], [0, s_, c]], "y": [[c, 0, s_], [0, 1, 0], [-s_, 0, c]], "z": [[c, -s_, 0], [s_, c, 0], [0, 0, 1]]}[axis]
+        M = np.eye(4)
+        M[:3, :3] = R
+        M[:3, 3] = t
+        return M
+
+    near = frames.copy()
+    near[1] *= np.float32(0.08)  # 80 .. 400 mm
+    cases = [("pitch 2 deg", rot("x", 2.0, [-25.0, 1.5, 4.0]), frames, 0), ("roll 1.5 deg", rot("z", 1.5, [-25.0, 0.0, 0.0]), frames, 0),
+             ("roll 6 deg", rot("z", 6.0, [10.0, -3.0, 0.0]), frames, 3), ("near scene, 30 mm vertical baseline", rot("y", 0.3, [0.0, 30.0, 0.0]), near, 1)]
+    for name, TT, src, flagged in cases:
+        dsrc = torch.from_numpy(src).cuda()
+        ex.rectify_device(dsrc.data_ptr(), dout.data_ptr(), 3, TT, s)
+        got = dout.cpu().numpy()
+        for f in range(3):
+            ref = orc.rectify(src[f], TT)
+            assert np.array_equal(got[f].view(np.uint32), ref.view(np.uint32)), f"rectified depth differs: {name}, frame {f}"
+            assert (ref > 0).mean() > 0.2, name
+        assert ex.rectify_flagged() == flagged, f"{name}: {ex.rectify_flagged()} frames went to the general kernels, expected {flagged}"
+    ex.rectify_device(din.data_ptr(), dout.data_ptr(), 3, T, s)
     # rectified frames feed the extractor like in examples/main_CAPE.cpp:186
     ex.extract_device(dout.data_ptr(), 3, s)
     res = ex.results(3)
