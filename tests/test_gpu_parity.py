@@ -515,6 +515,28 @@ def test_pathological_values_terminate_and_match_labels(oracle_mod):
         ex.close()
 
 
+def test_rectify_depth_1280x960(oracle_mod):
+    """N3 at the wide geometry (bands of 8 target rows: the LDS keys of a band are 8 B per target)."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    W, H = 1280, 960
+    intr = {k: v * 2 for k, v in synth.DEFAULT_INTRINSICS.items()}
+    frames = np.stack([synth.tunnel(seed=4, frame=3, width=W, height=H, intr=intr), synth.room(seed=9, frame=2, width=W, height=H, intr=intr)])
+    a = np.deg2rad(0.7)
+    T = np.array([[np.cos(a), 0, np.sin(a), -50.0], [0, 1, 0, 2.5], [-np.sin(a), 0, np.cos(a), 3.0], [0, 0, 0, 1]])
+    ex = Extractor(W, H, cylinders=False, max_batch=2, **intr)
+    orc = oracle_mod.Oracle(W, H, cylinders=False, **intr)
+    din = torch.from_numpy(frames).cuda()
+    dout = torch.empty_like(din)
+    ex.rectify_device(din.data_ptr(), dout.data_ptr(), 2, T, torch.cuda.current_stream().cuda_stream)
+    got = dout.cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f].view(np.uint32), orc.rectify(frames[f], T).view(np.uint32))
+    assert ex.rectify_flagged() == 0
+    ex.close()
+
+
 def test_rectify_depth_parity(oracle_mod):
     """N3: device rectify_depth == oracle (deterministic last-writer-wins), then the rectified image through the path."""
     import torch
