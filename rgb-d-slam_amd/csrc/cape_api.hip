@@ -1071,6 +1071,31 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
     return cape_extract(h, h->depthStage, n_frames, stream_);
 }
 
+int cape_extract_u16_host(cape_handle h, const uint16_t* depth_host, float scale, int32_t n_frames, void* stream_)
+{
+    if (!h || !depth_host || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle/depth or negative frame count");
+    if (n_frames > h->cfg.max_batch)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds max_batch");
+    CAPE_ON_DEVICE(h);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StreamScope streamScope(h, stream);
+    if (streamScope.rc() != CAPE_OK)
+        return streamScope.rc();
+    // like cape_extract_host: a few pinned frames are read in place, everything else is staged with one copy
+    const size_t frameBytes = (size_t)h->cfg.width * h->cfg.height * sizeof(uint16_t);
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, depth_host) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer;
+    if (!pinned)
+        (void)hipGetLastError();
+    if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 8 == 0)
+        return cape_extract_u16(h, static_cast<const uint16_t*>(attr.devicePointer), scale, n_frames, stream_);
+    if (!h->depthStage) // (sized for float32 frames: cape_extract_host shares it)
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), (size_t)h->cfg.max_batch * h->cfg.width * h->cfg.height * sizeof(float)));
+    CAPE_HIP_TRY(hipMemcpyAsync(h->depthStage, depth_host, (size_t)n_frames * frameBytes, hipMemcpyHostToDevice, stream));
+    return cape_extract_u16(h, reinterpret_cast<const uint16_t*>(h->depthStage), scale, n_frames, stream_);
+}
+
 int cape_device_results(cape_handle h, void** records, int32_t** plane_labels, int32_t** cyl_labels, double** boundary)
 {
     if (!h)

@@ -168,9 +168,10 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
 }
 
 // one chunk (<= _maxBatch frames) through the C ABI: H2D copy + kernels + D2H of records and boundary points
-bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, int m) const
+bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, const uint16_t* raw, float scale, int m) const
 {
-    bool ok = cape_extract_host(shard.handle, depth, m, nullptr) == CAPE_OK;
+    // raw sensor images cross PCIe at half the bytes and are converted on the device
+    bool ok = (raw ? cape_extract_u16_host(shard.handle, raw, scale, m, nullptr) : cape_extract_host(shard.handle, depth, m, nullptr)) == CAPE_OK;
     shard.devicePolygons = false;
     if (ok && _devicePolygons && shard.maxBatch > 8)
     {
@@ -195,15 +196,16 @@ bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, int m)
     return ok;
 }
 
-void Primitive_Detection::run_shard(Shard& shard, const float* depth, int firstFrame, int n, std::vector<plane_container>& planes,
-                                    std::vector<cylinder_container>& cylinders, bool& ok) const
+void Primitive_Detection::run_shard(Shard& shard, const float* depth, const uint16_t* raw, float scale, int firstFrame, int n,
+                                    std::vector<plane_container>& planes, std::vector<cylinder_container>& cylinders, bool& ok) const
 {
     const size_t frameElems = static_cast<size_t>(_width) * _height;
     ok = true;
     for (int base = 0; base < n; base += shard.maxBatch)
     {
         const int m = (n - base < shard.maxBatch) ? n - base : shard.maxBatch;
-        if (!extract_chunk(shard, depth + static_cast<size_t>(firstFrame + base) * frameElems, m))
+        const size_t offset = static_cast<size_t>(firstFrame + base) * frameElems;
+        if (!extract_chunk(shard, depth ? depth + offset : nullptr, raw ? raw + offset : nullptr, scale, m))
         {
             ok = false;
             return;
@@ -217,6 +219,18 @@ void Primitive_Detection::run_shard(Shard& shard, const float* depth, int firstF
 void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames, std::vector<plane_container>& planes,
                                                 std::vector<cylinder_container>& cylinders) noexcept
 {
+    batch_impl(depth, nullptr, 1.0f, n_frames, planes, cylinders);
+}
+
+void Primitive_Detection::find_primitives_batch(const uint16_t* raw, float scale, int n_frames, std::vector<plane_container>& planes,
+                                                std::vector<cylinder_container>& cylinders) noexcept
+{
+    batch_impl(nullptr, raw, scale, n_frames, planes, cylinders);
+}
+
+void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, float scale, int n_frames, std::vector<plane_container>& planes,
+                                     std::vector<cylinder_container>& cylinders) noexcept
+{
     try
     {
         // (Plane / Cylinder are copy-constructible but not assignable, like the reference's: no vector::assign here)
@@ -224,7 +238,7 @@ void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames
         cylinders.clear();
         planes.resize(n_frames > 0 ? n_frames : 0);
         cylinders.resize(n_frames > 0 ? n_frames : 0);
-        if (n_frames <= 0 || !depth)
+        if (n_frames <= 0 || (!depth && !raw))
             return;
         int wanted = _requestedShards;
         if (wanted <= 0 && (cape_device_count(&wanted) != CAPE_OK || wanted <= 0))
@@ -251,7 +265,7 @@ void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames
         if (shards == 1)
         {
             bool good = true;
-            run_shard(_shards[0], depth, 0, n_frames, planes, cylinders, good);
+            run_shard(_shards[0], depth, raw, scale, 0, n_frames, planes, cylinders, good);
             ok[0] = good;
         }
         else
@@ -267,7 +281,7 @@ void Primitive_Detection::find_primitives_batch(const float* depth, int n_frames
                     bool good = true;
                     try
                     {
-                        run_shard(_shards[k], depth, first, count, planes, cylinders, good);
+                        run_shard(_shards[k], depth, raw, scale, first, count, planes, cylinders, good);
                     }
                     catch (const std::exception&)
                     {
@@ -309,7 +323,7 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
         }
         const depth_image d = depthImage.isContinuous() ? depthImage : depthImage.clone();
         const auto t0 = std::chrono::steady_clock::now();
-        if (!extract_chunk(_single, d.ptr<float>(0), 1))
+        if (!extract_chunk(_single, d.ptr<float>(0), nullptr, 1.0f, 1))
         {
             outputs::log_error("find_primitives: " + _single.error);
             return;

@@ -13,6 +13,7 @@
 #ifndef RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
 #define RGBDSLAM_FEATURES_PRIMITIVES_PRIMITIVEDETECTION_HPP
 
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
@@ -45,6 +46,13 @@ class Primitive_Detection
     // depth: n_frames contiguous row-major float32 images on the host.  Sharded over the visible devices (or over
     // set_shard_count() handles); planes[f] / cylinders[f] are frame f's containers whatever device produced them.
     void find_primitives_batch(const float* depth,
+                               int n_frames,
+                               std::vector<plane_container>& planes,
+                               std::vector<cylinder_container>& cylinders) noexcept;
+    // the same from the raw 16-bit sensor images (what the datasets' depth PNGs decode to; depth = raw * scale, e.g. 1/5 for
+    // TUM, examples/main_TUM.cpp:221,242): half the bytes over PCIe, the conversion happens on the device
+    void find_primitives_batch(const uint16_t* raw,
+                               float scale,
                                int n_frames,
                                std::vector<plane_container>& planes,
                                std::vector<cylinder_container>& cylinders) noexcept;
@@ -96,9 +104,13 @@ class Primitive_Detection
     };
     bool make_shard(Shard& s, int device, int maxBatch) noexcept;
     bool ensure_shards(int wanted) noexcept;
-    bool extract_chunk(Shard& shard, const float* depth, int m) const;
+    bool extract_chunk(Shard& shard, const float* depth, const uint16_t* raw, float scale, int m) const;
+    void batch_impl(const float* depth, const uint16_t* raw, float scale, int n_frames, std::vector<plane_container>& planes,
+                    std::vector<cylinder_container>& cylinders) noexcept;
     void run_shard(Shard& shard,
                    const float* depth,
+                   const uint16_t* raw,
+                   float scale,
                    int firstFrame,
                    int n,
                    std::vector<plane_container>& planes,

@@ -121,7 +121,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
+    "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_extract_u16_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_sync_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
@@ -160,6 +160,7 @@ def load_library():
     L.cape_extract.argtypes = [vp, vp, C.c_int32, vp]
     L.cape_extract_host.argtypes = [vp, vp, C.c_int32, vp]
     L.cape_extract_u16.argtypes = [vp, vp, C.c_float, C.c_int32, vp]
+    L.cape_extract_u16_host.argtypes = [vp, vp, C.c_float, C.c_int32, vp]
     L.cape_rectify_depth.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.cape_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.cape_copy_results.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
@@ -285,6 +286,16 @@ class Extractor:
         assert d.shape[1:] == (self.height, self.width)
         _check(self.L, self.L.cape_extract_host(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0], C.c_void_p(stream)),
                "cape_extract_host")
+        return d.shape[0]
+
+    def extract_host_u16(self, raw, scale, stream=0):
+        """Raw uint16 sensor frames in host memory (row N4 over PCIe: half the bytes of float32)."""
+        d = np.ascontiguousarray(raw, dtype=np.uint16)
+        if d.ndim == 2:
+            d = d[None]
+        assert d.shape[1:] == (self.height, self.width)
+        _check(self.L, self.L.cape_extract_u16_host(self.h, d.ctypes.data_as(C.c_void_p), C.c_float(scale), d.shape[0], C.c_void_p(stream)),
+               "cape_extract_u16_host")
         return d.shape[0]
 
     def host_alloc(self, shape, dtype=np.float32):

@@ -134,6 +134,38 @@ int main(int argc, char** argv)
             std::printf("V%zu %d\n", k, same ? 1 : 0);
         }
     }
+    // N4 through the overlay: the batch as raw 16-bit sensor images (depth quantised to 0.2 mm like a TUM PNG) == the same
+    // quantised depths handed over as float32
+    if (batchFrames > 0)
+    {
+        const size_t count = static_cast<size_t>(W) * H * (1 + batchFrames);
+        std::vector<uint16_t> raw(count);
+        std::vector<float> quantised(count);
+        for (size_t i = 0; i < count; ++i)
+        {
+            const float v = depth[i] * 5.0f;
+            raw[i] = v > 0.0f && v < 65535.0f ? static_cast<uint16_t>(v + 0.5f) : 0;
+            quantised[i] = static_cast<float>(raw[i]) * 0.2f;
+        }
+        std::vector<plane_container> fp, up;
+        std::vector<cylinder_container> fc, uc;
+        detector->set_shard_count(shards);
+        detector->find_primitives_batch(quantised.data(), 1 + batchFrames, fp, fc);
+        detector->find_primitives_batch(raw.data(), 0.2f, 1 + batchFrames, up, uc);
+        bool same = fp.size() == up.size();
+        size_t planesSeen = 0;
+        for (size_t k = 0; same && k < fp.size(); ++k)
+        {
+            same = fp[k].size() == up[k].size() && fc[k].size() == uc[k].size();
+            for (size_t i = 0; same && i < fp[k].size(); ++i)
+            {
+                const vector3 a = fp[k][i].get_normal(), b = up[k][i].get_normal();
+                same = a.x() == b.x() && a.y() == b.y() && a.z() == b.z() && fp[k][i].get_d() == up[k][i].get_d();
+                ++planesSeen;
+            }
+        }
+        std::printf("U %d %zu\n", same ? 1 : 0, planesSeen);
+    }
     // N2 on the polygons: the device's find_matches between consecutive frames of a one-shard batch against find_plane_match
     // on the containers the batch returned (same planes, same polygons, same order)
     if (batchFrames > 0)

@@ -97,6 +97,9 @@ def test_sharded_batch_matches_oracle(oracle_mod, host_binaries, tmp_path, shard
         host = [ln[len(tag):] for ln in lines if ln.startswith(f"H{k} ")]
         assert dev == host and len(dev) > 0
         assert f"V{k} 1" in lines
+    # the batch as raw uint16 images (find_primitives_batch(const uint16_t*, scale, ...)) == the quantised depths as float32
+    U = [ln.split() for ln in lines if ln.startswith("U ")][0]
+    assert U[1] == "1" and int(U[2]) >= len(frames)
 
 
 def test_polygon_matcher_equals_host_selection(host_binaries, tmp_path):

@@ -422,6 +422,15 @@ def test_raw_uint16_input_path(oracle_mod):
     orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
     for f in range(len(raw)):
         compare_frame(orc.run(depth[f]), ex, res, f)
+    # the same frames from host memory (cape_extract_u16_host): pageable, then pinned (three frames are read in place over PCIe)
+    first = res.records.tobytes()
+    ex.extract_host_u16(raw, 0.2, torch.cuda.current_stream().cuda_stream)
+    assert ex.results(len(raw)).records.tobytes() == first
+    pinned = ex.host_alloc(raw.shape, np.uint16)
+    pinned[...] = raw
+    ex.extract_host_u16(pinned, 0.2, torch.cuda.current_stream().cuda_stream)
+    assert ex.results(len(raw)).records.tobytes() == first
+    ex.host_free(pinned)
     ex.close()
 
 
