@@ -395,6 +395,12 @@ typedef struct cape_frame_match_exact
 int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* stream);
 int cape_copy_polygon_matches(cape_handle h, int32_t n_frames, cape_frame_match_exact* out);
 
+/* A stream of the handle's device for callers that do not link the HIP runtime themselves (the overlay): non-blocking, so the
+ * work of several handles driven from several host threads overlaps instead of meeting on the legacy null stream.  Pass it as
+ * the `stream` argument of the calls below; destroy it before the handle. */
+int cape_stream_create(cape_handle h, void** stream_out);
+int cape_stream_destroy(cape_handle h, void* stream);
+
 /* Same, from host memory: H2D copy on `stream`, then cape_extract (host boundary of the reference's
  * cv::Mat_<float> argument).  The copy is part of the call; throughput numbers never use this entry. */
 int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, void* stream);

@@ -6,6 +6,7 @@
 // usage: latency_bench <frames.f32> <n_frames> <width> <height> <fx> <fy> <cx> <cy> <cylinders 0|1>
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -114,5 +115,50 @@ int main(int argc, char** argv)
         }
     report("overlay", t);
     std::printf("               (%ld planes seen in total)\n", planes);
+
+    // ---- overlay, batches of 64 host frames (the additions): containers per frame, polygons on the device or by the host class,
+    //      float32 or raw uint16 input
+    {
+        const char* eB = std::getenv("CAPE_BENCH_BATCH");
+        const char* eC = std::getenv("CAPE_BENCH_CHUNK");
+        const int B = eB ? std::atoi(eB) : 64;
+        if (eC)
+            det.set_chunk_frames(std::atoi(eC));
+        std::vector<float> batch(px * B);
+        std::vector<uint16_t> raw(px * B);
+        for (int k = 0; k < B; ++k)
+            std::memcpy(batch.data() + px * k, frames.data() + px * (k % nFrames), px * sizeof(float));
+        for (size_t i = 0; i < batch.size(); ++i)
+        {
+            const float v = batch[i] * 5.0f;
+            raw[i] = v > 0.0f && v < 65535.0f ? static_cast<uint16_t>(v + 0.5f) : 0;
+        }
+        std::vector<rgbd_slam::features::primitives::plane_container> bp;
+        std::vector<rgbd_slam::features::primitives::cylinder_container> bc;
+        for (int mode = 0; mode < 7; ++mode)
+        {
+            // (more shards than devices: the handles' copies, kernels and host work overlap on the one device)
+            det.set_shard_count(mode == 3 ? 2 : mode == 4 ? 4 : mode >= 5 ? 0 : 1);
+            det.set_device_polygons(mode != 1);
+            double best = 1e30;
+            for (int r = 0; r < 6; ++r)
+            {
+                const auto t0 = clk::now();
+                if (mode >= 2 && mode != 6)
+                    det.find_primitives_batch(raw.data(), 0.2f, B, bp, bc);
+                else
+                    det.find_primitives_batch(batch.data(), B, bp, bc);
+                const double dt = us(t0, clk::now());
+                if (r >= 1 && dt < best)
+                    best = dt;
+            }
+            size_t np = 0;
+            for (const auto& c : bp)
+                np += c.size();
+            std::printf("overlay batch of %d  %-44s %8.1f us per frame (%.0f frames/s, %zu planes per batch)\n", B,
+                        mode == 0 ? "float32 frames, polygons on the device" : mode == 1 ? "float32 frames, polygons by the host class" : mode == 2 ? "raw uint16 frames, polygons on the device" : mode == 3 ? "raw uint16 frames, two shards on the device" : mode == 4 ? "raw uint16 frames, four shards on the device" : mode == 5 ? "raw uint16 frames, default shards" : "float32 frames, default shards",
+                        best / B, 1e6 * B / best, np);
+        }
+    }
     return 0;
 }

@@ -1071,6 +1071,30 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
     return cape_extract(h, h->depthStage, n_frames, stream_);
 }
 
+int cape_stream_create(cape_handle h, void** stream_out)
+{
+    if (!h || !stream_out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    CAPE_ON_DEVICE(h);
+    hipStream_t s = nullptr;
+    CAPE_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = s;
+    return CAPE_OK;
+}
+
+int cape_stream_destroy(cape_handle h, void* stream)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (!stream)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h)); // (the handle's event may still refer to work on it)
+    CAPE_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    CAPE_HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return CAPE_OK;
+}
+
 int cape_extract_u16_host(cape_handle h, const uint16_t* depth_host, float scale, int32_t n_frames, void* stream_)
 {
     if (!h || !depth_host || n_frames < 0)

@@ -56,15 +56,19 @@ class Primitive_Detection
                                int n_frames,
                                std::vector<plane_container>& planes,
                                std::vector<cylinder_container>& cylinders) noexcept;
-    // 0 (default): one shard per visible device.  k > 0: k shards, shard i on device i % device_count -- more shards than
+    // 0 (default): one to four shards per visible device, by the size of the batch.  k > 0: k shards, shard i on device i % device_count -- more shards than
     // devices are legal (used by the tests to exercise the sharding on a one-GPU box).  Takes effect at the next batch.
     void set_shard_count(int shards) noexcept { _requestedShards = shards; }
+    // frames a shard sends through its handle at a time (default 256).  Larger chunks amortise the fixed latencies of a pass
+    // (the polygon kernels of 64 frames take 0.76 ms, of 512 frames 1.0 ms); takes effect when the shards are (re)created:
+    // call it before the first batch.
+    void set_chunk_frames(int frames) noexcept { _maxBatch = frames > 8 ? frames : 9; }
     // batches: boundary polygons on the device (default) or with the host class, plane by plane (A/B runs, tests)
     void set_device_polygons(bool on) noexcept { _devicePolygons = on; }
     [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
 
     // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
-    // shard (the last chunk of <= 64 frames); see cape_match_consecutive.  Enforced: returns false (and logs why) when the
+    // shard (the last chunk of <= 256 frames, set_chunk_frames); see cape_match_consecutive.  Enforced: returns false (and logs why) when the
     // last batch was cut over several shards, or when n_frames exceeds the frames of its last chunk.  Plane indices count the segments flagged
     // is_output, i.e. the planes BEFORE the polygon validity test drops any.
     bool match_consecutive(int n_frames,
@@ -87,6 +91,8 @@ class Primitive_Detection
     struct Shard
     {
         cape_handle handle = nullptr;
+        void* stream = nullptr; // batch shards: a non-blocking stream of the handle's device (cape_stream_create), so that the copies
+                                // and kernels of two shards on one device overlap; the one-frame handle stays on the null stream
         int device = 0;
         int maxBatch = 0;
         // where the last chunk's records / boundary points are: the shard's own copies (batch handles, results in HBM) or
@@ -120,13 +126,13 @@ class Primitive_Detection
 
     uint _width, _height;
     int _cells = 0, _boundaryCapacity = 0;
-    int _maxBatch = 64;
+    int _maxBatch = 256;
     int _requestedShards = 0;
     bool _devicePolygons = true;
     int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
     int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
-    mutable std::vector<Shard> _shards;    // batch shards (max_batch = 64 each), created at the first find_primitives_batch
+    mutable std::vector<Shard> _shards;    // batch shards (max_batch = set_chunk_frames each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
 
     // remove copy functions, like the reference (primitive_detection.hpp:228-230)

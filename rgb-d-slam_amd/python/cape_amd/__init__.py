@@ -121,7 +121,7 @@ CELL_STATS_DTYPE = np.dtype([
     ("inorder", "<u4"), ("pad", "<u4")], align=True)
 
 EXPORTED_SYMBOLS = [
-    "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_extract_u16_host", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
+    "cape_device_count", "cape_create", "cape_destroy", "cape_get_layout", "cape_extract", "cape_extract_u16", "cape_extract_host", "cape_extract_u16_host", "cape_stream_create", "cape_stream_destroy", "cape_rectify_depth", "cape_rectify_depth_host", "cape_device_results",
     "cape_gather_configure", "cape_pack_primitives", "cape_copy_packed", "cape_comm_unique_id", "cape_comm_init",
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_sync_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
