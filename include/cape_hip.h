@@ -377,7 +377,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
 enum
 {
     CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, or a polygon pair beyond the
-                                           kernel's capacities (128 vertices per ring, 1 024 slab boundaries, 16 edges of a
+                                           kernel's capacities (128 vertices per ring, 1 024 slab boundaries, 32 edges of a
                                            ring over one slab): no match is reported for the frame -- use the host class */
 };
 typedef struct cape_frame_match_exact

@@ -43,7 +43,7 @@ template <> struct Tier<0>
 };
 template <> struct Tier<1>
 {
-    static constexpr int kRing = 128, kXs = 1024, kStack = 16, kWavesPerGroup = 1, kGroupsPerCu = 2;
+    static constexpr int kRing = 128, kXs = 1024, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
 };
 constexpr int kTiers = 2;
 constexpr int MP = CAPE_MATCH_MAX_PLANES;
