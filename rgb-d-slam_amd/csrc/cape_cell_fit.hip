@@ -283,7 +283,9 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     // latest valid depth before it -- to release the workgroup's LDS earlier.  Bit-exact, and slower: 1.68 ms against 1.46 ms
     // per 4 096 frames.  One lane per cell runs a step in ~12 instructions for 64 cells at once; one lane per TEST pays the
     // index arithmetic, the look-back loop and its branches per test, ~5x the wave-instructions, and this kernel is bound by
-    // VALU issue, not by the LDS it holds.)
+    // VALU issue, not by the LDS it holds.  A persistent form -- 1 024 .. 4 096 workgroups looping over the band pairs, to save
+    // the gaps between a workgroup's end and its successor's start -- was slower still: 2.1-2.6 ms; the loop costs 38 VGPRs and
+    // with them the fifth wave per SIMD.)
     if (t >= 64)
         return;
     const int fb = t >> 5, fs = t & 31;
