@@ -218,7 +218,7 @@ struct cape_handle_s
     uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
     cape_frame_match_exact* matchesExact = nullptr;
-    unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 2 lists of max_batch x 256 pairs
+    unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 3 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
@@ -1837,7 +1837,7 @@ int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* s
     if (!h->matchesExact)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchesExact), (size_t)h->cfg.max_batch * sizeof(cape_frame_match_exact)));
     if (!h->matchLists)
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchLists), (64 + 2 * pairCapacity) * sizeof(unsigned)));
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchLists), (64 + 3 * pairCapacity) * sizeof(unsigned)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)

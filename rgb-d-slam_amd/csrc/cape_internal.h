@@ -156,7 +156,7 @@ struct MatchPolygonParams
     const double2* vertices;      // frames x boundaryCapacity
     cape_frame_match_exact* matches;
     unsigned* listCounts; // pairs on the work list of each capacity tier of the intersection kernel
-    unsigned* pairLists;  // 2 lists of pairCapacity entries: (frame << 8) | (j << 4) | i
+    unsigned* pairLists;  // 3 lists of pairCapacity entries: (frame << 8) | (j << 4) | i
     size_t pairCapacity;  // max_batch x 256
     int boundaryCapacity;
     int computeUnits;

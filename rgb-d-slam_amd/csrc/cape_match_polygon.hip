@@ -31,11 +31,11 @@ namespace {
 
 constexpr int kWaves = 2; // frames per workgroup of the gate / select kernels
 
-// Two instances of the intersection kernel, by capacity: vertices of one ring (simplified polygons: 13 on average, 90 at
+// Three instances of the intersection kernel, by capacity: vertices of one ring (simplified polygons: 13 on average, 90 at
 // most on the test streams), slab boundaries (vertices of both rings + edge crossings), edges of one ring over one slab,
 // independent waves per workgroup.  The capacities only size the LDS carve, i.e. how many waves a CU holds: the work is one
 // wave's dependent LDS round trips and only other waves fill the gaps.  The small instance takes ~95 % of the pairs; a pair
-// that exceeds one of its capacities moves to the large instance's work list.
+// that exceeds one of an instance's capacities moves to the next one's work list.
 template <int TIER> struct Tier;
 template <> struct Tier<0>
 {
@@ -43,9 +43,13 @@ template <> struct Tier<0>
 };
 template <> struct Tier<1>
 {
+    static constexpr int kRing = 128, kXs = 1024, kStack = 16, kWavesPerGroup = 1, kGroupsPerCu = 2;
+};
+template <> struct Tier<2> // the comb-shaped outline that comes along once in a few thousand frames
+{
     static constexpr int kRing = 128, kXs = 1024, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
 };
-constexpr int kTiers = 2;
+constexpr int kTiers = 3;
 constexpr int MP = CAPE_MATCH_MAX_PLANES;
 
 #define CAPE_MP_SYNC()                                                                                        \
@@ -687,6 +691,8 @@ hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipSt
     if (const hipError_t e = launch_tier<0>(p, blocks_for(Tier<0>::kGroupsPerCu, Tier<0>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
     if (const hipError_t e = launch_tier<1>(p, blocks_for(Tier<1>::kGroupsPerCu, Tier<1>::kWavesPerGroup), stream); e != hipSuccess)
+        return e;
+    if (const hipError_t e = launch_tier<2>(p, blocks_for(Tier<2>::kGroupsPerCu, Tier<2>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(cape_polygon_select_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
     return hipGetLastError();

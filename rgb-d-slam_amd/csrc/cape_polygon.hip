@@ -896,14 +896,8 @@ __global__ __launch_bounds__(256) void cape_polygon_list_kernel(PolygonParams p,
     const cape_frame_record& rec = p.records[frame];
     const bool isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
     const int nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
-    if (!isOut)
-    {
-        cape_polygon* o = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + lane];
-        o->vertex_count = 0;
-        o->flags = 0;
-        o->segment = (uint32_t)lane;
-        o->area = 0.0;
-    }
+    // (segments that are no output plane keep the empty record launch_polygons' memset left: 64 scattered partial-line stores per
+    //  frame cost more than clearing the whole array at the memory's pace)
     // 257 .. 1 024 candidates: the large instance; everything else (incl. what it will only flag: too few / too many points)
     // goes to the small one
     const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
@@ -953,6 +947,8 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
     for (int m = 0; m < 3; ++m)
         if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
             return e;
+    if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
+        return e;
     hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + 3) / 4), dim3(256), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
