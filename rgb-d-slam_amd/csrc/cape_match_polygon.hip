@@ -445,15 +445,18 @@ __device__ __forceinline__ unsigned pack_pair(int frame, int j, int i) { return 
 
 } // namespace
 
-// One wavefront per frame: the kept planes of the frame and of its predecessor, the gates of every (previous plane j, plane i)
+// One wavefront per frame, sixteen frames per workgroup: the kept planes of the frame and of its predecessor, the gates of every (previous plane j, plane i)
 // pair (Plane::is_distance_similar / is_normal_similar on the planes' parametrisations, shape_primitives.cpp:66-86) and the
 // work list of the pairs whose polygons are to be intersected.  A pair the gates reject holds -1.
-__global__ __launch_bounds__(64 * kWaves) void cape_polygon_gate_kernel(MatchPolygonParams p, int nFrames)
+constexpr int kGateFrames = 16; // frames (waves) of a gate workgroup
+__global__ __launch_bounds__(64 * kGateFrames) void cape_polygon_gate_kernel(MatchPolygonParams p, int nFrames)
 {
-    const int lane = threadIdx.x & 63;
-    const int frame = blockIdx.x * kWaves + (threadIdx.x >> 6);
-    if (frame >= nFrames)
-        return;
+    __shared__ unsigned s_count[kGateFrames];
+    __shared__ unsigned s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frameRaw = blockIdx.x * kGateFrames + wave;
+    const bool live = frameRaw < nFrames;
+    const int frame = live ? frameRaw : nFrames - 1; // (idle waves of the last workgroup shadow a real frame and store nothing)
     cape_frame_match_exact& out = p.matches[frame];
     const cape_frame_record& recC = p.records[frame];
     const cape_polygon* polC = p.polygons + (size_t)frame * CAPE_MAX_PLANES;
@@ -461,14 +464,14 @@ __global__ __launch_bounds__(64 * kWaves) void cape_polygon_gate_kernel(MatchPol
     const int nCur = valid_planes(recC, polC, lane, segC);
     const int nPrev = frame > 0 ? valid_planes(p.records[frame - 1], polC - CAPE_MAX_PLANES, lane, segP) : 0;
     const bool fits = nCur <= MP && nPrev <= MP;
-    if (lane == 0)
+    if (live && lane == 0)
     {
         out.n_prev = nPrev;
         out.n_cur = nCur;
         out.flags = fits ? 0u : (uint32_t)CAPE_MATCH_EXACT_OVERFLOW;
         out.pad = 0;
     }
-    if (lane < MP)
+    if (live && lane < MP)
     {
         out.match[lane] = -1;
         out.seg_prev[lane] = (lane < nPrev) ? segP : -1;
@@ -486,6 +489,9 @@ __global__ __launch_bounds__(64 * kWaves) void cape_polygon_gate_kernel(MatchPol
         const cape_plane_segment& Q = p.records[frame - 1].segments[segP];
         pn[0] = Q.out_normal[0], pn[1] = Q.out_normal[1], pn[2] = Q.out_normal[2], pd = Q.d;
     }
+    unsigned long long gatedMask[MP * MP / 64];
+    bool mine[MP * MP / 64];
+#pragma unroll
     for (int k = 0; k < MP * MP / 64; ++k)
     {
         const int pair = k * 64 + lane, j = pair / MP, i = pair % MP;
@@ -497,17 +503,39 @@ __global__ __launch_bounds__(64 * kWaves) void cape_polygon_gate_kernel(MatchPol
             const double cosAngle = (sn0 * qn0 + sn1 * qn1) + sn2 * qn2;
             gated = fabs(sd - qd) < p.maxDistance && fabs(cosAngle) > p.minCosAngle;
         }
-        out.inter_area[j][i] = gated ? nan_code(kNanPending) : -1.0;
-        const unsigned long long gb = __ballot(gated);
-        if (gb)
+        if (live)
+            out.inter_area[j][i] = gated ? nan_code(kNanPending) : -1.0;
+        gatedMask[k] = __ballot(gated);
+        mine[k] = gated;
+    }
+    // ONE atomic per workgroup on the list's counter (a counter every frame's wave bumps on its own serialises thousands of
+    // atomics on one address: 50 us of the call)
+    const unsigned myCount = (unsigned)(__popcll(gatedMask[0]) + __popcll(gatedMask[1]) + __popcll(gatedMask[2]) + __popcll(gatedMask[3]));
+    if (lane == 0)
+        s_count[wave] = live ? myCount : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        unsigned total = 0;
+        for (int w = 0; w < kGateFrames; ++w)
         {
-            unsigned base = 0;
-            if (lane == 0)
-                base = atomicAdd(&p.listCounts[0], (unsigned)__popcll(gb));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (gated)
-                p.pairLists[base + __popcll(gb & ((1ull << lane) - 1ull))] = pack_pair(frame, j, i);
+            const unsigned c = s_count[w];
+            s_count[w] = total;
+            total += c;
         }
+        s_base = total ? atomicAdd(&p.listCounts[0], total) : 0u;
+    }
+    __syncthreads();
+    if (!live)
+        return;
+    unsigned at = s_base + s_count[wave];
+#pragma unroll
+    for (int k = 0; k < MP * MP / 64; ++k)
+    {
+        const int pair = k * 64 + lane;
+        if (mine[k])
+            p.pairLists[at + __popcll(gatedMask[k] & ((1ull << lane) - 1ull))] = pack_pair(frame, pair / MP, pair % MP);
+        at += (unsigned)__popcll(gatedMask[k]);
     }
 }
 
@@ -678,7 +706,7 @@ hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipSt
 {
     if (const hipError_t e = hipMemsetAsync(p.listCounts, 0, kTiers * sizeof(unsigned), stream); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(cape_polygon_gate_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
+    hipLaunchKernelGGL(cape_polygon_gate_kernel, dim3((nFrames + kGateFrames - 1) / kGateFrames), dim3(64 * kGateFrames), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     // persistent grids: as many workgroups as the chip holds at once

@@ -887,17 +887,22 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
 
 // one wavefront per frame, lane j <- segment j: the work lists of the three polygon kernels, and the records of the segments
 // that need no kernel (not an output plane: empty record)
-__global__ __launch_bounds__(256) void cape_polygon_list_kernel(PolygonParams p, int nFrames)
+constexpr int kListFrames = 16; // frames (waves) of a list workgroup: ONE atomic per list and workgroup -- a counter that every
+                                // frame's wave bumps on its own serialises 4 096 atomics on one address (74 us of the pass)
+__global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames)
 {
-    const int lane = threadIdx.x & 63;
-    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (frame >= nFrames)
-        return;
-    const cape_frame_record& rec = p.records[frame];
-    const bool isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
-    const int nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
-    // (segments that are no output plane keep the empty record launch_polygons' memset left: 64 scattered partial-line stores per
-    //  frame cost more than clearing the whole array at the memory's pace)
+    __shared__ unsigned s_count[3][kListFrames], s_base[3][kListFrames];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * kListFrames + wave;
+    bool isOut = false;
+    int nPts = 0;
+    if (frame < nFrames)
+    {
+        const cape_frame_record& rec = p.records[frame];
+        isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
+        nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
+    }
+    // (segments that are no output plane keep the empty record launch_polygons' memset left)
     // 257 .. 1 024 candidates: the large instance; everything else (incl. what it will only flag: too few / too many points)
     // goes to the small one
     const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
@@ -909,19 +914,28 @@ __global__ __launch_bounds__(256) void cape_polygon_list_kernel(PolygonParams p,
     uint32_t* listS = p.lists + (size_t)kPolyFirstRung * p.listStride;
     uint32_t* listL = p.lists + (size_t)kPolyFull * p.listStride;
     const unsigned listCapacity = p.listStride - kPolyListHeader;
-    unsigned baseB = 0, baseR = 0, baseL = 0;
     if (lane == 0)
     {
-        if (mb)
-            baseB = atomicAdd(&listS[0], (unsigned)__popcll(mb));
-        if (mr)
-            baseR = atomicAdd(&listS[1], (unsigned)__popcll(mr));
-        if (ml)
-            baseL = atomicAdd(&listL[0], (unsigned)__popcll(ml));
+        s_count[0][wave] = (unsigned)__popcll(mb);
+        s_count[1][wave] = (unsigned)__popcll(mr);
+        s_count[2][wave] = (unsigned)__popcll(ml);
     }
-    baseB = __shfl(baseB, 0);
-    baseR = __shfl(baseR, 0);
-    baseL = __shfl(baseL, 0);
+    __syncthreads();
+    if (threadIdx.x < 3)
+    {
+        unsigned total = 0;
+        for (int w = 0; w < kListFrames; ++w)
+        {
+            s_base[threadIdx.x][w] = total;
+            total += s_count[threadIdx.x][w];
+        }
+        unsigned* counter = threadIdx.x == 0 ? &listS[0] : threadIdx.x == 1 ? &listS[1] : &listL[0];
+        const unsigned base = total ? atomicAdd(counter, total) : 0u;
+        for (int w = 0; w < kListFrames; ++w)
+            s_base[threadIdx.x][w] += base;
+    }
+    __syncthreads();
+    const unsigned baseB = s_base[0][wave], baseR = s_base[1][wave], baseL = s_base[2][wave];
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned entry = ((unsigned)frame << 8) | (unsigned)lane;
     if (big)
@@ -949,7 +963,7 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
             return e;
     if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + 3) / 4), dim3(256), 0, stream, p, nFrames);
+    hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
