@@ -257,6 +257,10 @@ typedef struct cape_layout
     uint64_t frame_record_bytes;  /* sizeof(cape_frame_record) */
     int32_t compute_units;        /* CUs of the handle's device */
     int32_t grow_frames_per_cu;   /* frames (one wavefront each) the grow kernel keeps in flight per CU (occupancy API) */
+    uint32_t effective_flags;     /* the CAPE_FLAG_* bits that are ACTIVE on this handle: CAPE_FLAG_ASYNC_SECOND_PASS is
+                                     cleared here when the handle cannot overlap (cylinders off, max_batch <= 8 or
+                                     sub_batches > 1), so a caller can tell whether the mode it asked for is in force */
+    uint32_t reserved;
 } cape_layout;
 
 /* Number of HIP devices this process sees (0 and CAPE_ERR_NO_DEVICE without a GPU): what a host-side batch API shards
@@ -355,7 +359,9 @@ typedef struct cape_polygon
 /* Builds the polygons of frames [0, n_frames) of the last cape_extract; asynchronous on `stream`. */
 int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream);
 /* Device pointers: polygons = n_frames x CAPE_MAX_PLANES cape_polygon (indexed by segment), vertices = n_frames x
- * boundary_capacity x 2 doubles.  Valid until the next cape_build_polygons / destroy. */
+ * boundary_capacity x 2 doubles.  Valid until the next cape_build_polygons / destroy.  CAPE_ERR_CAPACITY when no
+ * cape_build_polygons has run since the last cape_extract (the arrays would describe the PREVIOUS batch); the copy calls
+ * below likewise refuse more frames than the last cape_build_polygons / cape_match_polygons of the current batch covered. */
 int cape_device_polygons(cape_handle h, cape_polygon** polygons, double** vertices);
 /* Synchronous D2H copy of both arrays (either pointer may be NULL). */
 int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, double* vertices);
@@ -376,7 +382,9 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
 #define CAPE_MATCH_MAX_PLANES 16
 enum
 {
-    CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, or a polygon pair beyond the
+    CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, an output plane of either frame
+                                           whose polygon was left to the host class (CAPE_POLY_OVERFLOW: the host may keep it,
+                                           so the kept-plane indices are not known here), or a polygon pair beyond the
                                            kernel's capacities (128 vertices per ring, 1 024 slab boundaries, 32 edges of a
                                            ring over one slab): no match is reported for the frame -- use the host class */
 };

@@ -217,6 +217,7 @@ struct cape_handle_s
     double* polyVertices = nullptr;
     uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
+    int matchExactFrames = 0;       // frames of the last cape_match_polygons (0: none for the current batch)
     cape_frame_match_exact* matchesExact = nullptr;
     unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 3 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
@@ -656,6 +657,15 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "width/height must be positive multiples of 20, <= 1280; max_batch > 0");
     if (!(cfg->fx > 0) || !(cfg->fy > 0))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "focal lengths must be positive");
+    if (cfg->flags & ~(uint32_t)(CAPE_FLAG_CYLINDERS | CAPE_FLAG_ASYNC_SECOND_PASS))
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "unknown CAPE_FLAG_* bit in cape_config.flags");
+    // the debug knobs are read here, once per handle, and a value they do not know is an error, not a silent default
+    if (const char* e = std::getenv("CAPE_RESUME"))
+        if (std::string(e) != "off" && std::string(e) != "wave" && std::string(e) != "group")
+            return fail(CAPE_ERR_INVALID_ARGUMENT, "CAPE_RESUME must be off, wave or group");
+    if (const char* e = std::getenv("CAPE_SCHEDULE"))
+        if (std::string(e) != "two" && std::string(e) != "single")
+            return fail(CAPE_ERR_INVALID_ARGUMENT, "CAPE_SCHEDULE must be two or single");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -943,6 +953,8 @@ int cape_get_layout(cape_handle h, cape_layout* out)
     out->cells = h->cells;
     out->boundary_capacity = h->boundaryCap;
     out->frame_record_bytes = sizeof(cape_frame_record);
+    out->effective_flags = h->cfg.flags & ~(uint32_t)(h->sideStream ? 0u : CAPE_FLAG_ASYNC_SECOND_PASS);
+    out->reserved = 0;
     return CAPE_OK;
 }
 
@@ -973,6 +985,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
         return fail(CAPE_ERR_INVALID_ARGUMENT, "depth must be aligned to four pixels (16 bytes of float32, 8 bytes of uint16)");
     h->lastFrames = n_frames;
     h->polygonFrames = 0; // the polygons on the device belong to the previous batch
+    h->matchExactFrames = 0; // and so do the polygon matches
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h); // the handle's device, whatever the calling thread had current
@@ -1328,6 +1341,7 @@ int cape_rectify_depth(cape_handle h, const float* depth_dev, float* rectified_d
     cape::RectifyParams p;
     p.in = depth_dev;
     p.out = rectified_dev;
+    p.ldsLimitBytes = h->ldsLimit;
     p.frameFlag = h->rectFlags;
     p.flagged = h->rectFlags + h->rectFlagFrames;
     {
@@ -1729,8 +1743,12 @@ int cape_count_primitives(cape_handle h, int32_t n_frames, int32_t* n_planes, in
     {
         if (!h->countScratch)
             CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->countScratch), 4 * sizeof(int32_t)));
-        // behind the batch, wherever it was enqueued, without touching that stream
-        CAPE_HIP_TRY(h->workRecorded ? hipEventSynchronize(h->workDone) : hipDeviceSynchronize());
+        // behind the batch, wherever it was enqueued (the caller's stream AND the handle's side stream of an asynchronous
+        // second pass), without touching those streams
+        if (h->workRecorded || h->sidePending)
+            CAPE_HIP_TRY(drain_handle(h));
+        else
+            CAPE_HIP_TRY(hipDeviceSynchronize());
         hipStream_t st = nullptr;
         CAPE_HIP_TRY(cape::launch_count_primitives(h->records, n_frames, h->countScratch, st));
         CAPE_HIP_TRY(hipMemcpyAsync(tot, h->countScratch, sizeof(tot), hipMemcpyDeviceToHost, st));
@@ -1858,6 +1876,7 @@ int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* s
     const double planeMinimalOverlap = static_cast<double>(0.4f);
     p.minOverlap = (flags & CAPE_MATCH_ADVANCED) ? planeMinimalOverlap / 2 : planeMinimalOverlap;
     CAPE_HIP_TRY(cape::launch_match_polygons(p, n_frames, stream));
+    h->matchExactFrames = n_frames;
     return CAPE_OK;
 }
 
@@ -1867,6 +1886,8 @@ int cape_copy_polygon_matches(cape_handle h, int32_t n_frames, cape_frame_match_
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
     if (!h->matchesExact)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_polygons has not run");
+    if (n_frames > h->matchExactFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the frames of the last cape_match_polygons of the current batch");
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(drain_handle(h));
     CAPE_HIP_TRY(hipMemcpy(out, h->matchesExact, (size_t)n_frames * sizeof(cape_frame_match_exact), hipMemcpyDeviceToHost));
@@ -1877,6 +1898,8 @@ int cape_device_polygons(cape_handle h, cape_polygon** polygons, double** vertic
 {
     if (!h)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->polygonFrames <= 0)
+        return fail(CAPE_ERR_CAPACITY, "no polygons of the current batch: cape_build_polygons has not run since the last cape_extract");
     if (polygons)
         *polygons = h->polygons;
     if (vertices)
@@ -1890,6 +1913,8 @@ int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, 
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame count");
     if (!h->polygons)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "no polygons have been built yet");
+    if (n_frames > h->polygonFrames)
+        return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the frames of the last cape_build_polygons of the current batch");
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(drain_handle(h));
     const size_t n = (size_t)n_frames;

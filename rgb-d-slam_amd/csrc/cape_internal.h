@@ -128,6 +128,7 @@ struct RectifyParams
     unsigned* flagged;   // [1 + frames] count, then the flagged frames: redone by the general kernels
     int bandRows;        // 0: chosen by launch_rectify (CAPE_RECTIFY_BAND overrides it)
     int shiftLo, shiftHi; // predicted range of (target row - source row) for this rig, margin included (cape_rectify_depth)
+    int ldsLimitBytes = 0; // LDS one workgroup may use on the handle's device (0: unknown, 64 KB assumed)
     int W, H;
     const float* xpre; // [W] static_cast<float>(acol), ypre [H]
     const float* ypre;

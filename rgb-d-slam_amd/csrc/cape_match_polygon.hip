@@ -424,11 +424,16 @@ __device__ inline double rings_inter_area(const MpLds& L, int na, int nb, int la
 
 // the kept planes of a frame (output plane whose polygon Primitive_Detection keeps), in segment order: lane k < count holds
 // the segment index of plane k
-__device__ __forceinline__ int valid_planes(const cape_frame_record& rec, const cape_polygon* pol, int lane, int& mySeg)
+// hostOnly: some output plane of the frame has no device polygon (CAPE_POLY_OVERFLOW: its outline is left to the host class,
+// which may well keep it) -- the kept-plane indices of such a frame cannot be told here, so the caller flags it
+__device__ __forceinline__ int valid_planes(const cape_frame_record& rec, const cape_polygon* pol, int lane, int& mySeg, bool& hostOnly)
 {
     int nSeg = rec.header.n_plane_segments;
     nSeg = nSeg < 0 ? 0 : (nSeg > CAPE_MAX_PLANES ? CAPE_MAX_PLANES : nSeg);
-    const bool ok = lane < nSeg && rec.segments[lane].is_output != 0 && (pol[lane].flags & CAPE_POLY_VALID) != 0 && pol[lane].vertex_count >= 3;
+    const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
+    const unsigned flags = isOut ? pol[lane].flags : 0u;
+    const bool ok = isOut && (flags & CAPE_POLY_VALID) != 0 && pol[lane].vertex_count >= 3;
+    hostOnly = __ballot(isOut && (flags & CAPE_POLY_OVERFLOW) != 0) != 0ull;
     const unsigned long long m = __ballot(ok);
     // lane k takes the k-th set bit
     int seg = -1;
@@ -461,9 +466,10 @@ __global__ __launch_bounds__(64 * kGateFrames) void cape_polygon_gate_kernel(Mat
     const cape_frame_record& recC = p.records[frame];
     const cape_polygon* polC = p.polygons + (size_t)frame * CAPE_MAX_PLANES;
     int segC = -1, segP = -1;
-    const int nCur = valid_planes(recC, polC, lane, segC);
-    const int nPrev = frame > 0 ? valid_planes(p.records[frame - 1], polC - CAPE_MAX_PLANES, lane, segP) : 0;
-    const bool fits = nCur <= MP && nPrev <= MP;
+    bool hostOnlyC = false, hostOnlyP = false;
+    const int nCur = valid_planes(recC, polC, lane, segC, hostOnlyC);
+    const int nPrev = frame > 0 ? valid_planes(p.records[frame - 1], polC - CAPE_MAX_PLANES, lane, segP, hostOnlyP) : 0;
+    const bool fits = nCur <= MP && nPrev <= MP && !hostOnlyC && !hostOnlyP;
     if (live && lane == 0)
     {
         out.n_prev = nPrev;

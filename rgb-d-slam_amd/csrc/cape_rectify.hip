@@ -202,11 +202,16 @@ hipError_t launch_rectify(const RectifyParams& p, int nFrames, int computeUnits,
     if (p.bandRows > 0)
         for (log2R = 0; (2 << log2R) <= p.bandRows; ++log2R) // (a power of two)
             ;
-    while (p.bandRows <= 0 && log2R > 1 && ((size_t)p.W * 8 << log2R) > 96 * 1024)
+    // ... of THIS device: 96 KB of the 160 KB a gfx950 workgroup may have, never more than the device reports (ADVICE r3:
+    // a 64 KB device got an 80 KB launch and failed instead of taking a smaller band)
+    const size_t ldsLimit = p.ldsLimitBytes > 0 ? (size_t)p.ldsLimitBytes : 64 * 1024;
+    const size_t budget = ldsLimit < 96 * 1024 ? ldsLimit : 96 * 1024;
+    while (log2R > 1 && ((size_t)p.W * 8 << log2R) > (p.bandRows <= 0 ? budget : ldsLimit))
         --log2R;
     const int R = 1 << log2R;
     const int bands = (p.H + R - 1) / R;
-    if (p.shiftHi - p.shiftLo > 4 * R) // each band would scan five times its own rows
+    const bool fits = ((size_t)R * p.W * 8) <= ldsLimit;
+    if (!fits || p.shiftHi - p.shiftLo > 4 * R) // not even two rows of keys fit / each band would scan five times its own rows
         hipLaunchKernelGGL(cape_rectify_flag_all_kernel, dim3((unsigned)((nFrames + 255) / 256)), dim3(256), 0, stream, p, nFrames);
     else
         hipLaunchKernelGGL(cape_rectify_tile_kernel, dim3((unsigned)(bands * nFrames)), dim3(kTileThreads), (size_t)R * p.W * 8, stream, p, bands, log2R,

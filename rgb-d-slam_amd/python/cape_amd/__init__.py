@@ -40,7 +40,8 @@ class cape_config(C.Structure):
 class cape_layout(C.Structure):
     _fields_ = [("h_cells", C.c_int32), ("v_cells", C.c_int32), ("cells", C.c_int32),
                 ("boundary_capacity", C.c_int32), ("frame_record_bytes", C.c_uint64),
-                ("compute_units", C.c_int32), ("grow_frames_per_cu", C.c_int32)]
+                ("compute_units", C.c_int32), ("grow_frames_per_cu", C.c_int32),
+                ("effective_flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class cape_timings(C.Structure):
@@ -248,6 +249,7 @@ class Extractor:
         self.record_bytes = int(lay.frame_record_bytes)
         self.compute_units = int(lay.compute_units)
         self.grow_frames_per_cu = int(lay.grow_frames_per_cu)
+        self.effective_flags = int(lay.effective_flags)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

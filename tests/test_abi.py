@@ -55,6 +55,33 @@ def test_no_cpu_fallback(hip_library):
     assert lib.cape_create(C.byref(bad), C.byref(h)) == -1
 
 
+def test_create_rejects_unknown_flags_and_knob_values(hip_library):
+    """an unknown CAPE_FLAG_* bit, or a debug knob with a value the library does not know, is an error of
+    cape_create -- not a silent default.  (Argument checks run before the device probe: no GPU needed.)"""
+    import subprocess
+    import sys
+
+    import cape_amd
+
+    lib = cape_amd.load_library()
+    h = C.c_void_p()
+    bad = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 1 << 7, 0, 1, 0, 0)
+    assert lib.cape_create(C.byref(bad), C.byref(h)) == -1 and b"unknown CAPE_FLAG" in lib.cape_last_error()
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import cape_amd\n"
+        "L = cape_amd.load_library()\n"
+        "cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 1, 0, 1, 0, 0)\n"
+        "h = C.c_void_p()\n"
+        "print(L.cape_create(C.byref(cfg), C.byref(h)), L.cape_last_error().decode())\n" % os.path.join(ROOT, "rgb-d-slam_amd", "python"))
+    for knob in ("CAPE_RESUME", "CAPE_SCHEDULE"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "sideways"}), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-800:]
+        rc, msg = out.stdout.strip().split(" ", 1)
+        assert int(rc) == -1 and knob in msg
+
+
 def test_product_never_touches_oracle():
     """The product tree must not reference oracle/ (SURVEY / task rule: the oracle is the checker only)."""
     pkg = os.path.join(ROOT, "rgb-d-slam_amd")

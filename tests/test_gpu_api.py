@@ -140,3 +140,62 @@ def test_count_primitives_entry(oracle_mod):
     assert planes == int(hdr["n_planes"].sum()) and cyls == int(hdr["n_cylinders"].sum()) and most == int(hdr["n_planes"].max())
     assert planes > 0
     ex.close()
+
+
+def test_effective_flags_tell_whether_the_async_second_pass_is_active():
+    """CAPE_FLAG_ASYNC_SECOND_PASS is only usable with cylinders on, max_batch > 8 and no sub-batches; the layout
+    says what is in force."""
+    import cape_amd
+    from cape_amd import Extractor
+
+    on = Extractor(640, 480, cylinders=True, max_batch=32, async_second_pass=True, **_intr())
+    assert on.effective_flags & cape_amd.CAPE_FLAG_ASYNC_SECOND_PASS and on.effective_flags & cape_amd.CAPE_FLAG_CYLINDERS
+    on.close()
+    for kw in (dict(cylinders=False, max_batch=32), dict(cylinders=True, max_batch=4), dict(cylinders=True, max_batch=32, sub_batches=2)):
+        ex = Extractor(640, 480, async_second_pass=True, **kw, **_intr())
+        assert not (ex.effective_flags & cape_amd.CAPE_FLAG_ASYNC_SECOND_PASS), kw
+        ex.close()
+
+
+def test_count_primitives_waits_for_the_async_second_pass():
+    """cape_count_primitives read the records while the side stream's second pass was still writing them."""
+    import torch
+    from cape_amd import Extractor, synth, synth_gpu
+
+    n = 512
+    dev = synth_gpu.stream("room", 12, n, device="cuda", chunk=64)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = Extractor(640, 480, cylinders=True, max_batch=n, **_intr())
+    ref.extract_device(dev.data_ptr(), n, st)
+    want = ref.count_primitives(n)
+    ref.close()
+    ex = Extractor(640, 480, cylinders=True, max_batch=n, async_second_pass=True, **_intr())
+    for _ in range(5):
+        ex.extract_device(dev.data_ptr(), n, st)
+        assert ex.count_primitives(n) == want
+    ex.close()
+
+
+def test_polygon_reads_refuse_a_stale_batch():
+    """after a new cape_extract the polygons / polygon matches on the device belong to the previous batch."""
+    import torch
+    from cape_amd import CapeError, Extractor, synth_gpu
+
+    n = 4
+    dev = synth_gpu.stream("room", 3, n, device="cuda", chunk=4)
+    st = torch.cuda.current_stream().cuda_stream
+    ex = Extractor(640, 480, max_batch=n, **_intr())
+    ex.extract_device(dev.data_ptr(), n, st)
+    ex.build_polygons(n, st)
+    ex.match_polygons(n, 0, st)
+    ex.polygons(n), ex.polygon_matches(n)
+    ex.extract_device(dev.data_ptr(), n, st)
+    with pytest.raises(CapeError):
+        ex.polygons(n)
+    with pytest.raises(CapeError):
+        ex.polygon_matches(n)
+    ex.build_polygons(2, st)
+    ex.polygons(2)
+    with pytest.raises(CapeError):
+        ex.polygons(3)
+    ex.close()
