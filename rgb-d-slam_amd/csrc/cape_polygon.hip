@@ -2,14 +2,17 @@
 //
 // Replaces, for a batch, what the reference does on the host right after compute_plane_segment_boundary
 // (primitive_detection.cpp:622): utils::Polygon(points, normal, center) -- reference src/utils/polygon.cpp:168-229:
-// plane frame (:74-115), projection (:125-144), concave hull (:283-318, third_party/concave_fitting.cpp: Moreira-Santos
-// k-nearest-neighbours hull on the k ladder 3,3,5,7,11,13,17,21), convex-hull fallback (:268-281), area (:453-461) and
-// simplify (:578-601).  The algorithm is the one of this repo's dependency-free host class (host/boundary_polygon.cpp),
-// statement for statement and in the same operation order: + - x / sqrt and comparisons only (no libm call whose rounding
-// could differ between glibc and ocml), so the vertices are compared BIT FOR BIT against the host class
-// (tests/test_gpu_polygon.py).  The reference's own vertices are not a parity target -- it feeds FLANN's randomized
-// kd-trees a nondeterministically ordered point list (host/boundary_polygon.hpp) -- its validity / area / containment
-// contract is what tests/host/test_polygon.cpp replays.
+// plane frame (:74-115), projection (:125-144, in reverse order :187-192), concave hull (:283-318 over
+// third_party/concave_fitting.cpp:69-183: the Moreira-Santos k-nearest-neighbours walk on the k ladder 3,3,5,7,11,13,17,21
+// with its DBL_EPSILON comparisons, its Intersects, its PointInPolygon -- zero-crossings quirk included -- and no duplicate
+// removal on this call path), the repair of the hull into a closed clockwise ring (third_party/correct_boost_polygon.hpp),
+// convex-hull fallback (:268-281), area (:453-461) and simplify (:578-601).  The statements are those of this repo's
+// dependency-free host class (host/boundary_polygon.cpp), in the same operation order: + - x / and comparisons only (no libm
+// call whose rounding could differ between glibc and ocml), so the vertices are compared BIT FOR BIT against the host class
+// (tests/test_gpu_polygon.py) -- and both against oracle/polygon_oracle.cpp, the independent restatement of the reference's
+// files (tests/test_gpu_polygon_oracle.py).  Two things cannot be the reference's: FLANN's approximate search over randomized
+// kd-trees (here: the exact k nearest points) and the `-atan2` ordering of the candidates (here: exact turn predicates, which
+// order like the angles and cannot disagree between host and device on a near-tie).
 //
 // Layout: the points of a plane are its boundary candidates (<= kPolyMaxPoints), projected and sorted in LDS; a hull is a
 // list of point indices.  Lanes are parallel over points (distances, point-in-ring tests), over hull edges (intersection
@@ -120,19 +123,79 @@ __device__ __forceinline__ bool segments_intersect(const double2& a1, const doub
     return false;
 }
 
-// point_in_ring(p, ring, closed = true): crossing number; a point on the boundary counts as inside.  One lane, whole ring.
-__device__ __forceinline__ bool point_in_ring_closed(const double2& p, const double2* pts, const unsigned short* ring, int n)
+// ---- third_party/concave_fitting.cpp:186-201: the hull's comparisons carry a DBL_EPSILON slack (host: eq_eps ... points_equal)
+constexpr double kHullEps = 2.220446049250313e-16;
+__device__ __forceinline__ bool eq_eps(double a, double b) { return fabs(a - b) <= kHullEps; }
+__device__ __forceinline__ bool zero_eps(double a) { return fabs(a) <= kHullEps; }
+__device__ __forceinline__ bool lt_eps(double a, double b) { return a < (b - kHullEps); }
+__device__ __forceinline__ bool le_eps(double a, double b) { return a <= (b + kHullEps); }
+__device__ __forceinline__ bool gt_eps(double a, double b) { return a > (b + kHullEps); }
+__device__ __forceinline__ bool points_equal(const double2& a, const double2& b) { return eq_eps(a.x, b.x) && eq_eps(a.y, b.y); }
+
+// host/boundary_polygon.cpp: hull_edges_intersect = Intersects of concave_fitting.cpp:426-463 (crossing point of the carrier
+// lines, eight bounding tests with the slack; parallel segments never intersect).  Boxes more than 1e-9 apart cannot both
+// hold the crossing point: no division for nearly every pair.
+__device__ __forceinline__ bool hull_edges_intersect(const double2& a1p, const double2& a2p, const double2& b1p, const double2& b2p)
 {
-    bool inside = false, onEdge = false;
-    for (int i = 0, j = n - 1; i < n; j = i++)
+    const double ax1 = a1p.x, ay1 = a1p.y, ax2 = a2p.x, ay2 = a2p.y;
+    const double bx1 = b1p.x, by1 = b1p.y, bx2 = b2p.x, by2 = b2p.y;
+    const double aminx = pmin(ax1, ax2), amaxx = pmax(ax1, ax2), aminy = pmin(ay1, ay2), amaxy = pmax(ay1, ay2);
+    const double bminx = pmin(bx1, bx2), bmaxx = pmax(bx1, bx2), bminy = pmin(by1, by2), bmaxy = pmax(by1, by2);
+    if (bminx - amaxx > 1e-9 || aminx - bmaxx > 1e-9 || bminy - amaxy > 1e-9 || aminy - bmaxy > 1e-9)
+        return false;
+    const double a1 = ay2 - ay1;
+    const double b1 = ax1 - ax2;
+    const double c1 = a1 * ax1 + b1 * ay1;
+    const double a2 = by2 - by1;
+    const double b2 = bx1 - bx2;
+    const double c2 = a2 * bx1 + b2 * by1;
+    const double det = a1 * b2 - a2 * b1;
+    if (zero_eps(det))
+        return false;
+    const double x = (b2 * c1 - b1 * c2) / det;
+    const double y = (a1 * c2 - a2 * c1) / det;
+    return le_eps(aminx, x) && le_eps(x, amaxx) && le_eps(aminy, y) && le_eps(y, amaxy) && le_eps(bminx, x) && le_eps(x, bmaxx) &&
+           le_eps(bminy, y) && le_eps(y, bmaxy);
+}
+
+// host: point_in_hull = PointInPolygon of concave_fitting.cpp:393-423 over the hull list as the walk left it (consecutive
+// pairs, no wrap), zero-crossings quirk included.  One lane, whole hull.
+__device__ __forceinline__ bool point_in_hull(const double2& p, const double2* pts, const unsigned short* hull, int hs)
+{
+    if (hs <= 2)
+        return false;
+    const double x = p.x, y = p.y;
+    int inout = 0;
+    double2 q0 = pts[hull[0]];
+    for (int v = 0; v + 1 < hs; ++v)
     {
-        const double2 a = pts[ring[i]], b = pts[ring[j]];
-        if (pcross2(a, b, p) == 0 && pmin(a.x, b.x) <= p.x && p.x <= pmax(a.x, b.x) && pmin(a.y, b.y) <= p.y && p.y <= pmax(a.y, b.y))
-            onEdge = true; // the host returns `closed` here; the crossings counted so far no longer matter
-        if (((a.y > p.y) != (b.y > p.y)) && (p.x < (b.x - a.x) * (p.y - a.y) / (b.y - a.y) + a.x))
-            inside = !inside;
+        const double2 q1 = pts[hull[v + 1]];
+        if (((le_eps(q0.y, y) && lt_eps(y, q1.y)) || (le_eps(q1.y, y) && lt_eps(y, q0.y))) && !zero_eps(q1.y - q0.y) &&
+            lt_eps(x, q0.x + ((q1.x - q0.x) * (y - q0.y) / (q1.y - q0.y))))
+            inout++;
+        q0 = q1;
     }
-    return onEdge || inside;
+    if (inout == 0)
+        return true;
+    return (inout & 1) != 0;
+}
+
+// host: segment_distance2 (Boost's projected_point strategy, comparable form)
+__device__ __forceinline__ double segment_distance2(const double2& p, const double2& a, const double2& b)
+{
+    const double vx = b.x - a.x, vy = b.y - a.y, wx = p.x - a.x, wy = p.y - a.y;
+    const double c1 = wx * vx + wy * vy;
+    if (c1 <= 0)
+        return wx * wx + wy * wy;
+    const double c2 = vx * vx + vy * vy;
+    if (c2 <= c1)
+    {
+        const double ux = p.x - b.x, uy = p.y - b.y;
+        return ux * ux + uy * uy;
+    }
+    const double t = c1 / c2;
+    const double qx = a.x + t * vx, qy = a.y + t * vy;
+    return (p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy);
 }
 
 // ring_area_signed: ordered sum, one rounding per add (uniform: every lane walks the ring)
@@ -214,16 +277,21 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
     return (bx * ay - by * ax) < 0; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
 }
 
-// One run of the k-nearest-neighbours hull (host: concave_hull_k).  On success the hull's point indices are in L.hull[0, hs).
+// One run of the k-nearest-neighbours walk (host: concave_hull_k = ConcaveHull of concave_fitting.cpp:93-183).  On success the
+// hull's point indices are in L.hull[0, hs) exactly as the reference's vector holds them: ending with the start point again
+// when the walk came back to it, every point once when it ran out of points first.
 // `lowestDone` (ladder kernel only, else null): LDS word holding the lowest rung that already has its hull; a higher rung gives
 // up as soon as it sees one below it succeed -- it can no longer win.
-template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int k, int lane, int& hsOut, const volatile int* lowestDone = nullptr,
+template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const volatile int* lowestDone = nullptr,
                                                         int myRung = 0)
 {
     constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
     const double2* pts = L.pts;
     if (n < 3)
-        return false;
+    {
+        hsOut = 0;
+        return true;
+    }
     if (n == 3)
     {
         if (lane < 3)
@@ -232,25 +300,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         hsOut = 3;
         return true;
     }
-    k = k < 3 ? 3 : k;
-    k = k < n - 1 ? k : n - 1;
-    // lowest point (smallest y, then smallest x)
-    int first;
-    {
-        double by = __builtin_inf(), bx = __builtin_inf();
-        int bi = 0x7FFFFFFF;
-        for (int i = lane; i < n; i += 64)
-        {
-            const double2 q = pts[i];
-            if (q.y < by || (q.y == by && q.x < bx))
-            {
-                by = q.y;
-                bx = q.x;
-                bi = i;
-            }
-        }
-        first = wave_argmin2(by, bx, bi);
-    }
+    const double2 firstPt = pts[first];
     for (int i = lane; i < n; i += 64)
         L.used[i] = 0;
     CAPE_POLY_SYNC();
@@ -261,24 +311,23 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     }
     CAPE_POLY_SYNC();
     int hs = 1;
-    int usedCount = 1;
+    int usedCount = 1; // points hidden from the neighbour search
     int current = first;
-    double Px = -1.0, Py = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
+    double2 cur = firstPt;
+    double Px = 1.0, Py = 0.0; // prevAngle = 0: the +x direction
     int step = 1;
-    int remaining = n - 1;
-    while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
+    while ((!points_equal(cur, firstPt) || step == 1) && hs != n)
     {
         if (lowestDone && __builtin_amdgcn_readfirstlane(*lowestDone) < myRung)
             return false;
         if (step == 4)
         {
             if (lane == 0)
-                L.used[first] = 0; // the start point becomes reachable again once the hull has three edges
+                L.used[first] = 0; // the start point is put back into the index once the hull has three edges
             --usedCount;
             CAPE_POLY_SYNC();
         }
-        const double2 cur = pts[current];
-        // ---- k nearest unused neighbours of the current point, ascending (squared distance, index)
+        // ---- k nearest visible neighbours of the current point, ascending (squared distance, index)
         // key = the squared distance's bit pattern (>= +0: the bits order like the value) with its ten lowest mantissa bits
         // replaced by the point index: ONE 64-bit wave minimum per neighbour yields the nearest point and breaks ties (and
         // distances within 2^-42 of each other) by index.  The host class sorts by the very same key.
@@ -290,17 +339,16 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             key[j] = ~0ull;
             if (64 * j >= n)
                 continue; // (uniform: a plane of 150 points uses three of the sixteen slots)
-            if (i < n && !L.used[i] && i != current)
+            if (i < n && !L.used[i])
             {
                 const double2 q = pts[i];
-                const double dx = q.x - cur.x, dy = q.y - cur.y;
+                const double dx = cur.x - q.x, dy = cur.y - q.y;
                 key[j] = ((unsigned long long)__double_as_longlong(dx * dx + dy * dy) & ~1023ull) | (unsigned long long)i;
             }
         }
-        // every used point is on the hull and the current point is one of them
         const int cnt = n - usedCount;
-        if (cnt == 0)
-            break;
+        if (cnt <= 0)
+            return false; // no neighbour left: the reference leaves its candidate loop with `its` still set
         const int kk = k < cnt ? k : cnt;
         // candidate c lives in lane c (kk <= 21 < 64): index, edge vector, turn class
         int myCand = 0, myClass = 0;
@@ -310,8 +358,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         {
             // Many neighbours: ONE sort instead of kk minima.  Every lane offers its smallest key; sorted across the wave, lane c
             // holds the c-th smallest of them -- and these are the kk nearest points if no lane hides a second key below the
-            // kk-th (its points are 64 indices apart in a cloud sorted by x: near neighbours rarely share a lane).  Otherwise
-            // the minima below decide.
+            // kk-th.  Otherwise the minima below decide.
             unsigned long long head = ~0ull, second = ~0ull;
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
@@ -338,7 +385,6 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
                     myCand = idx;
                     myVx = q.x - cur.x;
                     myVy = q.y - cur.y;
-                    myClass = turn_class(Px, Py, myVx, myVy);
                 }
             }
         }
@@ -361,9 +407,11 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
                 myCand = idx;
                 myVx = q.x - cur.x;
                 myVy = q.y - cur.y;
-                myClass = turn_class(Px, Py, myVx, myVy);
             }
         }
+        if (myVx == 0 && myVy == 0)
+            myVx = 1.0; // a duplicate of the current point: atan2(+0, +0) = 0, the +x direction
+        myClass = turn_class(Px, Py, myVx, myVy);
         // ---- candidates by decreasing clockwise turn from the previous edge (a scan in nearest-first order, like the host's);
         //      the first whose edge crosses no hull edge wins
         unsigned tried = 0;
@@ -390,11 +438,12 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             tried |= 1u << b;
             const int cnd = __builtin_amdgcn_readlane(myCand, b);
             const double2 cp = pts[cnd];
-            const int jFirst = (cnd == first) ? 1 : 0;
+            const int jFirst = points_equal(cp, firstPt) ? 1 : 0;
             bool its = false;
-            // hull edges (h[j], h[j+1]), j in [jFirst, hs - 3]: the edge that ends at the current point shares it with the candidate edge
+            // hull edges (h[j], h[j+1]), j in [jFirst, hs - 3]: not the edge that ends at the current point, and not the first edge
+            // when the candidate is the start point (concave_fitting.cpp:146-163)
             for (int j = jFirst + lane; j + 2 < hs && !its; j += 64)
-                its = segments_intersect(cur, cp, pts[L.hull[j]], pts[L.hull[j + 1]]);
+                its = hull_edges_intersect(cur, cp, pts[L.hull[j]], pts[L.hull[j + 1]]);
             if (!__any(its))
             {
                 found = true;
@@ -403,15 +452,13 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         }
         if (!found)
             return false;
-        if (next == first)
-        {
-            current = first;
-            break;
-        }
         const double2 nx = pts[next];
         Px = cur.x - nx.x; // looking back along the new edge
         Py = cur.y - nx.y;
+        if (Px == 0 && Py == 0)
+            Px = 1.0;
         current = next;
+        cur = nx;
         if (lane == 0)
         {
             L.hull[hs] = (unsigned short)current;
@@ -419,21 +466,38 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         }
         ++hs;
         ++usedCount;
-        --remaining;
         ++step;
         CAPE_POLY_SYNC();
     }
-    if (current != first || hs < 3)
-        return false;
-    // every input point must lie inside or on the hull
+    // every point that is not a hull vertex must pass PointInPolygon (the start point is a hull vertex whether or not it is
+    // hidden from the search at this moment)
     bool outside = false;
     for (int i = lane; i < n; i += 64)
-        if (!L.used[i] && !point_in_ring_closed(pts[i], pts, L.hull, hs))
+        if (!L.used[i] && i != first && !point_in_hull(pts[i], pts, L.hull, hs))
             outside = true;
     if (__any(outside))
         return false;
     hsOut = hs;
     return true;
+}
+
+// host: find_min_y_point = FindMinYPoint of concave_fitting.cpp:231-243: std::min_element under (y ascending, x DESCENDING) with
+// the slack.  A comparison with a slack is not transitive, so the scan is the host's sequential one: every lane runs it.
+__device__ inline int find_min_y_point(const double2* pts, int n)
+{
+    int smallest = 0;
+    double2 b = pts[0];
+    for (int i = 1; i < n; ++i)
+    {
+        const double2 a = pts[i];
+        const bool less = eq_eps(a.y, b.y) ? gt_eps(a.x, b.x) : lt_eps(a.y, b.y);
+        if (less)
+        {
+            smallest = i;
+            b = a;
+        }
+    }
+    return smallest;
 }
 
 // bitonic sort of L.pts[0, n) by (x, y), ascending; n is padded to a power of two with +inf points
@@ -564,39 +628,19 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
             flags |= CAPE_POLY_OVERFLOW; // left to the host class
         else
         {
-            // ---- projection (polygon.cpp:125-144) and the hull's RemoveDuplicates: sort by (x, y), drop equal neighbours
+            // ---- projection (polygon.cpp:125-144), in REVERSE order like the reference (:187-192); no sort, no duplicate removal
+            //      (concave_fitting.cpp:69: the overload this path binds does not call RemoveDuplicates)
             const double* bnd = p.boundary + ((size_t)frame * p.boundaryCapacity + S.boundary_offset) * 3;
             for (int i = lane; i < nPts; i += 64)
             {
-                const double dx = bnd[3 * i] - cx, dy = bnd[3 * i + 1] - cy, dz = bnd[3 * i + 2] - cz;
+                const double* q = bnd + 3 * (nPts - 1 - i);
+                const double dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
                 L.pts[i] = make_double2((xax * dx + xay * dy) + xaz * dz, (yax * dx + yay * dy) + yaz * dz);
             }
             CAPE_POLY_SYNC();
-            sort_points(L, nPts, lane);
-            int n = 0;
-            for (int base = 0; base < nPts; base += 64)
-            {
-                const int i = base + lane;
-                double2 q = make_double2(0, 0);
-                bool keepIt = false;
-                if (i < nPts)
-                {
-                    q = L.pts[i];
-                    keepIt = true;
-                    if (i > 0)
-                    {
-                        const double2 prev = L.pts[i - 1];
-                        keepIt = !(prev.x == q.x && prev.y == q.y);
-                    }
-                }
-                const unsigned long long kb = __ballot(keepIt);
-                CAPE_POLY_SYNC(); // every lane has read its point (and its left neighbour) before the chunk is compacted
-                if (keepIt)
-                    L.pts[n + __popcll(kb & ((1ull << lane) - 1ull))] = q;
-                n += __popcll(kb);
-                CAPE_POLY_SYNC();
-            }
-            CAPE_PTICK(0); // projection, sort, duplicate removal
+            const int n = nPts;
+            const int first = find_min_y_point(L.pts, n);
+            CAPE_PTICK(0); // projection, start point
             // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
             int hs = 0;
             bool haveRing = false;
@@ -622,11 +666,11 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     const int rung = stage == 0 ? 2 + wave : 7 - wave; // (k = 5, 21), (7, 17), (11, 13): the long first walk is followed by the short second one
                     if (__builtin_amdgcn_readfirstlane(*(volatile int*)(s_ok + 8)) < rung)
                         break;
+                    if (ladder[rung] > n)
+                        continue; // the reference stops climbing when the next k exceeds the point count (concave_fitting.cpp:86-87)
                     CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool hullOk = concave_hull_k<CAP>(L, n, ladder[rung], lane, hs, s_ok + 8, rung);
+                    const bool ok = concave_hull_k<CAP>(L, n, first, ladder[rung], lane, hs, s_ok + 8, rung);
                     CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
-                    const bool ok = hullOk && ring_is_simple(L.pts, L.hull, hs, lane);
-                    CAPE_PTICK(2); // simple-ring test of a hull
                     if (ok)
                     {
                         myRung = rung;
@@ -664,18 +708,15 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                 for (int a = 0; a <= aLast && !haveRing; ++a)
                 {
                     const int k = ladder[a];
+                    if (a > 0 && k > n)
+                        break; // the next k exceeds the point count (concave_fitting.cpp:86-87)
                     // (the ladder's second rung repeats the first: the run is a pure function of the points and k, so a
                     //  failed k = 3 fails again -- the host class runs it twice, the result is the same)
                     if (a == 1)
                         continue;
                     CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool hullOk = concave_hull_k<CAP>(L, n, k, lane, hs);
+                    haveRing = concave_hull_k<CAP>(L, n, first, k, lane, hs);
                     CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
-                    if (hullOk && ring_is_simple(L.pts, L.hull, hs, lane))
-                        haveRing = true;
-                    CAPE_PTICK(2); // simple-ring test of a hull
-                    if (!haveRing && k > n)
-                        break;
                 }
                 if (MODE == kPolyFirstRung && !haveRing)
                 {
@@ -695,22 +736,57 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
             int rn = 0;
             if (haveRing)
             {
-                // clockwise like the reference's polygons: reversed if the signed area is positive
-                const bool rev = ring_area_signed(L.pts, L.hull, hs) > 0;
-                for (int i = lane; i < hs; i += 64)
-                    ring[i] = L.hull[rev ? hs - 1 - i : i];
-                rn = hs;
+                // The repair of the constructor (polygon.cpp:195-226 -> correct_boost_polygon.hpp:188-195, :172-186): the walk's ring,
+                // closed, is reversed when it runs counter-clockwise -- it does, and it still starts at the walk's start point.  Kept
+                // open here: the closing vertex goes.
+                int m = hs;
+                if (m > 1 && points_equal(L.pts[L.hull[m - 1]], L.pts[L.hull[0]]))
+                    --m;
+                const bool rev = m >= 3 && ring_area_signed(L.pts, L.hull, m) > 0;
+                for (int i = lane; i < m; i += 64)
+                    ring[i] = L.hull[(rev && i > 0) ? m - i : i];
+                rn = m;
                 CAPE_POLY_SYNC();
-                // Polygon's constructor asks is_valid() of the ORIENTED ring once more: on a near-degenerate sliver the
-                // intersection predicates of the reversed edges can round the other way, and the convex hull takes over
+                // A hull that touches or crosses itself is dissolved with Boost set operations in the reference
+                // (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull
                 if (!ring_is_simple(L.pts, ring, rn, lane))
                     haveRing = false;
+                CAPE_PTICK(2); // simple-ring test of the oriented hull
             }
             if (!haveRing)
             {
                 // ---- compute_convex_hull (monotone chain over the sorted, deduplicated points), reversed to clockwise.
                 //      Sequential by nature; every lane runs it on the same values, lane 0 writes.
                 flags |= CAPE_POLY_CONVEX_FALLBACK;
+                // the walk needed the points in the reference's order; the chain needs them sorted by (x, y) and distinct
+                int n = nPts;
+                sort_points(L, n, lane);
+                {
+                    int nd = 0;
+                    for (int base = 0; base < n; base += 64)
+                    {
+                        const int i = base + lane;
+                        double2 q = make_double2(0, 0);
+                        bool keepIt = false;
+                        if (i < n)
+                        {
+                            q = L.pts[i];
+                            keepIt = true;
+                            if (i > 0)
+                            {
+                                const double2 prev = L.pts[i - 1];
+                                keepIt = !(prev.x == q.x && prev.y == q.y);
+                            }
+                        }
+                        const unsigned long long kb = __ballot(keepIt);
+                        CAPE_POLY_SYNC(); // every lane has read its point (and its left neighbour) before the chunk is compacted
+                        if (keepIt)
+                            L.pts[nd + __popcll(kb & ((1ull << lane) - 1ull))] = q;
+                        nd += __popcll(kb);
+                        CAPE_POLY_SYNC();
+                    }
+                    n = nd;
+                }
                 if (n < 3)
                 {
                     if (lane < n)
@@ -740,13 +816,14 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                         CAPE_POLY_SYNC();
                     }
                     const int hn = kx - 1;
-                    // reversed into registers first: hull and ring share LDS when the chain ran past kPolyMaxPoints entries
+                    // clockwise, starting at the leftmost point like the chain (host: reverse(h.begin() + 1, h.end())); through
+                    // registers: hull and ring share LDS when the chain ran past kPolyMaxPoints entries
                     unsigned short tmp[kPolyPerLane];
 #pragma unroll
                     for (int j = 0; j < kPolyPerLane; ++j)
                     {
                         const int i = lane + 64 * j;
-                        tmp[j] = i < hn ? hstk[hn - 1 - i] : (unsigned short)0;
+                        tmp[j] = i < hn ? hstk[i == 0 ? 0 : hn - i] : (unsigned short)0;
                     }
                     CAPE_POLY_SYNC();
 #pragma unroll
@@ -762,7 +839,7 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
             }
             CAPE_PTICK(3); // orientation, validity of the oriented ring, convex fallback
             CAPE_PCOUNT(9, rn); // vertices before simplification
-            CAPE_PCOUNT(10, n); // distinct points
+            CAPE_PCOUNT(10, nPts); // points
             area = rn >= 3 ? fabs(ring_area_signed(L.pts, ring, rn)) : 0.0;
             // ---- simplify (polygon.cpp:578-601): Douglas-Peucker on the closed ring, threshold max(area / 1e5, 10); kept if the
             //      result is a simple ring whose area stays above 75 %
@@ -788,21 +865,11 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     if (b <= a + 1)
                         continue;
                     const double2 pa = L.pts[closed[a]], pb = L.pts[closed[b]];
-                    const double dx = pb.x - pa.x, dy = pb.y - pa.y;
-                    const double len = sqrt(dx * dx + dy * dy);
-                    unsigned long long best = 0ull; // distance bits (>= +0); the first index wins a tie, like the host's strict >
+                    unsigned long long best = 0ull; // squared distance bits (>= +0); the first index wins a tie, like the host's strict >
                     int bestI = 0x7FFFFFFF;
                     for (int i = a + 1 + lane; i < b; i += 64)
                     {
-                        const double2 q = L.pts[closed[i]];
-                        double d;
-                        if (len == 0)
-                        {
-                            const double ex = q.x - pa.x, ey = q.y - pa.y;
-                            d = sqrt(ex * ex + ey * ey);
-                        }
-                        else
-                            d = fabs(dx * (pa.y - q.y) - (pa.x - q.x) * dy) / len;
+                        const double d = segment_distance2(L.pts[closed[i]], pa, pb);
                         const unsigned long long db = (unsigned long long)__double_as_longlong(d);
                         if (bestI == 0x7FFFFFFF || db > best)
                         {
@@ -821,7 +888,7 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
                     const unsigned mineKey = (bestI != 0x7FFFFFFF && best == mx) ? (unsigned)(0x7FFFFFFF - bestI) : 0u;
                     const int idx = 0x7FFFFFFF - (int)wave_max_u32(mineKey);
                     const double dmax = __longlong_as_double((long long)mx);
-                    if (dmax > eps)
+                    if (dmax > eps * eps)
                     {
                         if (lane == 0)
                         {

@@ -93,62 +93,131 @@ double ring_area_signed(const std::vector<vector2>& r)
     return 0.5 * s;
 }
 
-// One run of the Moreira-Santos k-nearest-neighbours concave hull; false if no simple hull exists for this k.
-bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vector2>& hull)
+// ---- third_party/concave_fitting.cpp:186-201: every comparison of the hull carries a DBL_EPSILON slack.  Restated literally:
+//      IEEE additions and comparisons, so the device hull (csrc/cape_polygon.hip) evaluates the very same expressions.
+constexpr double kHullEps = std::numeric_limits<double>::epsilon();
+inline bool eq_eps(double a, double b) { return std::abs(a - b) <= kHullEps; }
+inline bool zero_eps(double a) { return std::abs(a) <= kHullEps; }
+inline bool lt_eps(double a, double b) { return a < (b - kHullEps); }
+inline bool le_eps(double a, double b) { return a <= (b + kHullEps); }
+inline bool gt_eps(double a, double b) { return a > (b + kHullEps); }
+inline bool points_equal(const vector2& a, const vector2& b) { return eq_eps(a[0], b[0]) && eq_eps(a[1], b[1]); }
+
+// Intersects, concave_fitting.cpp:426-463: the crossing point of the two carrier lines, then four bounding tests with the
+// slack.  Parallel (and collinear) segments never intersect (:446-449).  The early-out settles nearly every pair without
+// the two divisions: boxes further apart than 1e-9 cannot both hold the crossing point, whose tests allow ~4e-16.
+bool hull_edges_intersect(const vector2& a1p, const vector2& a2p, const vector2& b1p, const vector2& b2p)
+{
+    const double ax1 = a1p[0], ay1 = a1p[1], ax2 = a2p[0], ay2 = a2p[1];
+    const double bx1 = b1p[0], by1 = b1p[1], bx2 = b2p[0], by2 = b2p[1];
+    const double aminx = std::min(ax1, ax2), amaxx = std::max(ax1, ax2), aminy = std::min(ay1, ay2), amaxy = std::max(ay1, ay2);
+    const double bminx = std::min(bx1, bx2), bmaxx = std::max(bx1, bx2), bminy = std::min(by1, by2), bmaxy = std::max(by1, by2);
+    if (bminx - amaxx > 1e-9 || aminx - bmaxx > 1e-9 || bminy - amaxy > 1e-9 || aminy - bmaxy > 1e-9)
+        return false;
+    const double a1 = ay2 - ay1;
+    const double b1 = ax1 - ax2;
+    const double c1 = a1 * ax1 + b1 * ay1;
+    const double a2 = by2 - by1;
+    const double b2 = bx1 - bx2;
+    const double c2 = a2 * bx1 + b2 * by1;
+    const double det = a1 * b2 - a2 * b1;
+    if (zero_eps(det))
+        return false;
+    const double x = (b2 * c1 - b1 * c2) / det;
+    const double y = (a1 * c2 - a2 * c1) / det;
+    return le_eps(aminx, x) && le_eps(x, amaxx) && le_eps(aminy, y) && le_eps(y, amaxy) && le_eps(bminx, x) && le_eps(x, bmaxx) &&
+           le_eps(bminy, y) && le_eps(y, bmaxy);
+}
+
+// PointInPolygon, concave_fitting.cpp:393-423, over the hull's vertex list as the walk left it (closed or not; consecutive
+// pairs only, no wrap) -- with its quirk: a point whose ray towards +x crosses NO edge counts as inside (:416-417), so a
+// hull may leave points out on its right and still pass.
+bool point_in_hull(const vector2& p, const std::vector<vector2>& pts, const std::vector<size_t>& hull)
+{
+    if (hull.size() <= 2)
+        return false;
+    const double x = p[0], y = p[1];
+    int inout = 0;
+    for (size_t v = 0; v + 1 < hull.size(); ++v)
+    {
+        const vector2 &q0 = pts[hull[v]], &q1 = pts[hull[v + 1]];
+        if (((le_eps(q0[1], y) && lt_eps(y, q1[1])) || (le_eps(q1[1], y) && lt_eps(y, q0[1]))) && !zero_eps(q1[1] - q0[1]) &&
+            lt_eps(x, q0[0] + ((q1[0] - q0[0]) * (y - q0[1]) / (q1[1] - q0[1]))))
+            inout++;
+    }
+    if (inout == 0)
+        return true;
+    return inout % 2 != 0;
+}
+
+// FindMinYPoint, concave_fitting.cpp:231-243: std::min_element under (y ascending, then x DESCENDING), comparisons with the slack
+size_t find_min_y_point(const std::vector<vector2>& pts)
+{
+    size_t smallest = 0;
+    for (size_t i = 1; i < pts.size(); ++i)
+    {
+        const vector2 &a = pts[i], &b = pts[smallest];
+        const bool less = eq_eps(a[1], b[1]) ? gt_eps(a[0], b[0]) : lt_eps(a[1], b[1]);
+        if (less)
+            smallest = i;
+    }
+    return smallest;
+}
+
+// One run of the Moreira-Santos k-nearest-neighbours walk, ConcaveHull of concave_fitting.cpp:93-183, for one k.  `h` receives
+// the hull as point indices exactly as the reference's vector holds it: it ends with the start point again when the walk came
+// back to it, and holds every point once when it ran out of points first (:126: `hull.size() != pointList.size()`).
+// Two restatements, both forced by what the device can reproduce bit for bit:
+//  * FLANN's approximate search over randomized kd-trees (:109-111, :258-288) is the EXACT k nearest visible points, nearest
+//    first, ordered by ONE 64-bit key -- the squared distance's bit pattern (>= +0: the bits order like the value) with its
+//    ten lowest mantissa bits replaced by the point index: ties, and distances within 2^-42 of each other, go to the smaller
+//    index (the device picks a neighbour with a single wave-wide minimum of that key; sets beyond its 1 024 points keep the
+//    plain (distance, index) order).  The start point re-enters the index at step 4 under its own index (the reference gives
+//    the copy the id n, :131: that only matters to an exact distance tie).
+//  * SortByAngle (:296-315) orders the candidates by `-atan2` angles, descending, with the slack.  Here the clockwise turn
+//    from the previous edge is never computed as an angle: a class (same direction / less than half a turn / opposite / more)
+//    from the signs of one cross and one dot product, and inside a class one more cross product -- additions,
+//    multiplications and comparisons only, scanned nearest-first (the reference's sort of <= 16 candidates is an insertion
+//    sort: equal angles stay nearest-first there too).  An atan2 from glibc and one from ocml need not agree on two
+//    candidates a rounding error apart; these predicates do.  prevAngle = 0 (:122) is the +x direction, and so is the
+//    "direction" of a duplicate of the current point (atan2(+0, +0) = 0).
+bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std::vector<size_t>& h)
 {
     const size_t n = pts.size();
-    hull.clear();
+    h.clear();
     if (n < 3)
-        return false;
+        return true; // (:97-100)
     if (n == 3)
     {
-        hull = pts;
+        h = {0, 1, 2}; // (:101-105)
         return true;
     }
-    k = std::min(std::max<size_t>(k, 3), n - 1);
-    std::vector<char> used(n, 0);
-    size_t first = 0;
-    for (size_t i = 1; i < n; ++i)
-        if (pts[i][1] < pts[first][1] || (pts[i][1] == pts[first][1] && pts[i][0] < pts[first][0]))
-            first = i;
-    std::vector<size_t> h {first};
-    used[first] = 1;
+    std::vector<char> removed(n, 0);
+    h.push_back(first);
+    removed[first] = 1;
     size_t current = first;
-    double prevX = -1.0, prevY = 0.0; // walking direction so far: pointing west, the first turn is taken clockwise from it
+    double prevX = 1.0, prevY = 0.0;
     size_t step = 1;
-    size_t remaining = n - 1;
-    // nearest-first order of the candidates: by the squared distance's bit pattern (>= +0: the bits order like the value)
-    // with its ten lowest mantissa bits replaced by the point index -- a single 64-bit key, which is what lets the device
-    // hull (csrc/cape_polygon.hip) pick a neighbour with ONE wave-wide minimum; ties and distances within 2^-42 of each other
-    // go to the smaller index.  (Point sets beyond the device's 1 024 points keep the plain (distance, index) order.)
     std::vector<std::pair<uint64_t, size_t>> cand; // reused from step to step
     cand.reserve(n);
-    while ((current != first || step == 1) && remaining + (step > 3 ? 1 : 0) > 0)
+    while ((!points_equal(pts[current], pts[first]) || step == 1) && h.size() != n)
     {
         if (step == 4)
-            used[first] = 0; // the start point becomes reachable again once the hull has three edges
-        // k nearest unused neighbours of the current point
+            removed[first] = 0; // the start point is put back into the index once the hull has three edges (:128-134)
+        // k nearest visible neighbours of the current point (itself removed; a duplicate of it is a neighbour at distance 0)
         cand.clear();
         for (size_t i = 0; i < n; ++i)
-            if (!used[i] && i != current)
+            if (!removed[i])
             {
-                const double dx = pts[i][0] - pts[current][0], dy = pts[i][1] - pts[current][1];
+                const double dx = pts[current][0] - pts[i][0], dy = pts[current][1] - pts[i][1];
                 const double d2 = dx * dx + dy * dy;
                 uint64_t bits;
                 std::memcpy(&bits, &d2, sizeof bits);
                 cand.emplace_back(n <= 1024 ? ((bits & ~uint64_t(1023)) | static_cast<uint64_t>(i)) : bits, i);
             }
-        if (cand.empty())
-            break;
         const size_t kk = std::min(k, cand.size());
         std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
         cand.resize(kk);
-        // Candidates by decreasing clockwise turn from the previous edge, the first whose edge crosses no hull edge wins.  The
-        // turn is never computed as an angle: a class (same direction / less than half a turn / opposite / more) from the
-        // signs of one cross and one dot product, and inside a class one more cross product.  Additions, multiplications and
-        // comparisons only, scanned in nearest-first order -- so the device hull (csrc/cape_polygon.hip), which runs the very
-        // same statements, picks the same vertex even when two candidates are a rounding error apart (an atan2 from glibc
-        // and one from ocml need not agree there).
         auto turn_class = [&](double vx, double vy) {
             const double cr = prevX * vy - prevY * vx, dt = prevX * vx + prevY * vy;
             if (cr < 0)
@@ -168,8 +237,10 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
         for (size_t c = 0; c < kc; ++c)
         {
             const size_t i = cand[c].second;
-            cs[c] = {i, pts[i][0] - pts[current][0], pts[i][1] - pts[current][1], 0};
-            cs[c].cls = turn_class(cs[c].vx, cs[c].vy);
+            double vx = pts[i][0] - pts[current][0], vy = pts[i][1] - pts[current][1];
+            if (vx == 0 && vy == 0)
+                vx = 1.0;
+            cs[c] = {i, vx, vy, turn_class(vx, vy)};
         }
         auto turns_further = [](const Cand& a, const Cand& b) {
             if (a.cls != b.cls)
@@ -193,16 +264,12 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
             }
             tried |= 1u << best;
             const size_t cnd = cs[best].idx;
+            // (:146-163) the candidate edge against the hull edges (h[e], h[e+1]), e = h.size()-3 .. lastPoint: not the edge that
+            // ends at the current point, and not the first edge when the candidate is the start point
+            const size_t lastPoint = points_equal(pts[cnd], pts[first]) ? 1 : 0;
             bool its = false;
-            const size_t last = (cnd == first) ? 1 : 0;
-            for (size_t j = last; j + 2 < h.size() + 1 && !its; ++j)
-            {
-                if (j + 1 >= h.size())
-                    break;
-                if (j + 1 == h.size() - 1)
-                    continue; // the edge that ends at the current point shares it with the candidate edge
-                its = segments_intersect(pts[current], pts[cnd], pts[h[j]], pts[h[j + 1]]);
-            }
+            for (size_t e = lastPoint; e + 2 < h.size() && !its; ++e)
+                its = hull_edges_intersect(pts[current], pts[cnd], pts[h[e]], pts[h[e + 1]]);
             if (!its)
             {
                 found = true;
@@ -210,61 +277,67 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t k, std::vector<vecto
             }
         }
         if (!found)
-            return false;
-        if (next == first)
-        {
-            current = first;
-            break;
-        }
-        prevX = pts[current][0] - pts[next][0]; // looking back along the new edge
+            return false; // every candidate crosses the hull (:166-169), or none is left
+        prevX = pts[current][0] - pts[next][0]; // Angle(hull[step], hull[step - 1]) (:174): looking back along the new edge
         prevY = pts[current][1] - pts[next][1];
+        if (prevX == 0 && prevY == 0)
+            prevX = 1.0;
         current = next;
         h.push_back(current);
-        used[current] = 1;
-        --remaining;
+        removed[current] = 1;
         ++step;
     }
-    if (current != first || h.size() < 3)
-        return false;
-    hull.reserve(h.size());
+    // every point that is not a hull vertex must pass PointInPolygon (:176-182)
+    std::vector<char> onHull(n, 0);
     for (size_t i : h)
-        hull.push_back(pts[i]);
-    // every input point must lie inside or on the hull
+        onHull[i] = 1;
     for (size_t i = 0; i < n; ++i)
-        if (!used[i] && !point_in_ring(pts[i], hull, true))
+        if (!onHull[i] && !point_in_hull(pts[i], pts, h))
             return false;
     return true;
 }
 
-void douglas_peucker(const std::vector<vector2>& in, size_t a, size_t b, double eps, std::vector<char>& keep)
+// squared distance of p to the SEGMENT (a, b): boost::geometry's projected_point strategy in its comparable form, the
+// measure of its Douglas-Peucker (strategy::simplify::douglas_peucker)
+double segment_distance2(const vector2& p, const vector2& a, const vector2& b)
+{
+    const double vx = b[0] - a[0], vy = b[1] - a[1], wx = p[0] - a[0], wy = p[1] - a[1];
+    const double c1 = wx * vx + wy * vy;
+    if (c1 <= 0)
+        return wx * wx + wy * wy;
+    const double c2 = vx * vx + vy * vy;
+    if (c2 <= c1)
+    {
+        const double ux = p[0] - b[0], uy = p[1] - b[1];
+        return ux * ux + uy * uy;
+    }
+    const double t = c1 / c2;
+    const double qx = a[0] + t * vx, qy = a[1] + t * vy;
+    return (p[0] - qx) * (p[0] - qx) + (p[1] - qy) * (p[1] - qy);
+}
+
+// boost::geometry::simplify's Douglas-Peucker: the farthest point from the segment between the two kept ends (squared
+// distances, the first of equal maxima), kept when it lies further than the threshold
+void douglas_peucker(const std::vector<vector2>& in, size_t a, size_t b, double eps2, std::vector<char>& keep)
 {
     if (b <= a + 1)
         return;
     double dmax = -1;
     size_t idx = a;
-    const double dx = in[b][0] - in[a][0], dy = in[b][1] - in[a][1];
-    const double len = std::sqrt(dx * dx + dy * dy);
     for (size_t i = a + 1; i < b; ++i)
     {
-        double d;
-        if (len == 0)
-        {
-            const double ex = in[i][0] - in[a][0], ey = in[i][1] - in[a][1];
-            d = std::sqrt(ex * ex + ey * ey); // (not std::hypot: its rounding is the library's business, sqrt's is IEEE's)
-        }
-        else
-            d = std::abs(dx * (in[a][1] - in[i][1]) - (in[a][0] - in[i][0]) * dy) / len;
+        const double d = segment_distance2(in[i], in[a], in[b]);
         if (d > dmax)
         {
             dmax = d;
             idx = i;
         }
     }
-    if (dmax > eps)
+    if (dmax > eps2)
     {
         keep[idx] = 1;
-        douglas_peucker(in, a, idx, eps, keep);
-        douglas_peucker(in, idx, b, eps, keep);
+        douglas_peucker(in, a, idx, eps2, keep);
+        douglas_peucker(in, idx, b, eps2, keep);
     }
 }
 
@@ -398,32 +471,41 @@ std::vector<vector2> Polygon::compute_convex_hull(const std::vector<vector2>& in
         h[k++] = p[i - 1];
     }
     h.resize(k - 1);
-    std::reverse(h.begin(), h.end()); // clockwise like boost's default polygon
+    std::reverse(h.begin() + 1, h.end()); // clockwise like boost's default polygon, still starting at the leftmost point
     return h;
 }
 
-std::vector<vector2> Polygon::compute_concave_hull(const std::vector<vector2>& in) noexcept
+// Polygon::compute_concave_hull (polygon.cpp:283-318) over ::polygon::compute_concave_hull (concave_fitting.cpp:69-90, the
+// overload that takes a non-const vector: RemoveDuplicates of the other one does NOT run on this path) plus the repair the
+// constructor applies to its result (polygon.cpp:195-226 with third_party/correct_boost_polygon.hpp:188-195, :172-186): the
+// walk leaves a counter-clockwise ring that starts -- and, when it closed, ends -- at the lowest point; Boost wants it closed
+// and clockwise.  Returned open (no repeated vertex), clockwise, starting at the walk's start point; empty when no rung of
+// the ladder has a hull.
+std::vector<vector2> Polygon::compute_concave_hull(const std::vector<vector2>& pts) noexcept
 {
-    std::vector<vector2> pts = in;
-    std::sort(pts.begin(), pts.end());
-    pts.erase(std::unique(pts.begin(), pts.end()), pts.end()); // RemoveDuplicates
     std::vector<vector2> hull;
     if (pts.size() < 3)
         return hull;
-    // third_party/concave_fitting.cpp: k = 3, then the prime ladder, at most 8 attempts
+    // k = 3, then the prime ladder, at most 8 attempts (:72-88)
     static const size_t ladder[] = {3, 3, 5, 7, 11, 13, 17, 21};
-    for (size_t k : ladder)
+    const size_t first = find_min_y_point(pts);
+    std::vector<size_t> h;
+    bool ok = false;
+    for (size_t a = 0; a < 8 && !ok; ++a)
     {
-        if (concave_hull_k(pts, k, hull) && ring_is_simple(hull))
-        {
-            if (ring_area_signed(hull) > 0)
-                std::reverse(hull.begin(), hull.end());
-            return hull;
-        }
-        if (k > pts.size())
-            break;
+        ok = concave_hull_k(pts, first, ladder[a], h);
+        if (!ok && a + 1 < 8 && ladder[a + 1] > pts.size())
+            break; // (:86-87: the next k exceeds the point count)
     }
-    hull.clear();
+    if (!ok)
+        return hull;
+    if (h.size() > 1 && points_equal(pts[h.back()], pts[h.front()]))
+        h.pop_back(); // the closing vertex
+    hull.reserve(h.size());
+    for (size_t i : h)
+        hull.push_back(pts[i]);
+    if (hull.size() >= 3 && ring_area_signed(hull) > 0)
+        std::reverse(hull.begin() + 1, hull.end()); // clockwise, still starting at the walk's start point
     return hull;
 }
 
@@ -441,8 +523,10 @@ Polygon::Polygon(const std::vector<vector3>& points, const vector3& normal, cons
     for (auto it = points.rbegin(); it != points.rend(); ++it) // the reference projects in reverse order
         projected.push_back(get_projected_plan_coordinates(*it, _center, _xAxis, _yAxis));
     _ring = compute_concave_hull(projected);
+    // A hull that touches or crosses itself is dissolved into sub-rings and re-united with Boost set operations in the
+    // reference (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull (polygon.cpp:200-207)
     if (!is_valid())
-        _ring = compute_convex_hull(projected); // the reference first tries boost's `correct`, then this fallback
+        _ring = compute_convex_hull(projected);
     _area = area();
     simplify();
 }
@@ -920,7 +1004,7 @@ void Polygon::simplify(const double distanceThreshold) noexcept
         closed.push_back(ring.front());
         std::vector<char> keep(closed.size(), 0);
         keep.front() = keep.back() = 1;
-        douglas_peucker(closed, 0, closed.size() - 1, eps, keep);
+        douglas_peucker(closed, 0, closed.size() - 1, eps * eps, keep);
         std::vector<vector2> out;
         for (size_t i = 0; i + 1 < closed.size(); ++i)
             if (keep[i])
