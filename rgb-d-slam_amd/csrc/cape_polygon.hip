@@ -9,8 +9,8 @@
 // convex-hull fallback (:268-281), area (:453-461) and simplify (:578-601).  The statements are those of this repo's
 // dependency-free host class (host/boundary_polygon.cpp), in the same operation order: + - x / and comparisons only (no libm
 // call whose rounding could differ between glibc and ocml), so the vertices are compared BIT FOR BIT against the host class
-// (tests/test_gpu_polygon.py) -- and both against oracle/polygon_oracle.cpp, the independent restatement of the reference's
-// files (tests/test_gpu_polygon_oracle.py).  Two things cannot be the reference's: FLANN's approximate search over randomized
+// (tests/test_gpu_polygon.py) -- and both against the test suite's independent restatement of the reference's files
+// (tests/test_gpu_polygon_oracle.py).  Two things cannot be the reference's: FLANN's approximate search over randomized
 // kd-trees (here: the exact k nearest points) and the `-atan2` ordering of the candidates (here: exact turn predicates, which
 // order like the angles and cannot disagree between host and device on a near-tie).
 //
