@@ -170,6 +170,70 @@ def parity_check(ex, frames_host, intr, cylinders, n):
             "checker": "oracle/libcape_oracle.so on the first frames of the last timed step"}
 
 
+def polygon_check(ex, n):
+    """In-run check of rows N1 / N2 (checker only, outside every timed region): the device polygons of the first n frames of
+    the last batch and the polygon matches between them against the oracle of the reference's algorithm
+    (oracle/polygon_oracle.cpp: concave_fitting.cpp + polygon.cpp + MapPlane::find_matches restated)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import cape_amd
+    import polygon_oracle_py as P
+
+    P.build()
+    res = ex.results(n)
+    pol, ver = ex.polygons(n)
+    got = ex.polygon_matches(n)
+    out = dict(frames=n, planes=0, vertex_identical=0, iou_below_0999=0, validity_mismatches=0, reference_would_dissolve=0,
+               frame_pairs=0, match_decision_mismatches=0, matches=0)
+    kept, skip = [], set()
+    for f in range(n):
+        planes = []
+        for i, s in enumerate(res.segments(f)):
+            if not s["is_output"]:
+                continue
+            c0 = np.asarray(s["normal"], np.float64) * (-np.float64(s["d"]))
+            ref = P.Polygon.from_points(res.boundary_points(f, s), s["normal"], c0)
+            out["planes"] += 1
+            if ref.flags & P.NEEDS_DISSOLVE:
+                out["reference_would_dissolve"] += 1
+                skip.add(f)
+                continue
+            p = pol[f, i]
+            dev_valid = bool(p["flags"] & cape_amd.POLY_VALID) and int(p["vertex_count"]) >= 3
+            ref_valid = (not ref.threw) and ref.valid and ref.boundary_length() >= 3
+            if ref_valid:
+                planes.append((i, np.asarray(s["out_normal"], np.float64), float(s["d"]), ref))
+            if dev_valid != ref_valid:
+                out["validity_mismatches"] += 1
+                skip.add(f)
+                continue
+            if not dev_valid:
+                continue
+            o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+            verts = ver[f, o:o + c]
+            if len(verts) == len(ref.ring) and np.array_equal(verts, ref.ring):
+                out["vertex_identical"] += 1
+                continue
+            d = P.Polygon(verts, p["x_axis"], p["y_axis"], p["center"])
+            inter = d.inter_area(ref)
+            if inter / (d.area + ref.area - inter) < 0.999:
+                out["iou_below_0999"] += 1
+        kept.append(planes)
+    for f in range(1, n):
+        if f in skip or (f - 1) in skip or (got[f]["flags"] & cape_amd.MATCH_EXACT_OVERFLOW):
+            continue
+        prev, cur = kept[f - 1], kept[f]
+        want, _ = P.find_matches([q[1:] for q in prev], [q[1:] for q in cur])
+        out["frame_pairs"] += 1
+        out["matches"] += sum(1 for m in want if m >= 0)
+        if list(got[f]["match"][: len(prev)]) != want:
+            out["match_decision_mismatches"] += 1
+    out["ok"] = out["iou_below_0999"] == 0 and out["validity_mismatches"] == 0 and out["match_decision_mismatches"] == 0
+    out["checker"] = "oracle/polygon_oracle.cpp (the reference's concave hull / polygon / find_matches restated; pinned by the reference's tests/test_polygons.cpp)"
+    return out
+
+
 def parity_ok(pc):
     return bool(pc["labels_equal"] and pc["counts_equal"] and pc["segments_bitwise"] and pc["cylinders_bitwise"])
 
@@ -584,7 +648,7 @@ def main():
         ms = e0.elapsed_time(e1) / kp
         polygons_leg = {"ms_per_batch": ms, "planes": n_pl, "planes_per_s": n_pl / (ms * 1e-3), "frames_per_s": B / (ms * 1e-3),
                         "note": "cape_build_polygons over the batch's output planes; vertices bit-identical to the host class "
-                                "(tests/test_gpu_polygon.py), which builds ~80 k polygons/s on one core"}
+                                "(tests/test_gpu_polygon.py) and to the oracle of the reference's algorithm (tests/test_gpu_polygon_oracle.py)"}
         # "Next" row N2 on those polygons: the reference's intersection areas between consecutive frames (cape_match_polygons)
         ex.match_polygons(B, 0, stream)
         torch.cuda.synchronize()
@@ -665,6 +729,54 @@ def main():
         for e in pair:
             e.close()
         out["cylinders_on"] = cyl
+        # What Primitive_Detection::find_primitives RETURNS (primitive_detection.cpp:119-166, ending in add_planes_to_primitives
+        # :562-648): planes WITH their boundary polygons, the cylinder branch on -- plus the consumer's next step on them,
+        # MapPlane::find_matches between consecutive frames.  ONE timed region: extract + polygons + matches per step.
+        ex3 = Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, **intr)
+
+        def full_step():
+            ex3.extract_device(depth.data_ptr(), B, stream)
+            ex3.build_polygons(B, stream)
+            ex3.match_polygons(B, 0, stream)
+
+        for _ in range(3):
+            full_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            full_step()
+        torch.cuda.synchronize()
+        e4 = time.perf_counter() - t0
+        # the same step once more with events between the three calls (outside the timed region): where the time goes
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        parts = np.zeros(3)
+        for _ in range(5):
+            evs[0].record()
+            ex3.extract_device(depth.data_ptr(), B, stream)
+            evs[1].record()
+            ex3.build_polygons(B, stream)
+            evs[2].record()
+            ex3.match_polygons(B, 0, stream)
+            evs[3].record()
+            torch.cuda.synchronize()
+            parts += [evs[i].elapsed_time(evs[i + 1]) for i in range(3)]
+        parts /= 5
+        n_pl, n_cy, _ = ex3.count_primitives(B)
+        fpe = {"value": B * k2 / e4, "unit": "frames/s", "steps": k2, "ms_per_step": 1e3 * e4 / k2,
+               "call_ms": {"cape_extract (A1 + A2 + B, cylinder branch on)": float(parts[0]), "cape_build_polygons": float(parts[1]),
+                           "cape_match_polygons": float(parts[2])},
+               "planes_per_batch": n_pl, "cylinders_per_batch": n_cy,
+               "workload": f"the same {W}x{H} room stream: everything find_primitives returns (planes with boundary polygons, cylinders) "
+                           "+ find_matches between consecutive frames, one timed region"}
+        if not args.no_parity_check:
+            pc4 = parity_check(ex3, unique_dev[:16].cpu().numpy(), intr, True, 16)
+            fpe["parity_check"] = pc4
+            fpe["polygon_check"] = polygon_check(ex3, 32)
+            if not parity_ok(pc4) or not fpe["polygon_check"]["ok"]:
+                print(f"bench.py: find_primitives_equivalent results differ from the oracles: {pc4} {fpe['polygon_check']}", file=sys.stderr)
+                raise SystemExit(3)
+        ex3.close()
+        out["find_primitives_equivalent"] = fpe
     if out is not None and polygons_leg is not None:
         out["boundary_polygons"] = polygons_leg
     result_line = json.dumps(out) if out is not None else None
