@@ -401,6 +401,13 @@ typedef struct cape_frame_match_exact
 } cape_frame_match_exact;
 /* flags: CAPE_MATCH_ADVANCED, CAPE_MATCH_ALLOW_INDEX0 as for cape_match_consecutive.  Asynchronous on `stream`. */
 int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* stream);
+/* The same with the camera motion between consecutive frames -- what the reference does before its gates: the map plane goes
+ * through PlaneWorldCoordinates::to_camera_coordinates (map_primitive.cpp:100-101, plane_coordinates.cpp:20-24 with the plane
+ * matrix of camera_transformation.cpp:53-71) and its polygon through WorldPolygon::to_camera_space (map_primitive.cpp:103,
+ * polygon_coordinates.cpp:135-165) with `worldToCamera`.  Here the map is frame f-1: prev_to_cur = n_frames x 16 doubles in
+ * HOST memory (read before the call returns), row-major 4x4 [R t; 0 0 0 1], entry f taking a point of camera f-1's frame into
+ * camera f's; entry 0 is not read.  NULL = the identity = cape_match_polygons (a static camera). */
+int cape_match_polygons_pose(cape_handle h, int32_t n_frames, const double* prev_to_cur, uint32_t flags, void* stream);
 int cape_copy_polygon_matches(cape_handle h, int32_t n_frames, cape_frame_match_exact* out);
 
 /* A stream of the handle's device for callers that do not link the HIP runtime themselves (the overlay): non-blocking, so the

@@ -218,6 +218,7 @@ struct cape_handle_s
     uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
     int matchExactFrames = 0;       // frames of the last cape_match_polygons (0: none for the current batch)
+    double* matchPoses = nullptr;   // cape_match_polygons_pose: max_batch x 16 doubles, allocated on first use
     cape_frame_match_exact* matchesExact = nullptr;
     unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 3 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
@@ -270,6 +271,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->polyLadder);
     (void)hipFree(h->matchesExact);
     (void)hipFree(h->matchLists);
+    (void)hipFree(h->matchPoses);
     if (h->resultsOnHost)
     {
         if (h->polygons)
@@ -1840,7 +1842,19 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     return CAPE_OK;
 }
 
+static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* prev_to_cur, uint32_t flags, void* stream_);
+
 int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* stream_)
+{
+    return match_polygons_impl(h, n_frames, nullptr, flags, stream_);
+}
+
+int cape_match_polygons_pose(cape_handle h, int32_t n_frames, const double* prev_to_cur, uint32_t flags, void* stream_)
+{
+    return match_polygons_impl(h, n_frames, prev_to_cur, flags, stream_);
+}
+
+static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* prev_to_cur, uint32_t flags, void* stream_)
 {
     if (!h || n_frames < 0)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle or negative frame count");
@@ -1861,6 +1875,14 @@ int cape_match_polygons(cape_handle h, int32_t n_frames, uint32_t flags, void* s
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
     cape::MatchPolygonParams p;
+    if (prev_to_cur)
+    {
+        // the poses travel to the device in the caller's memory order: n_frames x 16 doubles (entry 0 is never read)
+        if (!h->matchPoses)
+            CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchPoses), (size_t)h->cfg.max_batch * 16 * sizeof(double)));
+        CAPE_HIP_TRY(hipMemcpyAsync(h->matchPoses, prev_to_cur, (size_t)n_frames * 16 * sizeof(double), hipMemcpyHostToDevice, stream));
+        p.poses = h->matchPoses;
+    }
     p.records = h->records;
     p.polygons = h->polygons;
     p.vertices = reinterpret_cast<const double2*>(h->polyVertices);

@@ -163,6 +163,7 @@ struct MatchPolygonParams
     int computeUnits;
     uint32_t flags;
     double minCosAngle, maxDistance, minOverlap; // as MatchParams
+    const double* poses = nullptr; // cape_match_polygons_pose: frames x 16, row-major [R t; 0 0 0 1] from camera f-1 to camera f; null = identity
 };
 
 // multi-GPU gather: device-side packing of the ragged primitive lists (cape_gather.hip)

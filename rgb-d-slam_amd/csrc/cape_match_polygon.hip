@@ -494,6 +494,23 @@ __global__ __launch_bounds__(64 * kGateFrames) void cape_polygon_gate_kernel(Mat
     {
         const cape_plane_segment& Q = p.records[frame - 1].segments[segP];
         pn[0] = Q.out_normal[0], pn[1] = Q.out_normal[1], pn[2] = Q.out_normal[2], pd = Q.d;
+        if (p.poses)
+        {
+            // the map plane seen from this frame's camera: PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24)
+            // with the plane matrix of camera_transformation.cpp:53-71, [R 0; -t^T R 1]; the PlaneCameraCoordinates constructor
+            // normalises the rotated normal (host: utils::plane_to_camera)
+            const double* T = p.poses + (size_t)frame * 16;
+            const double r0 = (T[0] * pn[0] + T[1] * pn[1]) + T[2] * pn[2], r1 = (T[4] * pn[0] + T[5] * pn[1]) + T[6] * pn[2],
+                         r2 = (T[8] * pn[0] + T[9] * pn[1]) + T[10] * pn[2];
+            const double t0 = T[3], t1 = T[7], t2 = T[11];
+            const double m0 = -((t0 * T[0] + t1 * T[4]) + t2 * T[8]), m1 = -((t0 * T[1] + t1 * T[5]) + t2 * T[9]),
+                         m2 = -((t0 * T[2] + t1 * T[6]) + t2 * T[10]);
+            pd = ((m0 * pn[0] + m1 * pn[1]) + m2 * pn[2]) + pd;
+            const double nn = sqrt((r0 * r0 + r1 * r1) + r2 * r2);
+            pn[0] = r0, pn[1] = r1, pn[2] = r2;
+            if (nn > 0)
+                pn[0] = r0 / nn, pn[1] = r1 / nn, pn[2] = r2 / nn;
+        }
     }
     unsigned long long gatedMask[MP * MP / 64];
     bool mine[MP * MP / 64];
@@ -593,12 +610,58 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                 L.ringA[v] = vertsC[v];
             // Polygon::project (polygon.cpp:338-382): every vertex of the previous plane's ring lifted to 3-D and expressed in
             // the frame of plane i; the projected ring is re-oriented clockwise like every polygon (OpenRing constructor)
+            // the frame the previous plane's polygon lives in: its own, or -- with a pose -- the one to_camera_space gives it
+            // (polygon_coordinates.cpp:135-165: centre through the transform, axes through its rotation and re-normalised)
+            double qc[3] = {PQ.center[0], PQ.center[1], PQ.center[2]}, qx[3] = {PQ.x_axis[0], PQ.x_axis[1], PQ.x_axis[2]},
+                   qy[3] = {PQ.y_axis[0], PQ.y_axis[1], PQ.y_axis[2]};
+            if (p.poses)
+            {
+                const double* T = p.poses + (size_t)frame * 16;
+                double nc[3], nx[3], ny[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                {
+                    nc[r] = ((T[4 * r] * qc[0] + T[4 * r + 1] * qc[1]) + T[4 * r + 2] * qc[2]) + T[4 * r + 3];
+                    nx[r] = (T[4 * r] * qx[0] + T[4 * r + 1] * qx[1]) + T[4 * r + 2] * qx[2];
+                    ny[r] = (T[4 * r] * qy[0] + T[4 * r + 1] * qy[1]) + T[4 * r + 2] * qy[2];
+                }
+                const double lx = sqrt((nx[0] * nx[0] + nx[1] * nx[1]) + nx[2] * nx[2]), ly = sqrt((ny[0] * ny[0] + ny[1] * ny[1]) + ny[2] * ny[2]);
+                if (lx > 0)
+                    nx[0] /= lx, nx[1] /= lx, nx[2] /= lx;
+                if (ly > 0)
+                    ny[0] /= ly, ny[1] /= ly, ny[2] /= ly;
+                // transform_boundary (polygon.cpp:430-451): every vertex lifted to 3-D, moved, re-expressed in the new frame; then the
+                // explicit-ring constructor's orientation fix (polygon.cpp:236-266)
+                for (int v = lane; v < nb; v += 64)
+                {
+                    const double2 q = vertsP[v];
+                    const double X = qc[0] + q.x * qx[0] + q.y * qy[0], Y = qc[1] + q.x * qx[1] + q.y * qy[1], Z = qc[2] + q.x * qx[2] + q.y * qy[2];
+                    const double mx = ((T[0] * X + T[1] * Y) + T[2] * Z) + T[3], my = ((T[4] * X + T[5] * Y) + T[6] * Z) + T[7],
+                                 mz = ((T[8] * X + T[9] * Y) + T[10] * Z) + T[11];
+                    const double dx = mx - nc[0], dy = my - nc[1], dz = mz - nc[2];
+                    L.ringB[v] = make_double2((nx[0] * dx + nx[1] * dy) + nx[2] * dz, (ny[0] * dx + ny[1] * dy) + ny[2] * dz);
+                }
+                CAPE_MP_SYNC();
+                if (ring_area_signed(L.ringB, nb) > 0)
+                {
+                    for (int v = lane; v < nb / 2; v += 64)
+                    {
+                        const double2 a = L.ringB[v], b = L.ringB[nb - 1 - v];
+                        L.ringB[v] = b;
+                        L.ringB[nb - 1 - v] = a;
+                    }
+                    CAPE_MP_SYNC();
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    qc[r] = nc[r], qx[r] = nx[r], qy[r] = ny[r];
+            }
             for (int v = lane; v < nb; v += 64)
             {
-                const double2 q = vertsP[v];
-                const double X = PQ.center[0] + q.x * PQ.x_axis[0] + q.y * PQ.y_axis[0];
-                const double Y = PQ.center[1] + q.x * PQ.x_axis[1] + q.y * PQ.y_axis[1];
-                const double Z = PQ.center[2] + q.x * PQ.x_axis[2] + q.y * PQ.y_axis[2];
+                const double2 q = p.poses ? L.ringB[v] : vertsP[v];
+                const double X = qc[0] + q.x * qx[0] + q.y * qy[0];
+                const double Y = qc[1] + q.x * qx[1] + q.y * qy[1];
+                const double Z = qc[2] + q.x * qx[2] + q.y * qy[2];
                 const double dx = X - PS.center[0], dy = Y - PS.center[1], dz = Z - PS.center[2];
                 L.ringB[v] = make_double2((PS.x_axis[0] * dx + PS.x_axis[1] * dy) + PS.x_axis[2] * dz,
                                           (PS.y_axis[0] * dx + PS.y_axis[1] * dy) + PS.y_axis[2] * dz);

@@ -675,6 +675,51 @@ bool Polygon::contains(const vector2& point) const noexcept
 
 vector3 Polygon::get_normal() const noexcept { return cross(_xAxis, _yAxis); }
 
+namespace {
+inline vector3 apply44(const double* T, const vector3& p)
+{
+    return {((T[0] * p[0] + T[1] * p[1]) + T[2] * p[2]) + T[3], ((T[4] * p[0] + T[5] * p[1]) + T[6] * p[2]) + T[7],
+            ((T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]) + T[11]};
+}
+inline vector3 rotate44(const double* T, const vector3& p)
+{
+    return {(T[0] * p[0] + T[1] * p[1]) + T[2] * p[2], (T[4] * p[0] + T[5] * p[1]) + T[6] * p[2], (T[8] * p[0] + T[9] * p[1]) + T[10] * p[2]};
+}
+} // namespace
+
+void plane_to_camera(const double* normal, double d, const double* T, double* normalOut, double* dOut)
+{
+    const vector3 n {normal[0], normal[1], normal[2]};
+    const vector3 rn = rotate44(T, n);
+    const vector3 nn = normalized(rn);
+    // last row of the plane matrix: -t^T R
+    const double t0 = T[3], t1 = T[7], t2 = T[11];
+    const double m0 = -((t0 * T[0] + t1 * T[4]) + t2 * T[8]), m1 = -((t0 * T[1] + t1 * T[5]) + t2 * T[9]),
+                 m2 = -((t0 * T[2] + t1 * T[6]) + t2 * T[10]);
+    normalOut[0] = nn[0];
+    normalOut[1] = nn[1];
+    normalOut[2] = nn[2];
+    *dOut = ((m0 * n[0] + m1 * n[1]) + m2 * n[2]) + d;
+}
+
+Polygon Polygon::to_camera_space(const double* T) const
+{
+    const vector3 newCenter = apply44(T, _center);
+    const vector3 newX = normalized(rotate44(T, _xAxis)), newY = normalized(rotate44(T, _yAxis));
+    auto move_ring = [&](const std::vector<vector2>& in) {
+        std::vector<vector2> ring;
+        ring.reserve(in.size());
+        for (const vector2& q : in)
+            ring.push_back(get_projected_plan_coordinates(apply44(T, get_point_from_plane_coordinates(q, _center, _xAxis, _yAxis)), newCenter,
+                                                          newX, newY));
+        return ring;
+    };
+    Polygon out(OpenRing {}, move_ring(_ring), newX, newY, newCenter);
+    for (const auto& h : _inners)
+        out.add_hole(move_ring(h));
+    return out;
+}
+
 Polygon Polygon::transform(const vector3& nextNormal, const vector3& nextCenter) const
 {
     const auto axes = get_plane_coordinate_system(nextNormal);

@@ -29,6 +29,11 @@ std::pair<vector3, vector3> get_plane_coordinate_system(const vector3& normal);
 vector2 get_projected_plan_coordinates(const vector3& point, const vector3& center, const vector3& xAxis, const vector3& yAxis);
 vector3 get_point_from_plane_coordinates(const vector2& point, const vector3& center, const vector3& xAxis, const vector3& yAxis);
 
+// PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24) through compute_plane_world_to_camera_matrix
+// (camera_transformation.cpp:53-71): for worldToCamera = [R t] the plane matrix is [R 0; -t^T R 1], and the
+// PlaneCameraCoordinates constructor normalises the rotated normal once (plane_coordinates.hpp:19-23).
+void plane_to_camera(const double* normal, double d, const double* worldToCamera, double* normalOut, double* dOut);
+
 class Polygon
 {
   public:
@@ -67,6 +72,11 @@ class Polygon
     // the rotation being about the origin like the reference) and re-expressed in the new frame
     [[nodiscard]] Polygon transform(const vector3& nextNormal, const vector3& nextCenter) const;
     [[nodiscard]] Polygon transform(const vector3& nextXAxis, const vector3& nextYAxis, const vector3& nextCenter) const;
+    // WorldPolygon::to_camera_space (polygon_coordinates.cpp:135-165 over Polygon::transform_boundary, polygon.cpp:430-451):
+    // the polygon seen from another camera.  worldToCamera = 16 doubles, row-major [R t; 0 0 0 1]: the centre goes through
+    // the whole transform, the axes through its rotation (re-normalised), every boundary point is lifted to 3-D, moved and
+    // re-expressed in the new frame.  Same statements as the device matcher (csrc/cape_match_polygon.hip).
+    [[nodiscard]] Polygon to_camera_space(const double* worldToCamera) const;
     // Polygon::merge_union (polygon.cpp:325-336 over union_one :463-493): this polygon becomes (this U other), `other`
     // being projected into this frame first; two disjoint polygons leave the larger one (the reference keeps the biggest
     // piece of the multi-polygon), then simplify().  A region that the two outlines enclose without covering it becomes an

@@ -412,7 +412,7 @@ bool Primitive_Detection::match_consecutive(int n_frames, std::vector<cape_frame
 }
 
 bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<cape_frame_match_exact>& matches, bool useAdvancedSearch,
-                                                     bool allowIndexZero) noexcept
+                                                     bool allowIndexZero, const double* prevToCur) noexcept
 {
     try
     {
@@ -426,7 +426,7 @@ bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<c
         const uint32_t flags = (useAdvancedSearch ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
                                (allowIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
         matches.resize(n_frames);
-        if (cape_match_polygons(_shards[0].handle, n_frames, flags, nullptr) != CAPE_OK ||
+        if (cape_match_polygons_pose(_shards[0].handle, n_frames, prevToCur, flags, nullptr) != CAPE_OK ||
             cape_copy_polygon_matches(_shards[0].handle, n_frames, matches.data()) != CAPE_OK)
         {
             outputs::log_error(std::string("match_consecutive_polygons: ") + cape_last_error());

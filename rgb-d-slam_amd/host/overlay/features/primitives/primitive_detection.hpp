@@ -80,10 +80,14 @@ class Primitive_Detection
     // detected polygon's area, map_primitive.cpp:137): see cape_match_polygons.  Same residency rules; needs the device
     // polygons of the batch (set_device_polygons(true), the default).  Plane indices are those of the plane_containers
     // find_primitives_batch returned.
+    // prevToCur (optional): n_frames x 16 doubles, row-major [R t; 0 0 0 1], entry f taking camera f-1's frame into camera f's --
+    // the worldToCamera the reference hands to find_matches when the map is the previous frame (map_primitive.cpp:100-104);
+    // nullptr = a static camera (see cape_match_polygons_pose)
     bool match_consecutive_polygons(int n_frames,
                                     std::vector<cape_frame_match_exact>& matches,
                                     bool useAdvancedSearch = false,
-                                    bool allowIndexZero = false) noexcept;
+                                    bool allowIndexZero = false,
+                                    const double* prevToCur = nullptr) noexcept;
 
     [[nodiscard]] bool is_ready() const noexcept { return _single.handle != nullptr; }
 

@@ -63,3 +63,24 @@ extern "C" double cape_host_polygon_inter_area(const double* ring_a, int na, con
         *area_b_out = b.get_area();
     return a.inter_area(b);
 }
+
+// The same with the projected polygon seen through a pose first: a.inter_area(b.to_camera_space(worldToCamera))
+// (map_primitive.cpp:103 then :137); plane_in / plane_out: (nx, ny, nz, d) of the map plane before / after
+// to_camera_coordinates (map_primitive.cpp:100-101).  tests/test_gpu_match_pose.py compares cape_match_polygons_pose with it.
+extern "C" double cape_host_polygon_inter_area_pose(const double* ring_a, int na, const double* x_a, const double* y_a, const double* c_a,
+                                                    const double* ring_b, int nb, const double* x_b, const double* y_b, const double* c_b,
+                                                    const double* world_to_camera, const double* plane_in, double* plane_out)
+{
+    using rgbd_slam::vector2;
+    using rgbd_slam::vector3;
+    std::vector<vector2> ra, rb;
+    for (int i = 0; i < na; ++i)
+        ra.emplace_back(ring_a[2 * i], ring_a[2 * i + 1]);
+    for (int i = 0; i < nb; ++i)
+        rb.emplace_back(ring_b[2 * i], ring_b[2 * i + 1]);
+    const rgbd_slam::utils::Polygon a(ra, vector3(x_a[0], x_a[1], x_a[2]), vector3(y_a[0], y_a[1], y_a[2]), vector3(c_a[0], c_a[1], c_a[2]));
+    const rgbd_slam::utils::Polygon b(rb, vector3(x_b[0], x_b[1], x_b[2]), vector3(y_b[0], y_b[1], y_b[2]), vector3(c_b[0], c_b[1], c_b[2]));
+    if (plane_in && plane_out)
+        rgbd_slam::utils::plane_to_camera(plane_in, plane_in[3], world_to_camera, plane_out, plane_out + 3);
+    return a.inter_area(b.to_camera_space(world_to_camera));
+}

@@ -127,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "cape_comm_destroy", "cape_gather_primitives", "cape_gather_primitives_root", "cape_count_primitives", "cape_gather_wait", "cape_copy_results", "cape_sync_results", "cape_host_results", "cape_host_alloc", "cape_host_free", "cape_host_register",
     "cape_host_unregister", "cape_copy_cell_stats", "cape_enable_timing", "cape_get_timings",
     "cape_reset_timings", "cape_match_consecutive", "cape_device_matches", "cape_copy_matches",
-    "cape_match_polygons", "cape_copy_polygon_matches",
+    "cape_match_polygons", "cape_match_polygons_pose", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
 ]
@@ -189,6 +189,7 @@ def load_library():
     L.cape_device_matches.argtypes = [vp, C.POINTER(vp)]
     L.cape_copy_matches.argtypes = [vp, C.c_int32, vp]
     L.cape_match_polygons.argtypes = [vp, C.c_int32, C.c_uint32, vp]
+    L.cape_match_polygons_pose.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp]
     L.cape_copy_polygon_matches.argtypes = [vp, C.c_int32, vp]
     L.cape_build_polygons.argtypes = [vp, C.c_int32, vp]
     L.cape_device_polygons.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -373,6 +374,12 @@ class Extractor:
     # ---- N2 on the boundary polygons (exact intersection areas; needs build_polygons of the batch first) ----
     def match_polygons(self, n_frames, flags=0, stream=0):
         _check(self.L, self.L.cape_match_polygons(self.h, n_frames, flags, C.c_void_p(stream)), "cape_match_polygons")
+
+    def match_polygons_pose(self, n_frames, prev_to_cur, flags=0, stream=0):
+        """prev_to_cur: n_frames x 4 x 4 (row-major [R t; 0 0 0 1]); entry f takes camera f-1's frame into camera f's."""
+        T = np.ascontiguousarray(prev_to_cur, np.float64).reshape(n_frames, 16)
+        _check(self.L, self.L.cape_match_polygons_pose(self.h, n_frames, T.ctypes.data_as(C.c_void_p), flags, C.c_void_p(stream)),
+               "cape_match_polygons_pose")
 
     def polygon_matches(self, n_frames):
         out = np.zeros(n_frames, MATCH_EXACT_DTYPE)

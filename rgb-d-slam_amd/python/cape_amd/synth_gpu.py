@@ -35,6 +35,23 @@ def _poses(scene, seed, start, n):
     return out
 
 
+def relative_poses(scene, seed, frames):
+    """4 x 4 transforms between consecutive entries of `frames` (frame numbers of the trajectory): entry i takes a point of the
+    camera frame of frames[i-1] into the camera frame of frames[i] (p_world = o + R p_camera); entry 0 is the identity."""
+    out = np.zeros((len(frames), 4, 4))
+    out[:, 3, 3] = 1.0
+    out[0, :3, :3] = np.eye(3)
+    prev = None
+    for i, f in enumerate(frames):
+        R, o = _poses(scene, seed, int(f), 1)[0]
+        if prev is not None:
+            Rp, op = prev
+            out[i, :3, :3] = R.T @ Rp
+            out[i, :3, 3] = R.T @ (op - o)
+        prev = (R, o)
+    return out
+
+
 def stream(scene, seed, n_frames, width=640, height=480, start=0, device="cuda", chunk=64, raw_u16=False):
     """n_frames x H x W float32 millimetres on `device` (or the raw uint16 TUM sensor units with raw_u16=True)."""
     import torch
