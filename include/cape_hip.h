@@ -385,7 +385,7 @@ enum
     CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, an output plane of either frame
                                            whose polygon was left to the host class (CAPE_POLY_OVERFLOW: the host may keep it,
                                            so the kept-plane indices are not known here), or a polygon pair beyond the
-                                           kernel's capacities (128 vertices per ring, 1 024 slab boundaries, 32 edges of a
+                                           kernel's capacities (512 vertices per ring, 2 048 slab boundaries, 32 edges of a
                                            ring over one slab): no match is reported for the frame -- use the host class */
 };
 typedef struct cape_frame_match_exact

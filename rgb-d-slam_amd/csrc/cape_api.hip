@@ -220,7 +220,7 @@ struct cape_handle_s
     int matchExactFrames = 0;       // frames of the last cape_match_polygons (0: none for the current batch)
     double* matchPoses = nullptr;   // cape_match_polygons_pose: max_batch x 16 doubles, allocated on first use
     cape_frame_match_exact* matchesExact = nullptr;
-    unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 3 lists of max_batch x 256 pairs
+    unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 4 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
     int ldsLimit = 0; // LDS bytes one workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     cape::StageAParams pa{};
@@ -1869,7 +1869,7 @@ static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* pr
     if (!h->matchesExact)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchesExact), (size_t)h->cfg.max_batch * sizeof(cape_frame_match_exact)));
     if (!h->matchLists)
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchLists), (64 + 3 * pairCapacity) * sizeof(unsigned)));
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchLists), (64 + 4 * pairCapacity) * sizeof(unsigned)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
@@ -1891,6 +1891,7 @@ static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* pr
     p.pairLists = h->matchLists + 64;
     p.pairCapacity = pairCapacity;
     p.computeUnits = h->computeUnits;
+    p.ldsLimitBytes = h->ldsLimit;
     p.boundaryCapacity = h->boundaryCap;
     p.flags = flags;
     p.minCosAngle = std::abs(std::cos(20.0 * M_PI / 180.0));

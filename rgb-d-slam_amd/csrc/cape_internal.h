@@ -157,12 +157,13 @@ struct MatchPolygonParams
     const double2* vertices;      // frames x boundaryCapacity
     cape_frame_match_exact* matches;
     unsigned* listCounts; // pairs on the work list of each capacity tier of the intersection kernel
-    unsigned* pairLists;  // 3 lists of pairCapacity entries: (frame << 8) | (j << 4) | i
+    unsigned* pairLists;  // 4 lists of pairCapacity entries: (frame << 8) | (j << 4) | i
     size_t pairCapacity;  // max_batch x 256
     int boundaryCapacity;
     int computeUnits;
     uint32_t flags;
     double minCosAngle, maxDistance, minOverlap; // as MatchParams
+    int ldsLimitBytes = 65536;     // LDS one workgroup may use on the handle's device
     const double* poses = nullptr; // cape_match_polygons_pose: frames x 16, row-major [R t; 0 0 0 1] from camera f-1 to camera f; null = identity
 };
 

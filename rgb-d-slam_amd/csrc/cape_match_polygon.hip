@@ -49,7 +49,18 @@ template <> struct Tier<2> // the comb-shaped outline that comes along once in a
 {
     static constexpr int kRing = 128, kXs = 1024, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
 };
-constexpr int kTiers = 3;
+template <> struct Tier<3> // outlines of more than 128 vertices: the 64 x 48 cell grid of 1280 x 960 frames shows them (207 on the
+{                          // TUM-like stream, profiles/r04_capacity_probe.txt); 145 KB of LDS, one wave per CU
+    static constexpr int kRing = 512, kXs = 2048, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
+};
+constexpr int kTiers = 4;
+// the largest capacity any LATER tier offers (a pair beyond a tier's capacity moves on while one of them can hold it)
+template <int TIER> constexpr int later_ring() { return TIER + 1 < kTiers ? (Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kRing > later_ring<TIER + 1>() ? Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kRing : later_ring<TIER + 1>()) : 0; }
+template <> constexpr int later_ring<kTiers>() { return 0; }
+template <int TIER> constexpr int later_xs() { return TIER + 1 < kTiers ? (Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kXs > later_xs<TIER + 1>() ? Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kXs : later_xs<TIER + 1>()) : 0; }
+template <> constexpr int later_xs<kTiers>() { return 0; }
+template <int TIER> constexpr int later_stack() { return TIER + 1 < kTiers ? (Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kStack > later_stack<TIER + 1>() ? Tier<(TIER + 1 < kTiers ? TIER + 1 : TIER)>::kStack : later_stack<TIER + 1>()) : 0; }
+template <> constexpr int later_stack<kTiers>() { return 0; }
 constexpr int MP = CAPE_MATCH_MAX_PLANES;
 
 #define CAPE_MP_SYNC()                                                                                        \
@@ -698,8 +709,8 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
         {
             bool again = false;
             if (kHasNext)
-                again = is_nan_code(result, kNanStack) || (is_nan_code(result, kNanSlabs) && Tier<kHasNext ? TIER + 1 : TIER>::kXs > T::kXs) ||
-                        (is_nan_code(result, kNanRing) && Tier<kHasNext ? TIER + 1 : TIER>::kRing > T::kRing);
+                again = (is_nan_code(result, kNanStack) && later_stack<TIER>() > T::kStack) || (is_nan_code(result, kNanSlabs) && later_xs<TIER>() > T::kXs) ||
+                        (is_nan_code(result, kNanRing) && later_ring<TIER>() > T::kRing);
             if (again)
                 p.pairLists[(size_t)(TIER + 1) * p.pairCapacity + atomicAdd(&p.listCounts[TIER + 1], 1u)] = pair;
             else
@@ -791,6 +802,9 @@ hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipSt
         return e;
     if (const hipError_t e = launch_tier<2>(p, blocks_for(Tier<2>::kGroupsPerCu, Tier<2>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
+    if (p.boundaryCapacity > Tier<2>::kRing && tier_lds_bytes<3>() <= (size_t)p.ldsLimitBytes) // (a ring is a subset of its plane's candidates)
+        if (const hipError_t e = launch_tier<3>(p, blocks_for(Tier<3>::kGroupsPerCu, Tier<3>::kWavesPerGroup), stream); e != hipSuccess)
+            return e;
     hipLaunchKernelGGL(cape_polygon_select_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
     return hipGetLastError();
 }

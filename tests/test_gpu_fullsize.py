@@ -40,6 +40,9 @@ def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=Fals
     ex.extract_device(dev.data_ptr(), n, stream)
     if match:
         ex.match_consecutive(n, 0, stream)
+        # the reference's own measure on the same batch: boundary polygons + their intersection areas (rows N1 / N2 on the device)
+        ex.build_polygons(n, stream)
+        ex.match_polygons(n, 0, stream)
     res = ex.results(n, with_boundary=True)
     _properties_all_frames(res, n, ex.cells)
     orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
@@ -63,6 +66,17 @@ def _check_stream(oracle_mod, scene, cyl, n, W=640, H=480, stride=16, match=Fals
         assert one.records["segments"][0][:ns].tobytes() == res.records["segments"][f][:ns].tobytes()
     ex1.close()
     matches = ex.matches(n) if match else None
+    if match:
+        import cape_amd
+
+        pol, _ = ex.polygons(n)
+        exact = ex.polygon_matches(n)
+        out = res.records["segments"]["is_output"][:n] == 1
+        # no BASELINE config may need the host class: no plane beyond the device hull's capacity, no frame beyond the matcher's
+        assert not (pol["flags"][out] & cape_amd.POLY_OVERFLOW).any(), "CAPE_POLY_OVERFLOW on a BASELINE stream"
+        assert not (exact["flags"] & cape_amd.MATCH_EXACT_OVERFLOW).any(), "CAPE_MATCH_EXACT_OVERFLOW on a BASELINE stream"
+        # (the tunnel shows one plane per frame, index 0, which the reference's `selectedIndex <= 0` never returns: areas, not matches)
+        assert (exact["inter_area"][1:, 0, 0] > 0).mean() > 0.9
     ex.close()
     kept = dev[list(keep)].cpu().numpy() if keep else None  # the very frames of the batch (a re-rendered stream may chunk its noise differently)
     return n_planes, n_cyl, res, (matches, kept) if match else None

@@ -184,3 +184,30 @@ def test_polygon_matches_argument_checks():
     with pytest.raises(cape_amd.CapeError):
         ex.match_polygons(2, 0, st)
     ex.close()
+
+
+def test_polygon_matches_1280x960_outlines_beyond_128_vertices(host_inter):
+    """BASELINE.json configs[4] geometry: the 64 x 48 cell grid shows outlines of more than 128 vertices (207 on this stream,
+    profiles/r04_capacity_probe.txt) -- the fourth capacity tier of the intersection kernel (512 vertices, 2 048 slab
+    boundaries).  No frame may fall back to the host class, and the areas stay bit-identical to it."""
+    import torch
+    import cape_amd
+    from cape_amd import Extractor, synth, synth_gpu
+
+    n = 64
+    intr = {k: v * 2.0 for k, v in synth.TUM_FR1_INTRINSICS.items()}
+    dev = synth_gpu.stream("tumlike", 17, n, width=1280, height=960, start=256, device="cuda", chunk=4)
+    ex = Extractor(1280, 960, cylinders=True, max_batch=n, **intr)
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_device(dev.data_ptr(), n, st)
+    ex.build_polygons(n, st)
+    ex.match_polygons(n, 0, st)
+    res = ex.results(n)
+    pol, ver = ex.polygons(n)
+    got = ex.polygon_matches(n)
+    assert int(pol["vertex_count"].max()) > 128, "the stream must show an outline the 128-vertex tiers cannot hold"
+    assert not (pol["flags"] & cape_amd.POLY_OVERFLOW).any()
+    assert not (got["flags"] & cape_amd.MATCH_EXACT_OVERFLOW).any()
+    pairs, matches = _check(ex, res, pol, ver, got, n, host_inter, 0)
+    assert pairs > n and matches > 0
+    ex.close()
