@@ -387,6 +387,10 @@ enum
                                            so the kept-plane indices are not known here), or a polygon pair beyond the
                                            kernel's capacities (512 vertices per ring, 2 048 slab boundaries, 32 edges of a
                                            ring over one slab): no match is reported for the frame -- use the host class */
+    ,
+    CAPE_MATCH_EXACT_HOST = 1u << 1     /* never set by the library: the C++ overlay marks the entries its host class computed (frame
+                                           pairs across a chunk / shard boundary, frames the device flagged); match[] is filled,
+                                           seg_prev / seg_cur / inter_area are not */
 };
 typedef struct cape_frame_match_exact
 {

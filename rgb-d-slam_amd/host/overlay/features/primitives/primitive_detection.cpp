@@ -234,6 +234,20 @@ void Primitive_Detection::run_shard(Shard& shard, const float* depth, const uint
             ok = false;
             return;
         }
+        if (_matchInBatch)
+        {
+            // the chunk's frames matched on the device right behind their polygons; its first frame (its predecessor went through
+            // another pass) and whatever the device flags are left to the host class once every shard is done (batch_impl)
+            const int g0 = firstFrame + base;
+            const uint32_t flags = (_matchAdvanced ? static_cast<uint32_t>(CAPE_MATCH_ADVANCED) : 0u) |
+                                   (_matchIndexZero ? static_cast<uint32_t>(CAPE_MATCH_ALLOW_INDEX0) : 0u);
+            const bool onDevice = shard.devicePolygons &&
+                                  cape_match_polygons_pose(shard.handle, m, _matchPoses ? _matchPoses + static_cast<size_t>(16) * g0 : nullptr, flags,
+                                                           shard.stream) == CAPE_OK &&
+                                  cape_copy_polygon_matches(shard.handle, m, _batchMatches.data() + g0) == CAPE_OK;
+            for (int f = 0; f < m; ++f)
+                _matchOnHost[g0 + f] = !onDevice || f == 0 || (_batchMatches[g0 + f].flags & CAPE_MATCH_EXACT_OVERFLOW) != 0;
+        }
         // containers are filled in place: a Plane copy would re-normalise its parametrisation once more
         for (int f = 0; f < m; ++f)
             collect(shard, f, planes[firstFrame + base + f], cylinders[firstFrame + base + f]);
@@ -294,6 +308,13 @@ void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, fl
             const int mb = _shards[0].maxBatch;
             _lastBatchResident = count <= 0 ? 0 : (count % mb == 0 ? mb : count % mb);
         }
+        if (_matchInBatch)
+        {
+            _batchMatches.assign(static_cast<size_t>(n_frames), cape_frame_match_exact {});
+            _matchOnHost.assign(static_cast<size_t>(n_frames), 1);
+        }
+        else
+            _batchMatches.clear();
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<char> ok(shards, 1);
         if (shards == 1)
@@ -330,6 +351,10 @@ void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, fl
             if (!ok[k])
                 outputs::log_error("find_primitives: shard " + std::to_string(k) + " failed (" + _shards[k].error +
                                    "); its frames yield no primitives");
+        if (_matchInBatch)
+            for (int f = 0; f < n_frames; ++f)
+                if (_matchOnHost[f])
+                    host_match(f, planes); // stitches the chunk and shard boundaries, serves the frames beyond the device's capacities
         _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     catch (const std::exception& e)
@@ -417,6 +442,12 @@ bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<c
     try
     {
         matches.clear();
+        if (_matchInBatch && n_frames >= 0 && static_cast<size_t>(n_frames) <= _batchMatches.size())
+        {
+            // set_batch_matching: the last batch was matched while it ran, stitched over its chunks and shards
+            matches.assign(_batchMatches.begin(), _batchMatches.begin() + n_frames);
+            return true;
+        }
         if (_shards.empty() || n_frames < 0 || _lastBatchShards != 1 || n_frames > _lastBatchResident || !_devicePolygons)
         {
             outputs::log_error("match_consecutive_polygons: needs a find_primitives_batch on ONE shard with device polygons, and at "
@@ -438,6 +469,51 @@ bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<c
     catch (const std::exception&)
     {
         return false;
+    }
+}
+
+// One frame's entry by the host class: MapPlane::find_matches of every plane of frame f-1 (through the pose, if any) against the
+// planes of frame f, like the device does it (cape_match_polygons_pose) and with the same statements.
+void Primitive_Detection::host_match(int f, const std::vector<plane_container>& planes) const
+{
+    cape_frame_match_exact& out = _batchMatches[static_cast<size_t>(f)];
+    out = cape_frame_match_exact {};
+    out.flags = CAPE_MATCH_EXACT_HOST;
+    for (int k = 0; k < CAPE_MATCH_MAX_PLANES; ++k)
+    {
+        out.match[k] = out.seg_prev[k] = out.seg_cur[k] = -1;
+        for (int i = 0; i < CAPE_MATCH_MAX_PLANES; ++i)
+            out.inter_area[k][i] = -1.0;
+    }
+    if (f == 0)
+        return;
+    const plane_container &prev = planes[static_cast<size_t>(f) - 1], &cur = planes[static_cast<size_t>(f)];
+    out.n_prev = static_cast<int32_t>(prev.size());
+    out.n_cur = static_cast<int32_t>(cur.size());
+    if (prev.size() > CAPE_MATCH_MAX_PLANES)
+        out.flags |= CAPE_MATCH_EXACT_OVERFLOW; // the table holds 16 previous planes
+    const double* T = _matchPoses ? _matchPoses + static_cast<size_t>(16) * f : nullptr;
+    std::vector<bool> matched(cur.size(), false);
+    for (size_t j = 0; j < prev.size() && j < CAPE_MATCH_MAX_PLANES; ++j)
+    {
+        int m = -1;
+        if (T)
+        {
+            // to_camera_coordinates (plane_coordinates.cpp:20-24): the rotated normal goes into the constructor, which normalises it once
+            const vector3 n = prev[j].get_normal();
+            const double d = prev[j].get_d();
+            const vector3 rn((T[0] * n[0] + T[1] * n[1]) + T[2] * n[2], (T[4] * n[0] + T[5] * n[1]) + T[6] * n[2], (T[8] * n[0] + T[9] * n[1]) + T[10] * n[2]);
+            const double m0 = -((T[3] * T[0] + T[7] * T[4]) + T[11] * T[8]), m1 = -((T[3] * T[1] + T[7] * T[5]) + T[11] * T[9]),
+                         m2 = -((T[3] * T[2] + T[7] * T[6]) + T[11] * T[10]);
+            const PlaneCameraCoordinates projected(rn, ((m0 * n[0] + m1 * n[1]) + m2 * n[2]) + d);
+            m = find_plane_match(cur, matched, projected, CameraPolygon(prev[j].get_boundary_polygon().to_camera_space(T)), _matchAdvanced,
+                                 _matchIndexZero);
+        }
+        else
+            m = find_plane_match(cur, matched, prev[j].get_parametrization(), prev[j].get_boundary_polygon(), _matchAdvanced, _matchIndexZero);
+        if (m >= 0)
+            matched[static_cast<size_t>(m)] = true;
+        out.match[j] = m;
     }
 }
 
@@ -466,7 +542,8 @@ void Primitive_Detection::show_statistics(const double meanFrameTreatmentDuratio
 }
 
 int find_plane_match(const plane_container& detectedPlanes, const std::vector<bool>& isDetectedFeatureMatched,
-                     const PlaneCameraCoordinates& projectedPlane, const CameraPolygon& projectedPolygon, bool useAdvancedSearch) noexcept
+                     const PlaneCameraCoordinates& projectedPlane, const CameraPolygon& projectedPolygon, bool useAdvancedSearch,
+                     bool allowIndexZero) noexcept
 {
     const double projectedArea = projectedPolygon.get_area();
     const double planeMinimalOverlap = parameters::matching::minimumPlaneOverlapToConsiderMatch; // float widened, like the reference's static double
@@ -492,7 +569,7 @@ int find_plane_match(const plane_container& detectedPlanes, const std::vector<bo
             greatestSimilarity = interArea;
         }
     }
-    if (selectedIndex <= 0) // quirk of the reference: index 0 can never be returned
+    if (selectedIndex < 0 || (selectedIndex == 0 && !allowIndexZero)) // quirk of the reference: index 0 can never be returned
         return -1;
     return selectedIndex;
 }

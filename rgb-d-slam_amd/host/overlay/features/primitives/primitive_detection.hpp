@@ -89,6 +89,21 @@ class Primitive_Detection
                                     bool allowIndexZero = false,
                                     const double* prevToCur = nullptr) noexcept;
 
+    // Matches between ALL consecutive frames of the following batches, computed while a batch runs: every chunk is matched on
+    // the device right behind its polygons (cape_match_polygons_pose); the frame pairs the device cannot serve -- across a chunk
+    // or shard boundary (the two frames went through different passes, maybe on different devices) and the frames it flags
+    // CAPE_MATCH_EXACT_OVERFLOW -- are matched by the host class (find_plane_match on the containers, entries marked
+    // CAPE_MATCH_EXACT_HOST).  batch_matches() then holds one complete entry per frame of the last batch, whatever its sharding.
+    // prevToCur: as for match_consecutive_polygons, n_frames x 16 doubles that must stay valid during find_primitives_batch.
+    void set_batch_matching(bool on, bool useAdvancedSearch = false, bool allowIndexZero = false, const double* prevToCur = nullptr) noexcept
+    {
+        _matchInBatch = on;
+        _matchAdvanced = useAdvancedSearch;
+        _matchIndexZero = allowIndexZero;
+        _matchPoses = prevToCur;
+    }
+    [[nodiscard]] const std::vector<cape_frame_match_exact>& batch_matches() const noexcept { return _batchMatches; }
+
     [[nodiscard]] bool is_ready() const noexcept { return _single.handle != nullptr; }
 
   private:
@@ -127,12 +142,17 @@ class Primitive_Detection
                    std::vector<cylinder_container>& cylinders,
                    bool& ok) const;
     void collect(const Shard& shard, int f, plane_container& planes, cylinder_container& cylinders) const;
+    void host_match(int f, const std::vector<plane_container>& planes) const;
 
     uint _width, _height;
     int _cells = 0, _boundaryCapacity = 0;
     int _maxBatch = 256;
     int _requestedShards = 0;
     bool _devicePolygons = true;
+    bool _matchInBatch = false, _matchAdvanced = false, _matchIndexZero = false;
+    const double* _matchPoses = nullptr;
+    mutable std::vector<cape_frame_match_exact> _batchMatches; // set_batch_matching: one entry per frame of the last batch
+    mutable std::vector<char> _matchOnHost;                    // frames whose entry the host class owes (chunk / shard starts, flagged frames)
     int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
     int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
@@ -154,7 +174,8 @@ int find_plane_match(const plane_container& detectedPlanes,
                      const std::vector<bool>& isDetectedFeatureMatched,
                      const PlaneCameraCoordinates& projectedPlane,
                      const CameraPolygon& projectedPolygon,
-                     bool useAdvancedSearch = false) noexcept;
+                     bool useAdvancedSearch = false,
+                     bool allowIndexZero = false) noexcept; // allowIndexZero: drop the quirk (what CAPE_MATCH_ALLOW_INDEX0 does on the device)
 
 } // namespace rgbd_slam::features::primitives
 #endif

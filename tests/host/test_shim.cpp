@@ -201,6 +201,49 @@ int main(int argc, char** argv)
         }
         std::printf("X %d %d %d %d\n", n, previous, matched, mismatches);
     }
+    // N2 over a whole batch, whatever its sharding: set_batch_matching matches every chunk on the device while the batch runs and
+    // stitches the chunk / shard boundaries with the host class.  Three shards (frame pairs across two shard boundaries are the
+    // host's) must give the decisions of one shard (every pair on the device) -- with a camera pose in both.
+    if (batchFrames > 0)
+    {
+        const int n = 1 + batchFrames;
+        // a small rigid motion between consecutive frames: 1.5 degrees about y, (20, -10, 15) mm
+        const double c = 0.99965732497555726, sn = 0.026176948307873153;
+        std::vector<double> poses(static_cast<size_t>(n) * 16, 0.0);
+        for (int f = 0; f < n; ++f)
+        {
+            double* T = poses.data() + static_cast<size_t>(f) * 16;
+            T[0] = c, T[2] = sn, T[5] = 1.0, T[8] = -sn, T[10] = c, T[15] = 1.0;
+            T[3] = 20.0, T[7] = -10.0, T[11] = 15.0;
+        }
+        std::vector<plane_container> p1, p3;
+        std::vector<cylinder_container> c1, c3;
+        detector->set_batch_matching(true, false, true, poses.data());
+        detector->set_shard_count(1);
+        detector->find_primitives_batch(depth.data(), n, p1, c1);
+        const std::vector<cape_frame_match_exact> one = detector->batch_matches();
+        detector->set_shard_count(3);
+        detector->find_primitives_batch(depth.data(), n, p3, c3);
+        const std::vector<cape_frame_match_exact>& three = detector->batch_matches();
+        std::vector<cape_frame_match_exact> viaCall;
+        const bool served = detector->match_consecutive_polygons(n, viaCall, false, true, poses.data()) && viaCall.size() == static_cast<size_t>(n);
+        detector->set_batch_matching(false);
+        int hostEntries = 0, hostEntriesOne = 0, mismatches = 0, matched = 0;
+        if (one.size() != static_cast<size_t>(n) || three.size() != static_cast<size_t>(n) || !served)
+            return 9;
+        for (int f = 0; f < n; ++f)
+        {
+            hostEntries += (three[f].flags & CAPE_MATCH_EXACT_HOST) != 0;
+            hostEntriesOne += (one[f].flags & CAPE_MATCH_EXACT_HOST) != 0;
+            mismatches += one[f].n_prev != three[f].n_prev || one[f].n_cur != three[f].n_cur;
+            for (int j = 0; j < one[f].n_prev && j < CAPE_MATCH_MAX_PLANES; ++j)
+            {
+                mismatches += one[f].match[j] != three[f].match[j] || viaCall[f].match[j] != three[f].match[j];
+                matched += one[f].match[j] >= 0;
+            }
+        }
+        std::printf("Y %d %d %d %d %d\n", n, hostEntriesOne, hostEntries, matched, mismatches);
+    }
     // rectify_depth with the default (identity) camera2 -> camera1 transform, then the rectified frame through the path
     depth_image rect;
     if (!depthOps->rectify_depth(img, rect))

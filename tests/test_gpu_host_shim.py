@@ -120,3 +120,8 @@ def test_polygon_matcher_equals_host_selection(host_binaries, tmp_path):
     n, previous, matched, mismatches = X
     assert n == len(frames) and previous >= 2 * (n - 1) and matched >= n - 1, X
     assert mismatches == 0, X
+    # set_batch_matching: the same batch over three shards, the two shard boundaries (and frame 0) stitched by the host class,
+    # gives the decisions of one shard matched on the device -- with a camera pose in both (cape_match_polygons_pose)
+    Y = [int(v) for v in [ln for ln in out.stdout.splitlines() if ln.startswith("Y ")][0].split()[1:]]
+    n, host_one, host_three, matched, mismatches = Y
+    assert n == len(frames) and host_one == 1 and host_three == 3 and matched >= n - 1 and mismatches == 0, Y
