@@ -63,9 +63,22 @@ __device__ __forceinline__ double eigen_hypot(double x, double y)
     return p * sqrt(1.0 + qp * qp);
 }
 
-// JacobiRotation<double>::makeGivens (real case)
+// JacobiRotation<double>::makeGivens (real case).  Eigen's two general branches (|p| > |q| and the other) are the same
+// statements with p and q swapped: ONE division, one square root and one reciprocal on selected operands give the same bits
+// as either branch (-(1/u) == (-1)/u), and the lanes of a wave no longer serialise the two.
 __device__ __forceinline__ void make_givens(double p, double q, double& c, double& s)
 {
+    const bool big = fabs(p) > fabs(q);
+    const double num = big ? q : p, den = big ? p : q;
+    const double t = num / den;
+    double u = sqrt(1.0 + t * t);
+    if (den < 0.0)
+        u = -u;
+    const double r = 1.0 / u;
+    const double first = big ? r : -r; // c of the first branch, s of the second
+    const double second = -t * first;  // s = -t * c, resp. c = -t * s
+    c = big ? first : second;
+    s = big ? second : first;
     if (q == 0.0)
     {
         c = p < 0.0 ? -1.0 : 1.0;
@@ -75,24 +88,6 @@ __device__ __forceinline__ void make_givens(double p, double q, double& c, doubl
     {
         c = 0.0;
         s = q < 0.0 ? 1.0 : -1.0;
-    }
-    else if (fabs(p) > fabs(q))
-    {
-        const double t = q / p;
-        double u = sqrt(1.0 + t * t);
-        if (p < 0.0)
-            u = -u;
-        c = 1.0 / u;
-        s = -t * c;
-    }
-    else
-    {
-        const double t = p / q;
-        double u = sqrt(1.0 + t * t);
-        if (q < 0.0)
-            u = -u;
-        s = -1.0 / u;
-        c = -t * s;
     }
 }
 
@@ -234,29 +229,49 @@ __device__ inline void self_adjoint_eigen3(double m00, double m10, double m11, d
                 mu -= e2 / (td + (td > 0.0 ? h : -h));
         }
 
-        double x = ((start == 0) ? d0 : d1) - mu;
-        double z = (start == 0) ? s0 : s1;
-        // k = start
+        // k = start: ONE rotation on (k, k + 1), k in {0, 1}, on selected operands -- the reference's generic loop body; the lanes of
+        // a wave sit in different (start, end) blocks, and three unrolled copies of it used to run one after the other
+        const bool k1 = start != 0;
+        const double dk = k1 ? d1 : d0, sk = k1 ? s1 : s0, dk1 = k1 ? d2 : d1;
+        double x = dk - mu;
+        double z = sk;
         if (z != 0.0)
         {
             double c, s;
             make_givens(x, z, c, s);
-            if (start == 0)
+            const double sdk = s * dk + c * sk;
+            const double dkp1 = s * sk + c * dk1;
+            const double ndk = c * (c * dk - s * sk) - s * (c * sk - s * dk1);
+            const double ndk1 = s * sdk + c * dkp1;
+            const double nsk = c * sdk - s * dkp1;
+            // q.applyOnTheRight(k, k + 1, rot)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
             {
-                const double sdk = s * d0 + c * s0;
-                const double dkp1 = s * s0 + c * d1;
-                const double nd0 = c * (c * d0 - s * s0) - s * (c * s0 - s * d1);
-                d1 = s * sdk + c * dkp1;
-                s0 = c * sdk - s * dkp1;
-                d0 = nd0;
+                const double xi = k1 ? Q[r][1] : Q[r][0], yi = k1 ? Q[r][2] : Q[r][1];
+                const double nx = c * xi - s * yi, ny = s * xi + c * yi;
+                Q[r][0] = k1 ? Q[r][0] : nx;
+                Q[r][1] = k1 ? nx : ny;
+                Q[r][2] = k1 ? ny : Q[r][2];
+            }
+            if (k1)
+            {
+                d1 = ndk;
+                d2 = ndk1;
+                s1 = nsk;
+            }
+            else
+            {
+                d0 = ndk;
+                d1 = ndk1;
+                s0 = nsk;
                 x = s0;
                 if (0 < end - 1)
                 {
                     z = -s * s1;
                     s1 = c * s1;
                 }
-                qr_rotate(Q, 0, c, s);
-                // k = 1 (only when end == 2)
+                // k = 1 (only when start == 0 and end == 2)
                 if (end == 2 && z != 0.0)
                 {
                     double c2, s2;
@@ -270,16 +285,6 @@ __device__ inline void self_adjoint_eigen3(double m00, double m10, double m11, d
                     s0 = c2 * s0 - s2 * z; // k > start
                     qr_rotate(Q, 1, c2, s2);
                 }
-            }
-            else // start == 1, end == 2: single rotation on (1,2)
-            {
-                const double sdk = s * d1 + c * s1;
-                const double dkp1 = s * s1 + c * d2;
-                const double nd1 = c * (c * d1 - s * s1) - s * (c * s1 - s * d2);
-                d2 = s * sdk + c * dkp1;
-                s1 = c * sdk - s * dkp1;
-                d1 = nd1;
-                qr_rotate(Q, 1, c, s);
             }
         }
     }
