@@ -50,6 +50,11 @@ if os.environ.get("CAPE_POLY_PHASES"):
     for k, nm in enumerate(names):
         print("  %-45s %8.0f ticks  %5.1f %%" % (nm, cyc[k] / planes, 100 * cyc[k] / tot))
 if os.environ.get("CAPE_POLY_PHASES"):
+    raw = ex.debug_cycles(B).astype(np.float64)
+    print("task kernel: static tasks %d (%.0f ticks each to get), spawned / idle-exit acquisitions %d (%.0f ticks each)" % (
+        raw[0, 26], raw[0, 24] / max(1, raw[0, 26]), raw[0, 27], raw[0, 25] / max(1, raw[0, 27])))
+    print("   acquisition loop iterations %d, failed CAS %d, spins on an unwritten slot %d" % (raw[0, 28], raw[0, 29], raw[0, 30]))
+if os.environ.get("CAPE_POLY_PHASES"):
     per = ex.debug_cycles(B).astype(np.float64)
     t = per[:, :6].sum(1)
     print("per-frame ticks percentiles:", {q: int(np.percentile(t, q)) for q in (50, 90, 99, 99.9, 100)})

@@ -215,7 +215,7 @@ struct cape_handle_s
     // N1 on the device: polygons of the last batch (allocated on first use)
     cape_polygon* polygons = nullptr;
     double* polyVertices = nullptr;
-    uint32_t* polyLadder = nullptr; // the three work lists of the polygon kernels
+    uint32_t* polyLadder = nullptr; // scratch of the polygon kernels: work lists, state words, parking area (polygon_scratch_bytes)
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
     int matchExactFrames = 0;       // frames of the last cape_match_polygons (0: none for the current batch)
     double* matchPoses = nullptr;   // cape_match_polygons_pose: max_batch x 16 doubles, allocated on first use
@@ -1812,14 +1812,13 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
         }
     }
     if (!h->polyLadder)
-        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), 3 * (B * CAPE_MAX_PLANES + cape::kPolyListHeader) * sizeof(uint32_t)));
+        CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->polyLadder), cape::polygon_scratch_bytes(B, h->boundaryCap)));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StreamScope streamScope(h, stream);
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
     cape::PolygonParams p;
-    p.lists = h->polyLadder;
-    p.listStride = (uint32_t)(B * CAPE_MAX_PLANES + cape::kPolyListHeader);
+    cape::polygon_bind_scratch(p, h->polyLadder, B, h->boundaryCap);
     if (h->computeUnits <= 0)
     {
         hipDeviceProp_t prop;
@@ -1989,7 +1988,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         step(hipMalloc(reinterpret_cast<void**>(&bnd), cap * 3 * sizeof(double)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&poly), CAPE_MAX_PLANES * sizeof(cape_polygon)), "hipMalloc") &&
         step(hipMalloc(reinterpret_cast<void**>(&verts), cap * 2 * sizeof(double)), "hipMalloc") &&
-        step(hipMalloc(reinterpret_cast<void**>(&ladder), 3 * (CAPE_MAX_PLANES + cape::kPolyListHeader) * sizeof(uint32_t)), "hipMalloc") &&
+        step(hipMalloc(reinterpret_cast<void**>(&ladder), cape::polygon_scratch_bytes(1, h->boundaryCap)), "hipMalloc") &&
         step(hipMemcpy(rec, hostRec, sizeof(cape_frame_record), hipMemcpyHostToDevice), "hipMemcpy") &&
         step(n ? hipMemcpy(bnd, points3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice) : hipSuccess, "hipMemcpy"))
     {
@@ -2000,8 +1999,7 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
         p.vertices = reinterpret_cast<double2*>(verts);
         p.boundaryCapacity = h->boundaryCap;
         p.prof = nullptr;
-        p.lists = ladder;
-        p.listStride = CAPE_MAX_PLANES + cape::kPolyListHeader;
+        cape::polygon_bind_scratch(p, ladder, 1, h->boundaryCap);
         p.computeUnits = 4;
         p.originInCentroid = 1; // an arbitrary origin, as the caller asked
         if (step(cape::launch_polygons(p, 1, nullptr), "launch") && step(hipDeviceSynchronize(), "hipDeviceSynchronize") &&

@@ -193,12 +193,18 @@ struct PolygonParams
     cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
     double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
     int boundaryCapacity;
-    uint32_t* lists;          // three work lists of listStride words: kPolyListHeader words, then (frame << 8 | segment) -- planes of
-    uint32_t listStride;      // up to 256 candidates, planes whose first hull rung failed, planes of 257 .. 1 024 candidates
+    uint32_t* lists;          // three work lists of listStride words (kPolyListHeader words, then entries): the planes of up to 256
+    uint32_t listStride;      // candidates, the queue of spawned (plane, rung) tasks, the planes of 257 .. 1 024 candidates
+    uint32_t* state;          // frames x CAPE_MAX_PLANES state words of the task kernel (done mask | hull mask << 8 | finalised << 16)
+    unsigned short* park;     // frames x 6 rungs x parkStride: hulls waiting for the verdict of lower rungs
+    uint32_t parkStride;      // boundaryCapacity + 2 * CAPE_MAX_PLANES (a plane's hull: length + at most count + 1 indices)
     int computeUnits;
     int originInCentroid;     // cape_debug_polygon only: the polygon's origin is read from the record's centroid field
     unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
+
+size_t polygon_scratch_bytes(size_t frames, int boundaryCapacity);
+void polygon_bind_scratch(PolygonParams& p, void* base, size_t frames, int boundaryCapacity);
 
 struct RcclUniqueId
 {

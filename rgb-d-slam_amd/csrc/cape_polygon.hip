@@ -34,21 +34,13 @@ constexpr int kPolyWavesPerGroup = 4;
 // are built by waves that hold 7 KB of LDS each, twenty to a CU; a plane with more goes to the kPolyMaxPoints
 // instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
 constexpr int kPolySmallPoints = 256;
-// The k ladder.  Nearly every plane gets its hull on the first rung (1.13 attempts on average), but a plane that climbs to
-// k = 21 spends ~3 ms in one wave, and a kernel lasts as long as its slowest wave (4.2 ms per 4 096 room frames, one plane in
-// a thousand).  So the small instance runs the FIRST rung only and defers a plane that fails it (work list 1) to the
-// ladder kernel: a workgroup of three waves per such plane, wave w on rung w + 2 (k = 5, 7, 11) all at once, then -- if none has
-// a hull -- on rung w + 5 (k = 13, 17, 21); the
-// lowest rung that yields a simple hull wins, exactly as if they had run one after the other (a run is a pure function of
-// the points and k).
-constexpr int kLadderWaves = 3;
 constexpr int kPolySortSelect = 5;  // neighbours from which the k-nearest selection sorts the lanes' keys instead of taking k minima
 constexpr int kPolyBigPoints = 100; // planes with at least as many boundary candidates are handed out first (longest first)
-enum PolyMode
+enum PolyList
 {
-    kPolyFirstRung = 0, // small instance: rung 0, defer on failure
-    kPolyLadder = 1,    // small instance, six waves per plane: rungs 2 .. 7 in parallel
-    kPolyFull = 2       // large instance: the whole ladder in one wave (rare twice over)
+    kPolyFirstRung = 0, // list 0: the planes of up to 256 candidates (static list of the task kernel)
+    kPolyLadder = 1,    // list 1: the task kernel's dynamic queue of spawned (plane, rung) tasks
+    kPolyFull = 2       // list 2: planes of 257 .. 1 024 candidates (the large instance: the whole ladder in one wave)
 };
 
 #ifdef CAPE_POLY_PROFILE
@@ -280,9 +272,9 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 // One run of the k-nearest-neighbours walk (host: concave_hull_k = ConcaveHull of concave_fitting.cpp:93-183).  On success the
 // hull's point indices are in L.hull[0, hs) exactly as the reference's vector holds them: ending with the start point again
 // when the walk came back to it, every point once when it ran out of points first.
-// `lowestDone` (ladder kernel only, else null): LDS word holding the lowest rung that already has its hull; a higher rung gives
-// up as soon as it sees one below it succeed -- it can no longer win.
-template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const volatile int* lowestDone = nullptr,
+// `planeState` (task kernel only, else null): the plane's state word in global memory; a rung gives up as soon as a lower rung
+// has its hull (or the plane is finalised) -- it can no longer win.  Looked at every eighth step.
+template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
                                                         int myRung = 0)
 {
     constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
@@ -318,8 +310,15 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     int step = 1;
     while ((!points_equal(cur, firstPt) || step == 1) && hs != n)
     {
-        if (lowestDone && __builtin_amdgcn_readfirstlane(*lowestDone) < myRung)
-            return false;
+        if (planeState && (step & 7) == 0)
+        {
+            uint32_t st = 0;
+            if (lane == 0)
+                st = atomicAdd(const_cast<uint32_t*>(planeState), 0u); // (as the atomics see it: see fresh_u32)
+            st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+            if ((st & (1u << 16)) || (((st >> 8) & 0xFFu) & ((1u << myRung) - 1u)))
+                return false;
+        }
         if (step == 4)
         {
             if (lane == 0)
@@ -528,27 +527,317 @@ __device__ inline void sort_points(const PolyLds& L, int n, int lane)
         }
 }
 
-template <int CAP, int MODE>
-__global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup), MODE == kPolyLadder ? 3 : 4) void cape_polygon_kernel(
-        PolygonParams p, int nFrames, int ldsPerWave)
+// ---------------------------------------------------------------------------------------------------------------------------
+// One plane's context: where it comes from, its plane frame (get_plane_coordinate_system, polygon.cpp:74-115 with
+// select_correct_transform :50-68), and what the constructor would do with it.
+struct PlaneCtx
+{
+    int frame, seg, nPts;
+    double cx, cy, cz, xax, xay, xaz, yax, yay, yaz;
+    uint32_t flags; // CAPE_POLY_REJECTED / CAPE_POLY_OVERFLOW decided up front
+};
+
+__device__ inline PlaneCtx plane_context(const PolygonParams& p, int frame, int seg)
+{
+    PlaneCtx c;
+    const cape_plane_segment& S = p.records[frame].segments[seg];
+    c.frame = frame;
+    c.seg = seg;
+    c.nPts = (int)S.boundary_count;
+    c.flags = 0;
+    const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
+    // the polygon's origin is Plane_Segment::get_center() = PlaneCoordinates::get_center() = normal * (-d), the point of the plane
+    // closest to the camera (primitive_detection.cpp:622, plane_segment.hpp:90, plane_coordinates.hpp:52) -- not the centroid
+    c.cx = p.originInCentroid ? S.centroid[0] : nx * (-S.d);
+    c.cy = p.originInCentroid ? S.centroid[1] : ny * (-S.d);
+    c.cz = p.originInCentroid ? S.centroid[2] : nz * (-S.d);
+    const double distX = fabs(nx), distY = fabs(ny), distZ = fabs(nz);
+    const double res = pmin(distX, pmin(distY, distZ));
+    double rx, ry, rz;
+    if (fabs(res - distX) <= 0.1)
+        rx = 1, ry = 0, rz = 0;
+    else if (fabs(res - distY) <= 0.1)
+        rx = 0, ry = 1, rz = 0;
+    else if (fabs(res - distZ) <= 0.1)
+        rx = 0, ry = 0, rz = 1;
+    else
+    {
+        rx = nz, ry = nx, rz = ny;
+        const double nn = sqrt((rx * rx + ry * ry) + rz * rz);
+        if (nn > 0)
+            rx /= nn, ry /= nn, rz /= nn;
+    }
+    // xAxis = normalized(cross(normal, r)) ; yAxis = normalized(cross(normal, xAxis))
+    double ax = ny * rz - nz * ry, ay = nz * rx - nx * rz, az = nx * ry - ny * rx;
+    const double an = sqrt((ax * ax + ay * ay) + az * az);
+    if (an > 0)
+        ax /= an, ay /= an, az /= an;
+    double bx = ny * az - nz * ay, by = nz * ax - nx * az, bz = nx * ay - ny * ax;
+    const double bn = sqrt((bx * bx + by * by) + bz * bz);
+    if (bn > 0)
+        bx /= bn, by /= bn, bz /= bn;
+    c.xax = ax, c.xay = ay, c.xaz = az, c.yax = bx, c.yay = by, c.yaz = bz;
+    const double normalNorm = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (!(fabs(normalNorm - 1.0) <= 1e-9) || c.nPts < 3)
+        c.flags |= CAPE_POLY_REJECTED; // the host constructor throws (normal not unit / fewer than 3 points)
+    else if (c.nPts > kPolyMaxPoints)
+        c.flags |= CAPE_POLY_OVERFLOW; // left to the host class
+    return c;
+}
+
+// projection (polygon.cpp:125-144), in REVERSE order like the reference (:187-192); no sort, no duplicate removal
+// (concave_fitting.cpp:69: the overload this path binds does not call RemoveDuplicates)
+__device__ inline void project_points(const PolygonParams& p, const PlaneCtx& c, const PolyLds& L, int lane)
+{
+    const cape_plane_segment& S = p.records[c.frame].segments[c.seg];
+    const double* bnd = p.boundary + ((size_t)c.frame * p.boundaryCapacity + S.boundary_offset) * 3;
+    for (int i = lane; i < c.nPts; i += 64)
+    {
+        const double* q = bnd + 3 * (c.nPts - 1 - i);
+        const double dx = q[0] - c.cx, dy = q[1] - c.cy, dz = q[2] - c.cz;
+        L.pts[i] = make_double2((c.xax * dx + c.xay * dy) + c.xaz * dz, (c.yax * dx + c.yay * dy) + c.yaz * dz);
+    }
+    CAPE_POLY_SYNC();
+}
+
+__device__ inline void write_record(const PolygonParams& p, const PlaneCtx& c, double area, int count, uint32_t flags, int lane)
+{
+    if (lane == 0)
+    {
+        cape_polygon* out = &p.polygons[(size_t)c.frame * CAPE_MAX_PLANES + c.seg];
+        out->x_axis[0] = c.xax; out->x_axis[1] = c.xay; out->x_axis[2] = c.xaz;
+        out->y_axis[0] = c.yax; out->y_axis[1] = c.yay; out->y_axis[2] = c.yaz;
+        out->center[0] = c.cx; out->center[1] = c.cy; out->center[2] = c.cz;
+        out->area = area;
+        out->vertex_offset = p.records[c.frame].segments[c.seg].boundary_offset;
+        out->vertex_count = (uint32_t)count;
+        out->flags = flags;
+        out->segment = (uint32_t)c.seg;
+    }
+}
+
+// Everything the constructor does once the ladder has spoken (polygon.cpp:195-231): the hull in L.hull[0, hs) -- or none --
+// becomes the oriented ring, the convex hull takes over if that ring is no polygon, then area, simplify, validity and the
+// stores.  `frame` / `_pt`: the profile build's counters.
+template <int CAP> __device__ inline void finish_polygon(const PolygonParams& p, const PlaneCtx& c, const PolyLds& L, bool haveRing, int hs, int lane)
 {
     constexpr int kPolyPerLane = CAP / 64;
-    constexpr int kWaves = MODE == kPolyLadder ? kLadderWaves : kPolyWavesPerGroup;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Work comes as lists of (frame << 8 | segment) written on the device: list 0 = the output planes of up to 256 boundary
-    // candidates (cape_polygon_list_kernel), list 1 = planes whose first rung failed (written by the first-rung instance),
-    // list 2 = planes of 257 .. 1 024 candidates.  A fixed grid strides over its list -- one WAVE per entry, or one WORKGROUP
-    // per entry in the ladder kernel -- so every resident wave has a plane (the first version launched eight waves per frame
-    // for ~2.5 planes: two thirds of the resident waves had nothing to do).
-    int* s_ok = reinterpret_cast<int*>(smem_all + (size_t)kWaves * ldsPerWave); // ladder kernel: verdict of every rung
-    // a list: [0] entries filled from the front (the big planes), [1] entries filled from the back, [2] the next entry to hand
-    // out, then the entries.  Waves (workgroups in the ladder kernel) take the next entry when they are done with theirs --
-    // big planes first, so that the longest walks start at once instead of at the end of somebody's queue.
-    uint32_t* list = p.lists + (size_t)MODE * p.listStride;
-    const unsigned nFront = list[0], nEntries = nFront + list[1];
-    const unsigned listCapacity = p.listStride - kPolyListHeader;
-    unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
+    const int nPts = c.nPts;
+    uint32_t flags = 0;
+    double2* vout = p.vertices + (size_t)c.frame * p.boundaryCapacity + p.records[c.frame].segments[c.seg].boundary_offset;
+    unsigned short* ring = L.ring;
+    int rn = 0;
+#ifdef CAPE_POLY_PROFILE
+    const int frame = c.frame;
+    unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#endif
+    if (haveRing)
+    {
+        // The repair of the constructor (polygon.cpp:195-226 -> correct_boost_polygon.hpp:188-195, :172-186): the walk's ring,
+        // closed, is reversed when it runs counter-clockwise -- it does, and it still starts at the walk's start point.  Kept
+        // open here: the closing vertex goes.
+        int m = hs;
+        if (m > 1 && points_equal(L.pts[L.hull[m - 1]], L.pts[L.hull[0]]))
+            --m;
+        const bool rev = m >= 3 && ring_area_signed(L.pts, L.hull, m) > 0;
+        for (int i = lane; i < m; i += 64)
+            ring[i] = L.hull[(rev && i > 0) ? m - i : i];
+        rn = m;
+        CAPE_POLY_SYNC();
+        // A hull that touches or crosses itself is dissolved with Boost set operations in the reference
+        // (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull
+        if (!ring_is_simple(L.pts, ring, rn, lane))
+            haveRing = false;
+        CAPE_PTICK(2); // simple-ring test of the oriented hull
+    }
+    if (!haveRing)
+    {
+        // ---- compute_convex_hull (monotone chain over the sorted, distinct points), clockwise from the leftmost point.
+        //      Sequential by nature; every lane runs it on the same values, lane 0 writes.
+        flags |= CAPE_POLY_CONVEX_FALLBACK;
+        // the walk needed the points in the reference's order; the chain needs them sorted by (x, y) and distinct
+        int n = nPts;
+        sort_points(L, n, lane);
+        {
+            int nd = 0;
+            for (int base = 0; base < n; base += 64)
+            {
+                const int i = base + lane;
+                double2 q = make_double2(0, 0);
+                bool keepIt = false;
+                if (i < n)
+                {
+                    q = L.pts[i];
+                    keepIt = true;
+                    if (i > 0)
+                    {
+                        const double2 prev = L.pts[i - 1];
+                        keepIt = !(prev.x == q.x && prev.y == q.y);
+                    }
+                }
+                const unsigned long long kb = __ballot(keepIt);
+                CAPE_POLY_SYNC(); // every lane has read its point (and its left neighbour) before the chunk is compacted
+                if (keepIt)
+                    L.pts[nd + __popcll(kb & ((1ull << lane) - 1ull))] = q;
+                nd += __popcll(kb);
+                CAPE_POLY_SYNC();
+            }
+            n = nd;
+        }
+        if (n < 3)
+        {
+            if (lane < n)
+                ring[lane] = (unsigned short)lane;
+            rn = n;
+        }
+        else
+        {
+            unsigned short* hstk = L.hull; // 2 n entries at most: hull + ring areas are contiguous
+            int kx = 0;
+            for (int i = 0; i < n; ++i)
+            {
+                while (kx >= 2 && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i]) <= 0)
+                    kx--;
+                if (lane == 0)
+                    hstk[kx] = (unsigned short)i;
+                kx++;
+                CAPE_POLY_SYNC();
+            }
+            for (int i = n - 1, t = kx + 1; i > 0; --i)
+            {
+                while (kx >= t && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i - 1]) <= 0)
+                    kx--;
+                if (lane == 0)
+                    hstk[kx] = (unsigned short)(i - 1);
+                kx++;
+                CAPE_POLY_SYNC();
+            }
+            const int hn = kx - 1;
+            // clockwise, starting at the leftmost point like the chain (host: reverse(h.begin() + 1, h.end())); through
+            // registers: hull and ring share LDS when the chain ran past kPolyMaxPoints entries
+            unsigned short tmp[kPolyPerLane];
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+            {
+                const int i = lane + 64 * j;
+                tmp[j] = i < hn ? hstk[i == 0 ? 0 : hn - i] : (unsigned short)0;
+            }
+            CAPE_POLY_SYNC();
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+            {
+                const int i = lane + 64 * j;
+                if (i < hn)
+                    ring[i] = tmp[j];
+            }
+            rn = hn;
+        }
+        CAPE_POLY_SYNC();
+    }
+    CAPE_PTICK(3); // orientation, validity of the oriented ring, convex fallback
+    CAPE_PCOUNT(9, rn); // vertices before simplification
+    CAPE_PCOUNT(10, nPts); // points
+    double area = rn >= 3 ? fabs(ring_area_signed(L.pts, ring, rn)) : 0.0;
+    // ---- simplify (polygon.cpp:578-601): Douglas-Peucker on the closed ring, threshold max(area / 1e5, 10); kept if the
+    //      result is a simple ring whose area stays above 75 %
+    if (rn >= 4)
+    {
+        const double eps = pmax(area / 1e5, 10.0);
+        unsigned short* closed = L.hull; // rn + 1 entries
+        for (int i = lane; i <= rn; i += 64)
+        {
+            closed[i] = ring[i < rn ? i : 0];
+            L.keep[i] = (i == 0 || i == rn) ? 1 : 0;
+        }
+        CAPE_POLY_SYNC();
+        int sp = 0;
+        if (lane == 0)
+            L.stack[0] = (unsigned)rn; // (a << 16) | b with a = 0
+        sp = 1;
+        CAPE_POLY_SYNC();
+        while (sp > 0)
+        {
+            const unsigned ab = L.stack[--sp];
+            const int a = (int)(ab >> 16), b = (int)(ab & 0xFFFFu);
+            if (b <= a + 1)
+                continue;
+            const double2 pa = L.pts[closed[a]], pb = L.pts[closed[b]];
+            unsigned long long best = 0ull; // squared distance bits (>= +0); the first index wins a tie, like the host's strict >
+            int bestI = 0x7FFFFFFF;
+            for (int i = a + 1 + lane; i < b; i += 64)
+            {
+                const double d = segment_distance2(L.pts[closed[i]], pa, pb);
+                const unsigned long long db = (unsigned long long)__double_as_longlong(d);
+                if (bestI == 0x7FFFFFFF || db > best)
+                {
+                    best = db;
+                    bestI = i;
+                }
+            }
+            // wave maximum of the distance, smallest index among the equal ones
+            unsigned long long mx = best;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                const unsigned long long ob = (unsigned long long)__shfl_xor((long long)mx, o);
+                mx = ob > mx ? ob : mx;
+            }
+            const unsigned mineKey = (bestI != 0x7FFFFFFF && best == mx) ? (unsigned)(0x7FFFFFFF - bestI) : 0u;
+            const int idx = 0x7FFFFFFF - (int)wave_max_u32(mineKey);
+            const double dmax = __longlong_as_double((long long)mx);
+            if (dmax > eps * eps)
+            {
+                if (lane == 0)
+                {
+                    L.keep[idx] = 1;
+                    L.stack[sp] = ((unsigned)a << 16) | (unsigned)idx;
+                    L.stack[sp + 1] = ((unsigned)idx << 16) | (unsigned)b;
+                }
+                sp += 2;
+                CAPE_POLY_SYNC();
+            }
+        }
+        // candidate ring = the kept vertices of closed[0, rn) ; built in the stack area (as u16), then tested
+        unsigned short* cand = reinterpret_cast<unsigned short*>(L.stack);
+        int cn = 0;
+        for (int base = 0; base < rn; base += 64)
+        {
+            const int i = base + lane;
+            const bool k = i < rn && L.keep[i];
+            const unsigned long long kb = __ballot(k);
+            if (k)
+                cand[cn + __popcll(kb & ((1ull << lane) - 1ull))] = closed[i];
+            cn += __popcll(kb);
+        }
+        CAPE_POLY_SYNC();
+        if (cn >= 3 && ring_is_simple(L.pts, cand, cn, lane))
+        {
+            const double newArea = fabs(ring_area_signed(L.pts, cand, cn));
+            if (newArea > area * 0.75)
+            {
+                for (int i = lane; i < cn; i += 64)
+                    ring[i] = cand[i];
+                rn = cn;
+                area = newArea;
+                flags |= CAPE_POLY_SIMPLIFIED;
+                CAPE_POLY_SYNC();
+            }
+        }
+    }
+    CAPE_PTICK(4); // area + simplify
+    // ---- what Primitive_Detection keeps: a valid polygon of at least three vertices (primitive_detection.cpp:623-631)
+    if (rn >= 3 && ring_is_simple(L.pts, ring, rn, lane))
+        flags |= CAPE_POLY_VALID;
+    for (int i = lane; i < rn; i += 64)
+        vout[i] = L.pts[ring[i]];
+    CAPE_PTICK(5); // final validity, vertex stores
+    CAPE_PCOUNT(11, 1); // planes
+    write_record(p, c, area, rn, flags, lane);
+    CAPE_POLY_SYNC();
+}
+
+template <int CAP> __device__ inline PolyLds carve_lds(unsigned char* smem)
+{
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
     L.hull = reinterpret_cast<unsigned short*>(L.pts + CAP);
@@ -556,404 +845,338 @@ __global__ __launch_bounds__(64 * (MODE == kPolyLadder ? kLadderWaves : kPolyWav
     L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2);
     L.used = reinterpret_cast<unsigned char*>(L.stack + CAP);
     L.keep = L.used + CAP;
+    return L;
+}
+
+__device__ __constant__ const int kLadderK[8] = {3, 3, 5, 7, 11, 13, 17, 21};
+
+// ---- the 1 024-point instance (planes of 257 .. 1 024 candidates: only the 64 x 48 cell grid shows them): one wave per plane walks
+//      the whole ladder, rung after rung.  A fixed grid strides over list 2.
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_large_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+{
+    constexpr int CAP = kPolyMaxPoints;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* list = p.lists + (size_t)kPolyFull * p.listStride;
+    const unsigned nEntries = list[0];
+    const PolyLds L = carve_lds<CAP>(smem_all + (size_t)wave * ldsPerWave);
     for (;;)
     {
         unsigned entryNo = 0;
-        if (MODE == kPolyLadder)
-        {
-            if (threadIdx.x == 0)
-                s_ok[9] = (int)atomicAdd(&list[2], 1u);
-            __syncthreads();
-            entryNo = (unsigned)s_ok[9];
-        }
-        else
-        {
-            if (lane == 0)
-                entryNo = atomicAdd(&list[2], 1u);
-            entryNo = (unsigned)__builtin_amdgcn_readfirstlane((int)entryNo);
-        }
+        if (lane == 0)
+            entryNo = atomicAdd(&list[2], 1u);
+        entryNo = (unsigned)__builtin_amdgcn_readfirstlane((int)entryNo);
         if (entryNo >= nEntries)
             break;
-        const unsigned entry = list[kPolyListHeader + (entryNo < nFront ? entryNo : listCapacity - 1 - (entryNo - nFront))];
-        const int frame = (int)(entry >> 8), seg = (int)(entry & 255u);
-        const cape_plane_segment& S = p.records[frame].segments[seg];
-        cape_polygon* out = &p.polygons[(size_t)frame * CAPE_MAX_PLANES + seg];
-        double2* vout = p.vertices + (size_t)frame * p.boundaryCapacity + S.boundary_offset;
-        const int nPts = (int)S.boundary_count;
-        uint32_t flags = 0;
-#ifdef CAPE_POLY_PROFILE
-        unsigned long long _pt = __builtin_amdgcn_s_memtime();
-#endif
-        // ---- plane frame: get_plane_coordinate_system (polygon.cpp:74-115 with select_correct_transform :50-68)
-        const double nx = S.normal[0], ny = S.normal[1], nz = S.normal[2];
-        // the polygon's origin is Plane_Segment::get_center() = PlaneCoordinates::get_center() = normal * (-d), the point of the plane
-        // closest to the camera (primitive_detection.cpp:622, plane_segment.hpp:90, plane_coordinates.hpp:52) -- not the centroid
-        const double cx = p.originInCentroid ? S.centroid[0] : nx * (-S.d), cy = p.originInCentroid ? S.centroid[1] : ny * (-S.d),
-                     cz = p.originInCentroid ? S.centroid[2] : nz * (-S.d);
-        double xax, xay, xaz, yax, yay, yaz;
+        const unsigned entry = list[kPolyListHeader + entryNo];
+        const PlaneCtx c = plane_context(p, (int)(entry >> 8), (int)(entry & 255u));
+        if (c.flags)
         {
-            const double distX = fabs(nx), distY = fabs(ny), distZ = fabs(nz);
-            const double res = pmin(distX, pmin(distY, distZ));
-            double rx, ry, rz;
-            if (fabs(res - distX) <= 0.1)
-                rx = 1, ry = 0, rz = 0;
-            else if (fabs(res - distY) <= 0.1)
-                rx = 0, ry = 1, rz = 0;
-            else if (fabs(res - distZ) <= 0.1)
-                rx = 0, ry = 0, rz = 1;
-            else
-            {
-                rx = nz, ry = nx, rz = ny;
-                const double nn = sqrt((rx * rx + ry * ry) + rz * rz);
-                if (nn > 0)
-                    rx /= nn, ry /= nn, rz /= nn;
-            }
-            // xAxis = normalized(cross(normal, r)) ; yAxis = normalized(cross(normal, xAxis))
-            double ax = ny * rz - nz * ry, ay = nz * rx - nx * rz, az = nx * ry - ny * rx;
-            const double an = sqrt((ax * ax + ay * ay) + az * az);
-            if (an > 0)
-                ax /= an, ay /= an, az /= an;
-            double bx = ny * az - nz * ay, by = nz * ax - nx * az, bz = nx * ay - ny * ax;
-            const double bn = sqrt((bx * bx + by * by) + bz * bz);
-            if (bn > 0)
-                bx /= bn, by /= bn, bz /= bn;
-            xax = ax, xay = ay, xaz = az, yax = bx, yay = by, yaz = bz;
+            write_record(p, c, 0.0, 0, c.flags, lane);
+            continue;
         }
-        const double normalNorm = sqrt((nx * nx + ny * ny) + nz * nz);
-        int count = 0;
-        double area = 0.0;
-        if (!(fabs(normalNorm - 1.0) <= 1e-9) || nPts < 3)
-            flags |= CAPE_POLY_REJECTED; // the host constructor throws (normal not unit / fewer than 3 points)
-        else if (nPts > kPolyMaxPoints)
-            flags |= CAPE_POLY_OVERFLOW; // left to the host class
-        else
+        project_points(p, c, L, lane);
+        const int n = c.nPts, first = find_min_y_point(L.pts, n);
+        int hs = 0;
+        bool haveRing = false;
+        for (int a = 0; a < 8 && !haveRing; ++a)
         {
-            // ---- projection (polygon.cpp:125-144), in REVERSE order like the reference (:187-192); no sort, no duplicate removal
-            //      (concave_fitting.cpp:69: the overload this path binds does not call RemoveDuplicates)
-            const double* bnd = p.boundary + ((size_t)frame * p.boundaryCapacity + S.boundary_offset) * 3;
-            for (int i = lane; i < nPts; i += 64)
-            {
-                const double* q = bnd + 3 * (nPts - 1 - i);
-                const double dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
-                L.pts[i] = make_double2((xax * dx + xay * dy) + xaz * dz, (yax * dx + yay * dy) + yaz * dz);
-            }
-            CAPE_POLY_SYNC();
-            const int n = nPts;
-            const int first = find_min_y_point(L.pts, n);
-            CAPE_PTICK(0); // projection, start point
-            // ---- concave hull on the k ladder (third_party/concave_fitting.cpp: k = 3, then the primes, at most 8 attempts)
-            int hs = 0;
-            bool haveRing = false;
-            if (n >= 3 && MODE == kPolyLadder)
-            {
-                // rungs 2, 3, 4 (k = 5, 7, 11) at once, one per wave; if none has a hull, rungs 5, 6, 7 (k = 13, 17, 21).  The
-                // lowest rung with a simple hull wins and finishes the polygon -- a higher rung gives up as soon as it sees a
-                // lower one succeed -- and if none has one, wave 0 takes the convex fallback (every wave holds the same points).
-                const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
-                constexpr int kNoRung = 99;
-                if (threadIdx.x == 0)
-                    s_ok[8] = kNoRung; // the lowest rung that has a hull so far
-                __syncthreads();
-#ifdef CAPE_POLY_PROFILE
-                const unsigned long long ladderStart = __builtin_amdgcn_s_memtime();
-#endif
-                // wave w walks rung w + 2 and, if that fails, rung 7 - w (the wave with the longest first walk, k = 11, takes the
-                // shortest second one, k = 13: 2-4 % on the whole pass) -- without waiting for the others; it stops as soon as a
-                // rung below its own has a hull (it can no longer win)
-                int myRung = kNoRung;
-                for (int stage = 0; stage < 2; ++stage)
-                {
-                    const int rung = stage == 0 ? 2 + wave : 7 - wave; // (k = 5, 21), (7, 17), (11, 13): the long first walk is followed by the short second one
-                    if (__builtin_amdgcn_readfirstlane(*(volatile int*)(s_ok + 8)) < rung)
-                        break;
-                    if (ladder[rung] > n)
-                        continue; // the reference stops climbing when the next k exceeds the point count (concave_fitting.cpp:86-87)
-                    CAPE_PCOUNT(8, 1); // hull attempts
-                    const bool ok = concave_hull_k<CAP>(L, n, first, ladder[rung], lane, hs, s_ok + 8, rung);
-                    CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
-                    if (ok)
-                    {
-                        myRung = rung;
-                        if (lane == 0)
-                            atomicMin(s_ok + 8, rung);
-                        break;
-                    }
-                }
-                __syncthreads();
-                const int best = s_ok[8];
-                __syncthreads(); // the word is reset for the next plane
-#ifdef CAPE_POLY_PROFILE
-                if (wave == 0)
-                {
-                    // slots 12 (no rung: convex fallback), 14 .. 19 (winning rung 2 .. 7), 20 points, 21 ticks, 22 slowest plane of the frame
-                    const unsigned long long dt = __builtin_amdgcn_s_memtime() - ladderStart;
-                    CAPE_PCOUNT(12 + (best == kNoRung ? 0 : best), 1);
-                    CAPE_PCOUNT(20, n);
-                    CAPE_PCOUNT(21, dt);
-                    if (lane == 0 && p.prof)
-                        atomicMax(&p.prof[(size_t)frame * kProfileSlots + 22], dt);
-                }
-#endif
-                const int winner = best == kNoRung ? -1 : (best <= 4 ? best - 2 : 7 - best);
-                haveRing = winner >= 0 && myRung == best;
-                if (wave != (winner < 0 ? 0 : winner))
-                    continue;
-                if (winner < 0)
-                    haveRing = false;
-            }
-            else if (n >= 3)
-            {
-                const int ladder[8] = {3, 3, 5, 7, 11, 13, 17, 21};
-                const int aLast = MODE == kPolyFull ? 7 : 0;
-                for (int a = 0; a <= aLast && !haveRing; ++a)
-                {
-                    const int k = ladder[a];
-                    if (a > 0 && k > n)
-                        break; // the next k exceeds the point count (concave_fitting.cpp:86-87)
-                    // (the ladder's second rung repeats the first: the run is a pure function of the points and k, so a
-                    //  failed k = 3 fails again -- the host class runs it twice, the result is the same)
-                    if (a == 1)
-                        continue;
-                    CAPE_PCOUNT(8, 1); // hull attempts
-                    haveRing = concave_hull_k<CAP>(L, n, first, k, lane, hs);
-                    CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
-                }
-                if (MODE == kPolyFirstRung && !haveRing)
-                {
-                    // the first rung failed: the ladder kernel takes the plane
-                    if (lane == 0)
-                    {
-                        uint32_t* ladderList = p.lists + (size_t)kPolyLadder * p.listStride;
-                        if (n >= kPolyBigPoints)
-                            ladderList[kPolyListHeader + atomicAdd(&ladderList[0], 1u)] = entry;
-                        else
-                            ladderList[kPolyListHeader + listCapacity - 1 - atomicAdd(&ladderList[1], 1u)] = entry;
-                    }
-                    continue;
-                }
-            }
-            unsigned short* ring = L.ring;
-            int rn = 0;
-            if (haveRing)
-            {
-                // The repair of the constructor (polygon.cpp:195-226 -> correct_boost_polygon.hpp:188-195, :172-186): the walk's ring,
-                // closed, is reversed when it runs counter-clockwise -- it does, and it still starts at the walk's start point.  Kept
-                // open here: the closing vertex goes.
-                int m = hs;
-                if (m > 1 && points_equal(L.pts[L.hull[m - 1]], L.pts[L.hull[0]]))
-                    --m;
-                const bool rev = m >= 3 && ring_area_signed(L.pts, L.hull, m) > 0;
-                for (int i = lane; i < m; i += 64)
-                    ring[i] = L.hull[(rev && i > 0) ? m - i : i];
-                rn = m;
-                CAPE_POLY_SYNC();
-                // A hull that touches or crosses itself is dissolved with Boost set operations in the reference
-                // (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull
-                if (!ring_is_simple(L.pts, ring, rn, lane))
-                    haveRing = false;
-                CAPE_PTICK(2); // simple-ring test of the oriented hull
-            }
-            if (!haveRing)
-            {
-                // ---- compute_convex_hull (monotone chain over the sorted, deduplicated points), reversed to clockwise.
-                //      Sequential by nature; every lane runs it on the same values, lane 0 writes.
-                flags |= CAPE_POLY_CONVEX_FALLBACK;
-                // the walk needed the points in the reference's order; the chain needs them sorted by (x, y) and distinct
-                int n = nPts;
-                sort_points(L, n, lane);
-                {
-                    int nd = 0;
-                    for (int base = 0; base < n; base += 64)
-                    {
-                        const int i = base + lane;
-                        double2 q = make_double2(0, 0);
-                        bool keepIt = false;
-                        if (i < n)
-                        {
-                            q = L.pts[i];
-                            keepIt = true;
-                            if (i > 0)
-                            {
-                                const double2 prev = L.pts[i - 1];
-                                keepIt = !(prev.x == q.x && prev.y == q.y);
-                            }
-                        }
-                        const unsigned long long kb = __ballot(keepIt);
-                        CAPE_POLY_SYNC(); // every lane has read its point (and its left neighbour) before the chunk is compacted
-                        if (keepIt)
-                            L.pts[nd + __popcll(kb & ((1ull << lane) - 1ull))] = q;
-                        nd += __popcll(kb);
-                        CAPE_POLY_SYNC();
-                    }
-                    n = nd;
-                }
-                if (n < 3)
-                {
-                    if (lane < n)
-                        ring[lane] = (unsigned short)lane;
-                    rn = n;
-                }
-                else
-                {
-                    unsigned short* hstk = L.hull; // 2 n entries at most: hull + ring areas are contiguous
-                    int kx = 0;
-                    for (int i = 0; i < n; ++i)
-                    {
-                        while (kx >= 2 && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i]) <= 0)
-                            kx--;
-                        if (lane == 0)
-                            hstk[kx] = (unsigned short)i;
-                        kx++;
-                        CAPE_POLY_SYNC();
-                    }
-                    for (int i = n - 1, t = kx + 1; i > 0; --i)
-                    {
-                        while (kx >= t && pcross2(L.pts[hstk[kx - 2]], L.pts[hstk[kx - 1]], L.pts[i - 1]) <= 0)
-                            kx--;
-                        if (lane == 0)
-                            hstk[kx] = (unsigned short)(i - 1);
-                        kx++;
-                        CAPE_POLY_SYNC();
-                    }
-                    const int hn = kx - 1;
-                    // clockwise, starting at the leftmost point like the chain (host: reverse(h.begin() + 1, h.end())); through
-                    // registers: hull and ring share LDS when the chain ran past kPolyMaxPoints entries
-                    unsigned short tmp[kPolyPerLane];
-#pragma unroll
-                    for (int j = 0; j < kPolyPerLane; ++j)
-                    {
-                        const int i = lane + 64 * j;
-                        tmp[j] = i < hn ? hstk[i == 0 ? 0 : hn - i] : (unsigned short)0;
-                    }
-                    CAPE_POLY_SYNC();
-#pragma unroll
-                    for (int j = 0; j < kPolyPerLane; ++j)
-                    {
-                        const int i = lane + 64 * j;
-                        if (i < hn)
-                            ring[i] = tmp[j];
-                    }
-                    rn = hn;
-                }
-                CAPE_POLY_SYNC();
-            }
-            CAPE_PTICK(3); // orientation, validity of the oriented ring, convex fallback
-            CAPE_PCOUNT(9, rn); // vertices before simplification
-            CAPE_PCOUNT(10, nPts); // points
-            area = rn >= 3 ? fabs(ring_area_signed(L.pts, ring, rn)) : 0.0;
-            // ---- simplify (polygon.cpp:578-601): Douglas-Peucker on the closed ring, threshold max(area / 1e5, 10); kept if the
-            //      result is a simple ring whose area stays above 75 %
-            if (rn >= 4)
-            {
-                const double eps = pmax(area / 1e5, 10.0);
-                unsigned short* closed = L.hull; // rn + 1 entries
-                for (int i = lane; i <= rn; i += 64)
-                {
-                    closed[i] = ring[i < rn ? i : 0];
-                    L.keep[i] = (i == 0 || i == rn) ? 1 : 0;
-                }
-                CAPE_POLY_SYNC();
-                int sp = 0;
-                if (lane == 0)
-                    L.stack[0] = (unsigned)rn; // (a << 16) | b with a = 0
-                sp = 1;
-                CAPE_POLY_SYNC();
-                while (sp > 0)
-                {
-                    const unsigned ab = L.stack[--sp];
-                    const int a = (int)(ab >> 16), b = (int)(ab & 0xFFFFu);
-                    if (b <= a + 1)
-                        continue;
-                    const double2 pa = L.pts[closed[a]], pb = L.pts[closed[b]];
-                    unsigned long long best = 0ull; // squared distance bits (>= +0); the first index wins a tie, like the host's strict >
-                    int bestI = 0x7FFFFFFF;
-                    for (int i = a + 1 + lane; i < b; i += 64)
-                    {
-                        const double d = segment_distance2(L.pts[closed[i]], pa, pb);
-                        const unsigned long long db = (unsigned long long)__double_as_longlong(d);
-                        if (bestI == 0x7FFFFFFF || db > best)
-                        {
-                            best = db;
-                            bestI = i;
-                        }
-                    }
-                    // wave maximum of the distance, smallest index among the equal ones
-                    unsigned long long mx = best;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-                    {
-                        const unsigned long long ob = (unsigned long long)__shfl_xor((long long)mx, o);
-                        mx = ob > mx ? ob : mx;
-                    }
-                    const unsigned mineKey = (bestI != 0x7FFFFFFF && best == mx) ? (unsigned)(0x7FFFFFFF - bestI) : 0u;
-                    const int idx = 0x7FFFFFFF - (int)wave_max_u32(mineKey);
-                    const double dmax = __longlong_as_double((long long)mx);
-                    if (dmax > eps * eps)
-                    {
-                        if (lane == 0)
-                        {
-                            L.keep[idx] = 1;
-                            L.stack[sp] = ((unsigned)a << 16) | (unsigned)idx;
-                            L.stack[sp + 1] = ((unsigned)idx << 16) | (unsigned)b;
-                        }
-                        sp += 2;
-                        CAPE_POLY_SYNC();
-                    }
-                }
-                // candidate ring = the kept vertices of closed[0, rn) ; built in the stack area (as u16), then tested
-                unsigned short* cand = reinterpret_cast<unsigned short*>(L.stack);
-                int cn = 0;
-                for (int base = 0; base < rn; base += 64)
-                {
-                    const int i = base + lane;
-                    const bool k = i < rn && L.keep[i];
-                    const unsigned long long kb = __ballot(k);
-                    if (k)
-                        cand[cn + __popcll(kb & ((1ull << lane) - 1ull))] = closed[i];
-                    cn += __popcll(kb);
-                }
-                CAPE_POLY_SYNC();
-                if (cn >= 3 && ring_is_simple(L.pts, cand, cn, lane))
-                {
-                    const double newArea = fabs(ring_area_signed(L.pts, cand, cn));
-                    if (newArea > area * 0.75)
-                    {
-                        for (int i = lane; i < cn; i += 64)
-                            ring[i] = cand[i];
-                        rn = cn;
-                        area = newArea;
-                        flags |= CAPE_POLY_SIMPLIFIED;
-                        CAPE_POLY_SYNC();
-                    }
-                }
-            }
-            CAPE_PTICK(4); // area + simplify
-            // ---- what Primitive_Detection keeps: a valid polygon of at least three vertices (primitive_detection.cpp:623-631)
-            if (rn >= 3 && ring_is_simple(L.pts, ring, rn, lane))
-                flags |= CAPE_POLY_VALID;
-            for (int i = lane; i < rn; i += 64)
-                vout[i] = L.pts[ring[i]];
-            count = rn;
-            CAPE_PTICK(5); // final validity, vertex stores
-            CAPE_PCOUNT(11, 1); // planes
+            const int k = kLadderK[a];
+            if (a > 0 && k > n)
+                break; // the next k exceeds the point count (concave_fitting.cpp:86-87)
+            if (a == 1)
+                continue; // (the second rung repeats the first: a run is a pure function of the points and k)
+            haveRing = concave_hull_k<CAP>(L, n, first, k, lane, hs);
         }
-        if (lane == 0)
-        {
-            out->x_axis[0] = xax; out->x_axis[1] = xay; out->x_axis[2] = xaz;
-            out->y_axis[0] = yax; out->y_axis[1] = yay; out->y_axis[2] = yaz;
-            out->center[0] = cx; out->center[1] = cy; out->center[2] = cz;
-            out->area = area;
-            out->vertex_offset = S.boundary_offset;
-            out->vertex_count = (uint32_t)count;
-            out->flags = flags;
-            out->segment = (uint32_t)seg;
-        }
-        CAPE_POLY_SYNC();
+        finish_polygon<CAP>(p, c, L, haveRing, hs, lane);
     }
 }
 
-// one wavefront per frame, lane j <- segment j: the work lists of the three polygon kernels, and the records of the segments
-// that need no kernel (not an output plane: empty record)
+// ---- planes of up to 256 candidates (every plane of the 640 x 480 streams): TASKS, one wavefront each ------------------------
+// A task is one run of the walk for one (plane, rung).  A plane enters through the static list (the output planes of the batch,
+// the big ones first) as its rung 0; a plane whose rungs all failed so far SPAWNS its next rungs into the dynamic queue, which
+// every idle wave serves first.  The rungs of a plane run side by side on whatever waves are free, exactly as if they had run
+// one after the other (a run is a pure function of the points and k; the lowest rung with a hull wins, concave_fitting.cpp:78-88):
+//   * per plane a STATE word (done mask | hull mask << 8 | finalised << 16), updated with one atomicOr per finished task;
+//   * a rung with a hull that cannot know yet whether a lower rung will have one PARKS its hull (point indices) in global
+//     memory; the wave whose atomicOr makes the verdict definitive -- the lowest hull's lower rungs are all done -- builds the
+//     polygon from it (every wave of a plane holds the same projected points);
+//   * the wave whose atomicOr completes a stage without any hull spawns the next stage, or takes the convex fallback when the
+//     ladder is exhausted.
+// How many rungs start together depends on the plane's size, because a kernel lasts as long as its longest CHAIN of walks:
+// below 100 candidates rung 0, then k = 5, 7, 11, then 13, 17, 21 (three short walks in a row at worst); from 100 on rung 0,
+// then all six; from 130 on all seven at once (one long walk).  Rounds 1-3 ran a first-rung kernel and then a ladder kernel
+// of three-wave workgroups: the second lasted as long as its slowest plane (0.93 of 1.0 ms) while the device idled.
+constexpr uint32_t kStDoneShift = 0, kStHullShift = 8, kStFinal = 1u << 16;
+constexpr uint32_t kTaskEmpty = 0xFFFFFFFFu, kTaskQuit = 0xFFFFFFFEu;
+constexpr int kParkRungs = 6;       // rungs 2 .. 7 park; rung 0 never waits for a lower one
+#ifndef CAPE_POLY_MID
+#define CAPE_POLY_MID 100
+#endif
+#ifndef CAPE_POLY_ALL
+#define CAPE_POLY_ALL 130
+#endif
+constexpr int kPolyMidPoints = CAPE_POLY_MID; // from here on the six remaining rungs start together
+constexpr int kPolyAllPoints = CAPE_POLY_ALL; // from here on all seven rungs start together
+
+__device__ __forceinline__ uint32_t rungs_that_exist(int n)
+{
+    uint32_t m = 1u; // rung 0; rung 1 repeats it
+#pragma unroll
+    for (int a = 2; a < 8; ++a)
+        if (kLadderK[a] <= n)
+            m |= 1u << a;
+    return m;
+}
+// cumulative stage masks of a plane of n candidates: the rungs started so far once stage i has been spawned
+__device__ __forceinline__ uint32_t stage_mask(int n, int stage, uint32_t exist)
+{
+    uint32_t m;
+    if (n >= kPolyAllPoints)
+        m = 0xFDu;
+    else if (n >= kPolyMidPoints)
+        m = stage == 0 ? 0x01u : 0xFDu;
+    else
+        m = stage == 0 ? 0x01u : (stage == 1 ? 0x1Du : 0xFDu);
+    return m & exist;
+}
+
+// a counter as the atomics see it
+__device__ __forceinline__ uint32_t fresh_u32(uint32_t* a) { return atomicAdd(a, 0u); }
+// polling loads: device scope (served by the L2 the atomics go to; the default system scope goes out to memory every time)
+__device__ __forceinline__ uint32_t load_u32(const uint32_t* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// a plane has its polygon; the wave that finishes the LAST one sends every waiting wave home: one kTaskQuit per wave of the grid
+// behind the last task (a wave holds at most one ticket at a time, so that many tickets can be out or still be taken)
+__device__ inline void plane_finished(uint32_t* statList, uint32_t* dynList, unsigned listCapacity, unsigned totalWaves, int lane)
+{
+    unsigned left = 1;
+    if (lane == 0)
+        left = atomicSub(&statList[3], 1u) - 1u;
+    left = (unsigned)__builtin_amdgcn_readfirstlane((int)left);
+    if (left != 0)
+        return;
+    unsigned at = 0;
+    if (lane == 0)
+        at = atomicAdd(&dynList[0], totalWaves);
+    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+    for (unsigned i = lane; i < totalWaves; i += 64)
+        if (at + i < listCapacity)
+            __hip_atomic_store(&dynList[kPolyListHeader + at + i], kTaskQuit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+{
+    constexpr int CAP = kPolySmallPoints;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* statList = p.lists + (size_t)kPolyFirstRung * p.listStride; // [0] front count [1] back count [2] next [3] planes not finished
+    uint32_t* dynList = p.lists + (size_t)kPolyLadder * p.listStride;     // [0] tail [1] head
+    const unsigned nFront = statList[0], nStatic = nFront + statList[1];
+    const unsigned listCapacity = p.listStride - kPolyListHeader;
+    const PolyLds L = carve_lds<CAP>(smem_all + (size_t)wave * ldsPerWave);
+    // One wave in four serves the spawned rungs from the start (they sit on some plane's critical chain of walks and must not
+    // queue behind the planes of the batch); the others take planes of the batch and become servers when those are handed out.
+#ifndef CAPE_POLY_SERVER_EVERY
+#define CAPE_POLY_SERVER_EVERY 1
+#endif
+    bool server = CAPE_POLY_SERVER_EVERY > 0 && wave == kPolyWavesPerGroup - 1 && blockIdx.x % (CAPE_POLY_SERVER_EVERY > 0 ? CAPE_POLY_SERVER_EVERY : 1) == 0; // (lane 0's copy counts)
+    const unsigned totalWaves = gridDim.x * kPolyWavesPerGroup;
+    if (statList[3] == 0u)
+        return; // no plane in the batch: nobody would ever send the waiting waves home
+    for (;;)
+    {
+        // ---- next task: a spawned rung first (it sits on some plane's critical chain), else the next plane of the batch
+        unsigned task = kTaskEmpty;
+        bool isStatic = false;
+#ifdef CAPE_POLY_PROFILE
+        const unsigned long long acq0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (lane == 0)
+        {
+            if (!server)
+            {
+                const unsigned e = atomicAdd(&statList[2], 1u);
+                if (e < nStatic)
+                {
+                    const unsigned entry = statList[kPolyListHeader + (e < nFront ? e : listCapacity - 1 - (e - nFront))];
+                    task = entry << 3; // rung 0
+                    isStatic = true;
+                }
+                else
+                    server = true; // the planes of the batch are handed out: from now on this wave serves spawned rungs
+            }
+            if (task == kTaskEmpty)
+            {
+                // a TICKET: the next slot of the queue is this wave's, whoever fills it and whenever.  No compare-and-swap, no shared
+                // word to poll -- every waiting wave watches its own slot (read with a fetch-add of 0: a plain load may be served by
+                // this XCD's L2, which is not coherent with the one the writer's store went through).  The wave that finishes the
+                // batch's last plane fills every ticket still out with kTaskQuit.
+                const unsigned ticket = atomicAdd(&dynList[1], 1u);
+                if (ticket < listCapacity)
+                {
+                    uint32_t t;
+                    while ((t = fresh_u32(&dynList[kPolyListHeader + ticket])) == kTaskEmpty)
+                        __builtin_amdgcn_s_sleep(64);
+                    task = t;
+                }
+                else
+                    task = kTaskQuit; // (cannot happen: the queue holds a slot per possible task and per wave)
+            }
+        }
+        task = (unsigned)__builtin_amdgcn_readfirstlane((int)task);
+        isStatic = __builtin_amdgcn_readfirstlane((int)isStatic) != 0;
+#ifdef CAPE_POLY_PROFILE
+        if (lane == 0 && p.prof)
+        {
+            // frame 0's slots 24 .. 27: ticks spent getting a task (static / spawned), tasks of either kind
+            atomicAdd(&p.prof[isStatic ? 24 : 25], __builtin_amdgcn_s_memtime() - acq0);
+            atomicAdd(&p.prof[isStatic ? 26 : 27], 1ull);
+        }
+#endif
+        if (task == kTaskQuit)
+            break;
+        const int rung = (int)(task & 7u);
+        const PlaneCtx c = plane_context(p, (int)(task >> 11), (int)((task >> 3) & 255u));
+#ifdef CAPE_POLY_PROFILE
+        const int frame = c.frame;
+        unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#endif
+        if (c.flags)
+        {
+            // nothing to walk (the list kernel sends these through as rung 0 only)
+            write_record(p, c, 0.0, 0, c.flags, lane);
+            plane_finished(statList, dynList, listCapacity, totalWaves, lane);
+            continue;
+        }
+        const int n = c.nPts;
+        uint32_t* state = p.state + (size_t)c.frame * CAPE_MAX_PLANES + c.seg;
+        if (!isStatic)
+        {
+            // a spawned rung that can no longer win (the plane has its polygon, or a lower rung its hull) is not walked at all
+            uint32_t st = 0;
+            if (lane == 0)
+                st = fresh_u32(state);
+            st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+            if ((st & kStFinal) || (((st >> kStHullShift) & 0xFFu) & ((1u << rung) - 1u)))
+                continue;
+        }
+        const uint32_t exist = rungs_that_exist(n);
+        auto spawn = [&](uint32_t rungs) {
+            // lane 0: append one task per rung; a queue that is full (never on the test streams: it holds 64 tasks per frame)
+            // sends the rungs back to the caller, which walks them itself
+            uint32_t left = rungs;
+            if (lane == 0 && rungs)
+            {
+                const unsigned cnt = (unsigned)__popc(rungs);
+                const unsigned at = atomicAdd(&dynList[0], cnt);
+                unsigned k = 0;
+                for (int a = 0; a < 8; ++a)
+                    if ((rungs >> a) & 1u)
+                    {
+                        if (at + k + totalWaves < listCapacity)
+                        {
+                            __hip_atomic_store(&dynList[kPolyListHeader + at + k], ((unsigned)c.frame << 11) | ((unsigned)c.seg << 3) | (unsigned)a, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            left &= ~(1u << a);
+                        }
+                        ++k;
+                    }
+            }
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+        };
+        project_points(p, c, L, lane);
+        const int first = find_min_y_point(L.pts, n);
+        CAPE_PTICK(0); // projection, start point
+        uint32_t mine = 1u << rung; // the rungs this wave walks: its task, plus whatever a full queue hands back
+        if (isStatic)
+            mine |= spawn(stage_mask(n, 0, exist) & ~1u);
+        bool finished = false;
+        while (mine && !finished)
+        {
+            const int r = __ffs((int)mine) - 1;
+            mine &= ~(1u << r);
+            int hs = 0;
+            CAPE_PCOUNT(8, 1); // hull attempts
+            const bool ok = concave_hull_k<CAP>(L, n, first, kLadderK[r], lane, hs, state, r);
+            CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
+            uint32_t old = 0;
+            if (lane == 0)
+            {
+                if (ok && r > 0)
+                {
+                    // park the hull: [0] its length, then the point indices
+                    unsigned short* park = p.park + ((size_t)c.frame * kParkRungs + (r - 2)) * p.parkStride + p.records[c.frame].segments[c.seg].boundary_offset + 2 * c.seg; // (offsets grow with the segment index: n + 2 entries fit)
+                    park[0] = (unsigned short)hs;
+                    for (int i = 0; i < hs; ++i)
+                        park[1 + i] = L.hull[i];
+                    __threadfence();
+                }
+                old = atomicOr(state, (1u << (kStDoneShift + r)) | (ok ? (1u << (kStHullShift + r)) : 0u));
+            }
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            const uint32_t now = old | (1u << r) | (ok ? (1u << (kStHullShift + r)) : 0u);
+            const uint32_t done = now & 0xFFu, hulls = (now >> kStHullShift) & 0xFFu;
+            int winner = -2; // -2: nothing to decide yet, -1: convex fallback, >= 0: this rung's hull
+            if (hulls)
+            {
+                const int w = __ffs((int)hulls) - 1;
+                if ((done & exist & ((1u << w) - 1u)) == (exist & ((1u << w) - 1u)))
+                    winner = w;
+            }
+            else
+            {
+                // a stage without a hull is complete: the wave whose bit completed it moves the plane on
+                for (int stage = 0; stage < 3; ++stage)
+                {
+                    const uint32_t sm = stage_mask(n, stage, exist);
+                    if ((done & sm) == sm && (old & sm) != sm)
+                    {
+                        const uint32_t next = stage < 2 ? (stage_mask(n, stage + 1, exist) & ~sm) : 0u;
+                        if (sm == exist)
+                            winner = -1; // the ladder is exhausted
+                        else if (next)
+                            mine |= spawn(next);
+                        break;
+                    }
+                }
+            }
+            if (winner == 0 && r != 0)
+                winner = -2; // rung 0 never parks (no lower rung can overrule it): the wave that walked it builds the polygon itself
+            if (winner != -2)
+            {
+                uint32_t before = kStFinal;
+                if (lane == 0)
+                    before = atomicOr(state, kStFinal);
+                before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+                if (!(before & kStFinal))
+                {
+                    if (winner >= 0 && !(ok && winner == r))
+                    {
+                        // somebody else's hull: out of the parking area (its writer fenced before it set the bit this wave saw)
+                        __threadfence();
+                        const unsigned short* park = p.park + ((size_t)c.frame * kParkRungs + (winner - 2)) * p.parkStride + p.records[c.frame].segments[c.seg].boundary_offset + 2 * c.seg; // (offsets grow with the segment index: n + 2 entries fit)
+                        hs = (int)__hip_atomic_load(&park[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int i = lane; i < hs; i += 64)
+                            L.hull[i] = __hip_atomic_load(&park[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        CAPE_POLY_SYNC();
+                    }
+                    CAPE_PCOUNT(12 + (winner < 0 ? 0 : winner), 1);
+                    finish_polygon<CAP>(p, c, L, winner >= 0, hs, lane);
+#ifdef CAPE_POLY_DEBUG_RUNG
+                    if (lane == 0)
+                        p.polygons[(size_t)c.frame * CAPE_MAX_PLANES + c.seg].flags |= ((uint32_t)(winner + 1) << 8) | ((uint32_t)r << 12) | (now << 16);
+#endif
+                    plane_finished(statList, dynList, listCapacity, totalWaves, lane);
+                }
+                finished = true;
+            }
+        }
+    }
+}
+
+// one wavefront per frame, lane j <- segment j: the static list of the task kernel (planes of up to 256 candidates; the big
+// ones from the front, the others from the back), the list of the 1 024-point instance, and the count of planes to finish
 constexpr int kListFrames = 16; // frames (waves) of a list workgroup: ONE atomic per list and workgroup -- a counter that every
                                 // frame's wave bumps on its own serialises 4 096 atomics on one address (74 us of the pass)
 __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames)
@@ -968,13 +1191,13 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
         const cape_frame_record& rec = p.records[frame];
         isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
         nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
+        p.state[(size_t)frame * CAPE_MAX_PLANES + lane] = 0u;
     }
     // (segments that are no output plane keep the empty record launch_polygons' memset left)
     // 257 .. 1 024 candidates: the large instance; everything else (incl. what it will only flag: too few / too many points)
-    // goes to the small one
+    // goes to the task kernel
     const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
     const bool small = isOut && !large;
-    // small-instance planes: the big ones from the front of the list, the others from its back (see cape_polygon_kernel)
     const bool big = small && nPts >= kPolyBigPoints && nPts <= kPolySmallPoints;
     const bool rest = small && !big;
     const unsigned long long mb = __ballot(big), mr = __ballot(rest), ml = __ballot(large);
@@ -998,6 +1221,8 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
         }
         unsigned* counter = threadIdx.x == 0 ? &listS[0] : threadIdx.x == 1 ? &listS[1] : &listL[0];
         const unsigned base = total ? atomicAdd(counter, total) : 0u;
+        if (threadIdx.x < 2 && total)
+            atomicAdd(&listS[3], total); // planes the task kernel has to finish
         for (int w = 0; w < kListFrames; ++w)
             s_base[threadIdx.x][w] += base;
     }
@@ -1013,6 +1238,8 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
         listL[kPolyListHeader + baseL + __popcll(ml & below)] = entry;
 }
 
+constexpr size_t kPolyQuitSlots = 8192; // room behind the tasks of a queue for one kTaskQuit per wave of the task kernel's grid
+
 size_t polygon_lds_bytes(int cap)
 {
     size_t b = (size_t)cap * 16;            // pts
@@ -1022,35 +1249,50 @@ size_t polygon_lds_bytes(int cap)
     return (b + 15) & ~(size_t)15;
 }
 
+// scratch of a polygon pass over `frames` frames: three work lists, the state words, the parking area
+size_t polygon_scratch_bytes(size_t frames, int boundaryCapacity)
+{
+    const size_t lists = 3 * (frames * CAPE_MAX_PLANES + kPolyListHeader + kPolyQuitSlots) * sizeof(uint32_t);
+    const size_t state = frames * CAPE_MAX_PLANES * sizeof(uint32_t);
+    const size_t park = frames * kParkRungs * ((size_t)boundaryCapacity + 2 * CAPE_MAX_PLANES) * sizeof(unsigned short);
+    return lists + state + park + 64;
+}
+void polygon_bind_scratch(PolygonParams& p, void* base, size_t frames, int boundaryCapacity)
+{
+    p.lists = static_cast<uint32_t*>(base);
+    p.listStride = (uint32_t)(frames * CAPE_MAX_PLANES + kPolyListHeader + kPolyQuitSlots);
+    p.state = p.lists + 3 * (size_t)p.listStride;
+    p.park = reinterpret_cast<unsigned short*>(p.state + frames * CAPE_MAX_PLANES);
+    p.parkStride = (uint32_t)(boundaryCapacity + 2 * CAPE_MAX_PLANES);
+}
+
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    // the headers of the three work lists (list m at p.lists + m * listStride)
+    // the headers of the three work lists (list m at p.lists + m * listStride), and the dynamic queue's "not written yet" marks
     for (int m = 0; m < 3; ++m)
         if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
             return e;
+    const size_t wanted = (size_t)nFrames * CAPE_MAX_PLANES + kPolyQuitSlots;
+    const size_t queue = wanted < (size_t)(p.listStride - kPolyListHeader) ? wanted : (size_t)(p.listStride - kPolyListHeader);
+    if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)kPolyLadder * p.listStride + kPolyListHeader, 0xFF, queue * sizeof(uint32_t), stream); e != hipSuccess)
+        return e;
     if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
-    // fixed grids striding over their lists: enough workgroups to fill the device, never more than the list can hold
+    // persistent grids: as many workgroups as the device holds at once (four waves per SIMD), never more than there can be planes
     const int maxPlanes = nFrames * CAPE_MAX_PLANES;
-    const int gridSmall = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * 5);
-    const int gridLadder = std::min(maxPlanes, p.computeUnits * 6);
+    const int gridSmall = std::min(std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * 4), (int)(kPolyQuitSlots / kPolyWavesPerGroup));
     const int gridLarge = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits);
-    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyFirstRung>), dim3(gridSmall), dim3(64 * kPolyWavesPerGroup),
-                       (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p, nFrames, ldsSmall);
-    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
-        return e;
-    // planes that failed the first rung: one workgroup of three waves each
-    hipLaunchKernelGGL((cape_polygon_kernel<kPolySmallPoints, kPolyLadder>), dim3(gridLadder), dim3(64 * kLadderWaves),
-                       (size_t)ldsSmall * kLadderWaves + 64, stream, p, nFrames, ldsSmall);
+    hipLaunchKernelGGL(cape_polygon_task_kernel, dim3(gridSmall), dim3(64 * kPolyWavesPerGroup), (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,
+                       nFrames, ldsSmall);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     if (p.boundaryCapacity > kPolySmallPoints) // a plane cannot hold more boundary points than the frame
-        hipLaunchKernelGGL((cape_polygon_kernel<kPolyMaxPoints, kPolyFull>), dim3(gridLarge), dim3(64 * kPolyWavesPerGroup),
-                           (size_t)ldsLarge * kPolyWavesPerGroup + 64, stream, p, nFrames, ldsLarge);
+        hipLaunchKernelGGL(cape_polygon_large_kernel, dim3(gridLarge), dim3(64 * kPolyWavesPerGroup), (size_t)ldsLarge * kPolyWavesPerGroup + 64, stream, p,
+                           nFrames, ldsLarge);
     return hipGetLastError();
 }
 
