@@ -53,7 +53,9 @@ if os.environ.get("CAPE_POLY_PHASES"):
     raw = ex.debug_cycles(B).astype(np.float64)
     print("task kernel: static tasks %d (%.0f ticks each to get), spawned / idle-exit acquisitions %d (%.0f ticks each)" % (
         raw[0, 26], raw[0, 24] / max(1, raw[0, 26]), raw[0, 27], raw[0, 25] / max(1, raw[0, 27])))
-    print("   acquisition loop iterations %d, failed CAS %d, spins on an unwritten slot %d" % (raw[0, 28], raw[0, 29], raw[0, 30]))
+    t = ex.debug_cycles(B)[0].astype(np.int64)
+    print("   timeline (ticks from the first wave's start): planes of the batch handed out %d, last polygon %d, last wave leaves %d; busy %.0f ticks per wave (%d waves)" % (
+        t[7] - t[6], t[23] - t[6], t[31] - t[6], float(t[28]) / (ex.compute_units * 16), ex.compute_units * 16))
 if os.environ.get("CAPE_POLY_PHASES"):
     per = ex.debug_cycles(B).astype(np.float64)
     t = per[:, :6].sum(1)

@@ -1834,6 +1834,7 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     p.prof = h->debugCycles;
 #ifdef CAPE_POLY_PROFILE
     CAPE_HIP_TRY(hipMemsetAsync(h->debugCycles, 0, (size_t)n_frames * cape::kProfileSlots * 8, stream));
+    CAPE_HIP_TRY(hipMemsetAsync(h->debugCycles + 6, 0xFF, 2 * 8, stream)); // the two minima of the task kernel's timeline
 #endif
     h->doneArmed = false; // the chain's completion word was written before this kernel: results are waited for the slow way
     CAPE_HIP_TRY(cape::launch_polygons(p, n_frames, stream));

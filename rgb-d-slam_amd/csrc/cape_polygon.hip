@@ -273,7 +273,7 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 // hull's point indices are in L.hull[0, hs) exactly as the reference's vector holds them: ending with the start point again
 // when the walk came back to it, every point once when it ran out of points first.
 // `planeState` (task kernel only, else null): the plane's state word in global memory; a rung gives up as soon as a lower rung
-// has its hull (or the plane is finalised) -- it can no longer win.  Looked at every eighth step.
+// has its hull (or the plane is finalised) -- it can no longer win.  Looked at every sixteenth step (a read-modify-write: ~2 us).
 template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
                                                         int myRung = 0)
 {
@@ -293,15 +293,42 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         return true;
     }
     const double2 firstPt = pts[first];
-    for (int i = lane; i < n; i += 64)
-        L.used[i] = 0;
-    CAPE_POLY_SYNC();
-    if (lane == 0)
+    // Every lane keeps ITS points (i = lane + 64 j) in registers for the whole walk, and which of them are hidden from the
+    // neighbour search as a bit mask: the walk's inner loop reads LDS only for the hull edges.  (A lone wave -- the end of a
+    // batch, a one-frame call -- pays ~120 cycles per dependent LDS round trip; a step had eight of them.)
+    // (the 1 024-point instance has sixteen points per lane: those stay in LDS, only the mask lives in a register)
+    constexpr bool kInRegs = kPolyPerLane <= 4;
+    double2 myPts[kInRegs ? kPolyPerLane : 1];
+    unsigned myUsed = 0; // bit j: point lane + 64 j is hidden (on the hull)
+    if (kInRegs)
     {
-        L.hull[0] = (unsigned short)first;
-        L.used[first] = 1;
+#pragma unroll
+        for (int j = 0; j < (kInRegs ? kPolyPerLane : 1); ++j)
+        {
+            const int i = lane + 64 * j;
+            myPts[j] = (64 * j < n && i < n) ? pts[i] : make_double2(0.0, 0.0);
+        }
     }
-    CAPE_POLY_SYNC();
+    auto my_point = [&](int j) { return kInRegs ? myPts[kInRegs ? j : 0] : pts[lane + 64 * j]; };
+    // the point with index idx, from its owner's registers (idx is uniform)
+    auto point_of = [&](int idx) {
+        if (!kInRegs)
+            return pts[idx];
+        const int owner = idx & 63, slot = idx >> 6;
+        double2 q = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < (kInRegs ? kPolyPerLane : 1); ++j)
+            if (slot == j)
+                q = make_double2(readlane_f64(myPts[j].x, owner), readlane_f64(myPts[j].y, owner));
+        return q;
+    };
+    auto hide = [&](int idx, bool hidden) {
+        if (lane == (idx & 63))
+            myUsed = hidden ? (myUsed | (1u << (idx >> 6))) : (myUsed & ~(1u << (idx >> 6)));
+    };
+    if (lane == 0)
+        L.hull[0] = (unsigned short)first;
+    hide(first, true);
     int hs = 1;
     int usedCount = 1; // points hidden from the neighbour search
     int current = first;
@@ -310,7 +337,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     int step = 1;
     while ((!points_equal(cur, firstPt) || step == 1) && hs != n)
     {
-        if (planeState && (step & 7) == 0)
+        if (planeState && (step & 15) == 0)
         {
             uint32_t st = 0;
             if (lane == 0)
@@ -321,10 +348,8 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         }
         if (step == 4)
         {
-            if (lane == 0)
-                L.used[first] = 0; // the start point is put back into the index once the hull has three edges
+            hide(first, false); // the start point is put back into the index once the hull has three edges
             --usedCount;
-            CAPE_POLY_SYNC();
         }
         // ---- k nearest visible neighbours of the current point, ascending (squared distance, index)
         // key = the squared distance's bit pattern (>= +0: the bits order like the value) with its ten lowest mantissa bits
@@ -338,9 +363,9 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             key[j] = ~0ull;
             if (64 * j >= n)
                 continue; // (uniform: a plane of 150 points uses three of the sixteen slots)
-            if (i < n && !L.used[i])
+            if (i < n && !((myUsed >> j) & 1u))
             {
-                const double2 q = pts[i];
+                const double2 q = my_point(j);
                 const double dx = cur.x - q.x, dy = cur.y - q.y;
                 key[j] = ((unsigned long long)__double_as_longlong(dx * dx + dy * dy) & ~1023ull) | (unsigned long long)i;
             }
@@ -351,7 +376,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         const int kk = k < cnt ? k : cnt;
         // candidate c lives in lane c (kk <= 21 < 64): index, edge vector, turn class
         int myCand = 0, myClass = 0;
-        double myVx = 0.0, myVy = 0.0;
+        double myVx = 0.0, myVy = 0.0, myPx = 0.0, myPy = 0.0; // candidate c's point lives in lane c too
         bool selected = false;
         if (kk >= kPolySortSelect)
         {
@@ -382,6 +407,8 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
                     const int idx = (int)(sorted & 1023ull);
                     const double2 q = pts[idx];
                     myCand = idx;
+                    myPx = q.x;
+                    myPy = q.y;
                     myVx = q.x - cur.x;
                     myVy = q.y - cur.y;
                 }
@@ -400,10 +427,12 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             for (int j = 0; j < kPolyPerLane; ++j)
                 if (64 * j < n && key[j] == m)
                     key[j] = ~0ull; // taken (keys are unique: they carry the index)
+            const double2 q = point_of(idx);
             if (lane == c)
             {
-                const double2 q = pts[idx];
                 myCand = idx;
+                myPx = q.x;
+                myPy = q.y;
                 myVx = q.x - cur.x;
                 myVy = q.y - cur.y;
             }
@@ -416,6 +445,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         unsigned tried = 0;
         bool found = false;
         int next = 0;
+        double2 nextPt = make_double2(0.0, 0.0);
         for (int t = 0; t < kk && !found; ++t)
         {
             int b = -1, bClass = 0;
@@ -436,7 +466,7 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             }
             tried |= 1u << b;
             const int cnd = __builtin_amdgcn_readlane(myCand, b);
-            const double2 cp = pts[cnd];
+            const double2 cp = make_double2(readlane_f64(myPx, b), readlane_f64(myPy, b));
             const int jFirst = points_equal(cp, firstPt) ? 1 : 0;
             bool its = false;
             // hull edges (h[j], h[j+1]), j in [jFirst, hs - 3]: not the edge that ends at the current point, and not the first edge
@@ -447,11 +477,12 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
             {
                 found = true;
                 next = cnd;
+                nextPt = cp;
             }
         }
         if (!found)
             return false;
-        const double2 nx = pts[next];
+        const double2 nx = nextPt;
         Px = cur.x - nx.x; // looking back along the new edge
         Py = cur.y - nx.y;
         if (Px == 0 && Py == 0)
@@ -459,10 +490,8 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
         current = next;
         cur = nx;
         if (lane == 0)
-        {
             L.hull[hs] = (unsigned short)current;
-            L.used[current] = 1;
-        }
+        hide(current, true);
         ++hs;
         ++usedCount;
         ++step;
@@ -471,9 +500,13 @@ template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n
     // every point that is not a hull vertex must pass PointInPolygon (the start point is a hull vertex whether or not it is
     // hidden from the search at this moment)
     bool outside = false;
-    for (int i = lane; i < n; i += 64)
-        if (!L.used[i] && i != first && !point_in_hull(pts[i], pts, L.hull, hs))
+#pragma unroll
+    for (int j = 0; j < kPolyPerLane; ++j)
+    {
+        const int i = lane + 64 * j;
+        if (64 * j < n && i < n && !((myUsed >> j) & 1u) && i != first && !point_in_hull(my_point(j), pts, L.hull, hs))
             outside = true;
+    }
     if (__any(outside))
         return false;
     hsOut = hs;
@@ -907,7 +940,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_large
 // below 100 candidates rung 0, then k = 5, 7, 11, then 13, 17, 21 (three short walks in a row at worst); from 100 on rung 0,
 // then all six; from 130 on all seven at once (one long walk).  Rounds 1-3 ran a first-rung kernel and then a ladder kernel
 // of three-wave workgroups: the second lasted as long as its slowest plane (0.93 of 1.0 ms) while the device idled.
-constexpr uint32_t kStDoneShift = 0, kStHullShift = 8, kStFinal = 1u << 16;
+constexpr uint32_t kStDoneShift = 0, kStHullShift = 8, kStFinal = 1u << 16, kStSpawnShift = 17;
 constexpr uint32_t kTaskEmpty = 0xFFFFFFFFu, kTaskQuit = 0xFFFFFFFEu;
 constexpr int kParkRungs = 6;       // rungs 2 .. 7 park; rung 0 never waits for a lower one
 #ifndef CAPE_POLY_MID
@@ -928,17 +961,22 @@ __device__ __forceinline__ uint32_t rungs_that_exist(int n)
             m |= 1u << a;
     return m;
 }
-// cumulative stage masks of a plane of n candidates: the rungs started so far once stage i has been spawned
-__device__ __forceinline__ uint32_t stage_mask(int n, int stage, uint32_t exist)
+// the rungs to start next for a plane of n candidates of which `spawned` have been started and none has a hull: all that remain
+// when the plane is big or the device is running out of planes to start (its waves would idle while a chain of short walks
+// dribbles on), else the next three
+__device__ __forceinline__ uint32_t next_rungs(int n, uint32_t exist, uint32_t spawned, bool deviceIdle)
 {
-    uint32_t m;
-    if (n >= kPolyAllPoints)
-        m = 0xFDu;
-    else if (n >= kPolyMidPoints)
-        m = stage == 0 ? 0x01u : 0xFDu;
-    else
-        m = stage == 0 ? 0x01u : (stage == 1 ? 0x1Du : 0xFDu);
-    return m & exist;
+    uint32_t remaining = exist & ~spawned;
+    if (n >= kPolyMidPoints || deviceIdle)
+        return remaining;
+    uint32_t out = 0;
+    for (int k = 0; k < 3 && remaining; ++k)
+    {
+        const uint32_t low = remaining & (0u - remaining);
+        out |= low;
+        remaining &= ~low;
+    }
+    return out;
 }
 
 // a counter as the atomics see it
@@ -984,6 +1022,12 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
     const unsigned totalWaves = gridDim.x * kPolyWavesPerGroup;
     if (statList[3] == 0u)
         return; // no plane in the batch: nobody would ever send the waiting waves home
+#ifdef CAPE_POLY_PROFILE
+    // frame 0's spare slots: 6 kernel start (min), 7 static list handed out (min), 23 last polygon (max), 31 last wave leaves (max), 28 busy ticks (sum)
+    unsigned long long* tl = p.prof;
+    if (lane == 0)
+        atomicMin(&tl[6], __builtin_amdgcn_s_memtime());
+#endif
     for (;;)
     {
         // ---- next task: a spawned rung first (it sits on some plane's critical chain), else the next plane of the batch
@@ -1004,7 +1048,12 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
                     isStatic = true;
                 }
                 else
+                {
                     server = true; // the planes of the batch are handed out: from now on this wave serves spawned rungs
+#ifdef CAPE_POLY_PROFILE
+                    atomicMin(&tl[7], __builtin_amdgcn_s_memtime());
+#endif
+                }
             }
             if (task == kTaskEmpty)
             {
@@ -1035,7 +1084,31 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
         }
 #endif
         if (task == kTaskQuit)
+        {
+#ifdef CAPE_POLY_PROFILE
+            if (lane == 0)
+                atomicMax(&tl[31], __builtin_amdgcn_s_memtime());
+#endif
             break;
+        }
+#ifdef CAPE_POLY_PROFILE
+        const unsigned long long busy0 = __builtin_amdgcn_s_memtime();
+        struct BusyScope
+        {
+            unsigned long long* tl;
+            unsigned long long t0;
+            int lane;
+            __device__ ~BusyScope()
+            {
+                if (lane == 0)
+                {
+                    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                    atomicAdd(&tl[28], t1 - t0);
+                    atomicMax(&tl[23], t1);
+                }
+            }
+        } busyScope {tl, busy0, lane};
+#endif
         const int rung = (int)(task & 7u);
         const PlaneCtx c = plane_context(p, (int)(task >> 11), (int)((task >> 3) & 255u));
 #ifdef CAPE_POLY_PROFILE
@@ -1090,7 +1163,13 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
         CAPE_PTICK(0); // projection, start point
         uint32_t mine = 1u << rung; // the rungs this wave walks: its task, plus whatever a full queue hands back
         if (isStatic)
-            mine |= spawn(stage_mask(n, 0, exist) & ~1u);
+        {
+            // the plane's first rungs: rung 0, and with it all the others when the plane is big (one long walk instead of a chain)
+            const uint32_t firstRungs = n >= kPolyAllPoints ? exist : 1u;
+            if (lane == 0)
+                atomicOr(state, firstRungs << kStSpawnShift);
+            mine |= spawn(firstRungs & ~1u);
+        }
         bool finished = false;
         while (mine && !finished)
         {
@@ -1098,7 +1177,8 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
             mine &= ~(1u << r);
             int hs = 0;
             CAPE_PCOUNT(8, 1); // hull attempts
-            const bool ok = concave_hull_k<CAP>(L, n, first, kLadderK[r], lane, hs, state, r);
+            // (rung 0 cannot be overruled, so it never looks at the state word while it walks)
+            const bool ok = concave_hull_k<CAP>(L, n, first, kLadderK[r], lane, hs, r > 0 ? state : nullptr, r);
             CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
             uint32_t old = 0;
             if (lane == 0)
@@ -1126,18 +1206,19 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
             }
             else
             {
-                // a stage without a hull is complete: the wave whose bit completed it moves the plane on
-                for (int stage = 0; stage < 3; ++stage)
+                // every rung started so far is done and none has a hull: the wave whose bit completed the set moves the plane on
+                const uint32_t spawned = (now >> kStSpawnShift) & 0xFFu;
+                if ((done & spawned) == spawned && ((old & 0xFFu) & spawned) != spawned)
                 {
-                    const uint32_t sm = stage_mask(n, stage, exist);
-                    if ((done & sm) == sm && (old & sm) != sm)
+                    const bool deviceIdle = load_u32(&statList[2]) >= nStatic; // (a stale value only delays the switch)
+                    const uint32_t next = next_rungs(n, exist, spawned, deviceIdle);
+                    if (!next)
+                        winner = -1; // the ladder is exhausted
+                    else
                     {
-                        const uint32_t next = stage < 2 ? (stage_mask(n, stage + 1, exist) & ~sm) : 0u;
-                        if (sm == exist)
-                            winner = -1; // the ladder is exhausted
-                        else if (next)
-                            mine |= spawn(next);
-                        break;
+                        if (lane == 0)
+                            atomicOr(state, next << kStSpawnShift);
+                        mine |= spawn(next);
                     }
                 }
             }
