@@ -184,7 +184,8 @@ struct PackParams
 };
 
 // N1 on the device: boundary polygons (cape_polygon.hip)
-constexpr int kPolyListHeader = 4; // words in front of a polygon work list: front count, back count, next entry, spare
+constexpr int kPolyListHeader = 40; // words in front of a polygon work list: [0] entries, [1] head / spare, [2] next entry, [3] planes to finish,
+                                    // [4, 20) planes per size bucket, [20, 36) placed per bucket (static list of the task kernel)
 constexpr int kPolyMaxPoints = 1024; // boundary candidates of one plane the device hull takes (more: CAPE_POLY_OVERFLOW, host class)
 struct PolygonParams
 {

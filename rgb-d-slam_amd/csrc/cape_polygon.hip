@@ -35,7 +35,6 @@ constexpr int kPolyWavesPerGroup = 4;
 // instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
 constexpr int kPolySmallPoints = 256;
 constexpr int kPolySortSelect = 5;  // neighbours from which the k-nearest selection sorts the lanes' keys instead of taking k minima
-constexpr int kPolyBigPoints = 100; // planes with at least as many boundary candidates are handed out first (longest first)
 enum PolyList
 {
     kPolyFirstRung = 0, // list 0: the planes of up to 256 candidates (static list of the task kernel)
@@ -1010,7 +1009,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* statList = p.lists + (size_t)kPolyFirstRung * p.listStride; // [0] front count [1] back count [2] next [3] planes not finished
     uint32_t* dynList = p.lists + (size_t)kPolyLadder * p.listStride;     // [0] tail [1] head
-    const unsigned nFront = statList[0], nStatic = nFront + statList[1];
+    const unsigned nStatic = statList[0];
     const unsigned listCapacity = p.listStride - kPolyListHeader;
     const PolyLds L = carve_lds<CAP>(smem_all + (size_t)wave * ldsPerWave);
     // One wave in four serves the spawned rungs from the start (they sit on some plane's critical chain of walks and must not
@@ -1043,7 +1042,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
                 const unsigned e = atomicAdd(&statList[2], 1u);
                 if (e < nStatic)
                 {
-                    const unsigned entry = statList[kPolyListHeader + (e < nFront ? e : listCapacity - 1 - (e - nFront))];
+                    const unsigned entry = statList[kPolyListHeader + e];
                     task = entry << 3; // rung 0
                     isStatic = true;
                 }
@@ -1256,15 +1255,22 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_
     }
 }
 
-// one wavefront per frame, lane j <- segment j: the static list of the task kernel (planes of up to 256 candidates; the big
-// ones from the front, the others from the back), the list of the 1 024-point instance, and the count of planes to finish
-constexpr int kListFrames = 16; // frames (waves) of a list workgroup: ONE atomic per list and workgroup -- a counter that every
+// one wavefront per frame, lane j <- segment j: the static list of the task kernel (planes of up to 256 candidates), the list of
+// the 1 024-point instance, and the count of planes to finish.  The static list is ordered by size, the biggest planes first
+// (sixteen buckets of sixteen candidates): a kernel of independent walks ends with its last-started chains, and those should be
+// the short ones -- a plane of 30 candidates taken last costs three walks of ten steps, one of 150 three of fifty.  Two passes
+// of the same kernel: count per bucket, then place (the bucket's offset is the sum of the counts before it).
+constexpr int kListFrames = 16; // frames (waves) of a list workgroup: ONE atomic per counter and workgroup -- a counter that every
                                 // frame's wave bumps on its own serialises 4 096 atomics on one address (74 us of the pass)
-__global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames)
+constexpr int kSizeBuckets = 16;
+__global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames, int pass)
 {
-    __shared__ unsigned s_count[3][kListFrames], s_base[3][kListFrames];
+    __shared__ unsigned s_cnt[kSizeBuckets + 1], s_base[kSizeBuckets + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.x * kListFrames + wave;
+    if (threadIdx.x <= kSizeBuckets)
+        s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     bool isOut = false;
     int nPts = 0;
     if (frame < nFrames)
@@ -1272,51 +1278,53 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
         const cape_frame_record& rec = p.records[frame];
         isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
         nPts = isOut ? (int)rec.segments[lane].boundary_count : 0;
-        p.state[(size_t)frame * CAPE_MAX_PLANES + lane] = 0u;
+        if (pass == 0)
+            p.state[(size_t)frame * CAPE_MAX_PLANES + lane] = 0u;
     }
     // (segments that are no output plane keep the empty record launch_polygons' memset left)
     // 257 .. 1 024 candidates: the large instance; everything else (incl. what it will only flag: too few / too many points)
     // goes to the task kernel
     const bool large = isOut && nPts > kPolySmallPoints && nPts <= kPolyMaxPoints;
     const bool small = isOut && !large;
-    const bool big = small && nPts >= kPolyBigPoints && nPts <= kPolySmallPoints;
-    const bool rest = small && !big;
-    const unsigned long long mb = __ballot(big), mr = __ballot(rest), ml = __ballot(large);
+    // bucket 0 holds the biggest planes (what the task kernel will only flag -- more than 1 024 candidates -- costs nothing: last)
+    const int sized = nPts > kPolySmallPoints ? 0 : nPts;
+    const int bucket = large ? kSizeBuckets : (kSizeBuckets - 1 - (sized * kSizeBuckets) / (kPolySmallPoints + 1));
+    unsigned myPos = 0;
+    if (small || large)
+        myPos = atomicAdd(&s_cnt[bucket], 1u);
+    __syncthreads();
     uint32_t* listS = p.lists + (size_t)kPolyFirstRung * p.listStride;
     uint32_t* listL = p.lists + (size_t)kPolyFull * p.listStride;
-    const unsigned listCapacity = p.listStride - kPolyListHeader;
-    if (lane == 0)
+    uint32_t* counts = listS + 4;                 // [16] planes per bucket (pass 0)
+    uint32_t* cursors = listS + 4 + kSizeBuckets; // [16] placed so far (pass 1)
+    if (threadIdx.x <= kSizeBuckets && s_cnt[threadIdx.x])
     {
-        s_count[0][wave] = (unsigned)__popcll(mb);
-        s_count[1][wave] = (unsigned)__popcll(mr);
-        s_count[2][wave] = (unsigned)__popcll(ml);
-    }
-    __syncthreads();
-    if (threadIdx.x < 3)
-    {
-        unsigned total = 0;
-        for (int w = 0; w < kListFrames; ++w)
+        const unsigned c = s_cnt[threadIdx.x];
+        if (pass == 0)
         {
-            s_base[threadIdx.x][w] = total;
-            total += s_count[threadIdx.x][w];
+            if (threadIdx.x < kSizeBuckets)
+            {
+                atomicAdd(&counts[threadIdx.x], c);
+                atomicAdd(&listS[0], c); // planes on the static list
+                atomicAdd(&listS[3], c); // planes the task kernel has to finish
+            }
         }
-        unsigned* counter = threadIdx.x == 0 ? &listS[0] : threadIdx.x == 1 ? &listS[1] : &listL[0];
-        const unsigned base = total ? atomicAdd(counter, total) : 0u;
-        if (threadIdx.x < 2 && total)
-            atomicAdd(&listS[3], total); // planes the task kernel has to finish
-        for (int w = 0; w < kListFrames; ++w)
-            s_base[threadIdx.x][w] += base;
+        else
+            s_base[threadIdx.x] = threadIdx.x < kSizeBuckets ? atomicAdd(&cursors[threadIdx.x], c) : atomicAdd(&listL[0], c);
     }
+    if (pass == 0)
+        return;
     __syncthreads();
-    const unsigned baseB = s_base[0][wave], baseR = s_base[1][wave], baseL = s_base[2][wave];
-    const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned entry = ((unsigned)frame << 8) | (unsigned)lane;
-    if (big)
-        listS[kPolyListHeader + baseB + __popcll(mb & below)] = entry;
-    if (rest)
-        listS[kPolyListHeader + listCapacity - 1 - (baseR + __popcll(mr & below))] = entry;
+    if (small)
+    {
+        unsigned before = 0; // planes in bigger buckets
+        for (int k = 0; k < bucket; ++k)
+            before += counts[k];
+        listS[kPolyListHeader + before + s_base[bucket] + myPos] = entry;
+    }
     if (large)
-        listL[kPolyListHeader + baseL + __popcll(ml & below)] = entry;
+        listL[kPolyListHeader + s_base[kSizeBuckets] + myPos] = entry;
 }
 
 constexpr size_t kPolyQuitSlots = 8192; // room behind the tasks of a queue for one kTaskQuit per wave of the task kernel's grid
@@ -1359,9 +1367,12 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
         return e;
     if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames);
-    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
-        return e;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames, pass);
+        if (const hipError_t e = hipGetLastError(); e != hipSuccess)
+            return e;
+    }
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
     // persistent grids: as many workgroups as the device holds at once (four waves per SIMD), never more than there can be planes
     const int maxPlanes = nFrames * CAPE_MAX_PLANES;
