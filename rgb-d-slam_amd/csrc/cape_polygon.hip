@@ -1002,7 +1002,10 @@ __device__ inline void plane_finished(uint32_t* statList, uint32_t* dynList, uns
             __hip_atomic_store(&dynList[kPolyListHeader + at + i], kTaskQuit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_task_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+#ifndef CAPE_POLY_OCC
+#define CAPE_POLY_OCC 4
+#endif
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_polygon_task_kernel(PolygonParams p, int nFrames, int ldsPerWave)
 {
     constexpr int CAP = kPolySmallPoints;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -1376,7 +1379,7 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
     // persistent grids: as many workgroups as the device holds at once (four waves per SIMD), never more than there can be planes
     const int maxPlanes = nFrames * CAPE_MAX_PLANES;
-    const int gridSmall = std::min(std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * 4), (int)(kPolyQuitSlots / kPolyWavesPerGroup));
+    const int gridSmall = std::min(std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * CAPE_POLY_OCC), (int)(kPolyQuitSlots / kPolyWavesPerGroup));
     const int gridLarge = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits);
     hipLaunchKernelGGL(cape_polygon_task_kernel, dim3(gridSmall), dim3(64 * kPolyWavesPerGroup), (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,
                        nFrames, ldsSmall);
