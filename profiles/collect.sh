@@ -13,7 +13,7 @@
 # Everything is first written under gpurun_out/ (the only directory that travels back); profiles/make_traffic.py then turns
 # the PMC passes into profiles/traffic.json.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/collect_$TAG
 mkdir -p $OUT
