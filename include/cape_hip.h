@@ -344,7 +344,10 @@ enum
     CAPE_POLY_CONVEX_FALLBACK = 1u << 1, /* no concave hull on the k ladder: compute_convex_hull was used */
     CAPE_POLY_SIMPLIFIED = 1u << 2,      /* simplify() replaced the ring (area stayed above 75 %) */
     CAPE_POLY_OVERFLOW = 1u << 3,        /* more than 1024 boundary points: not built, left to the host class */
-    CAPE_POLY_REJECTED = 1u << 4         /* the host constructor would throw (fewer than 3 points / normal not unit) */
+    CAPE_POLY_REJECTED = 1u << 4,        /* the host constructor would throw (fewer than 3 points / normal not unit) */
+    CAPE_POLY_DISSOLVED = 1u << 5        /* the walk's hull crossed itself (the reference's Intersects misses crossings with axis-parallel
+                                            edges) and was cut apart at its crossings like correct_boost_polygon.hpp does; the ring may
+                                            hold vertices that are no boundary candidates (the crossing points) */
 };
 typedef struct cape_polygon
 {

@@ -313,6 +313,7 @@ enum : int
     F_NEEDS_DISSOLVE = 32, // the hull touches or crosses itself: the reference dissolves it with Boost set operations
                            // (correct_boost_polygon.hpp:229-330), which this oracle does not restate -- reported, never guessed
     F_HULL_FAILED = 64,    // no rung of the ladder produced a hull (concave_fitting.cpp:89)
+    F_DISSOLVED = 128,     // the hull crossed itself and was cut apart at its crossings (dissolve_proper_crossings)
 };
 
 // polygon.cpp:50-68
@@ -454,7 +455,68 @@ bool polygon_is_valid(const Ring& r)
 // impl::correct(ring, clockwise) = close (:188-195), reverse if its area is negative (:172-186), no self turns (:127-160)
 // -> the ring itself if |area| > 0 (:349-356), else nothing.  needsDissolve: the ring touches or crosses itself, the
 // reference then traces sub-rings and unions them with Boost -- not restated.
-bool repair_ring(Ring ring, Ring& out, bool& needsDissolve)
+// dissolve (correct_boost_polygon.hpp:127-160, :199-330) for PROPER crossings: the crossing point becomes a pseudo-vertex of both
+// edges (:146-157), the trace from a start key follows the ring up to the crossing, takes the by-pass to the other edge and
+// runs on (:286-300): the ring comes apart into the part that runs on past the crossing and the loop it cuts off.  The
+// constructor keeps result[0] (polygon.cpp:209-211) of pieces ordered by decreasing |area| (fill_non_zero_winding :371-375; a
+// loop cut off by a crossing winds the other way and lies outside the rest, so it is not subtracted from it: covered_by :383-392
+// fails) -- UNPINNED where it leans on Boost (the turn point's coordinates, the order of the union's output): restated as "cut at
+// the first crossing in edge order, keep the piece of greater |area|, orient it clockwise (:358-369), repeat".  A ring that merely
+// touches itself (a vertex on another edge, collinear overlap) needs Boost's union of the traced pieces: not restated.
+bool first_contact(const Ring& r, size_t& ci, size_t& cj, bool& proper)
+{
+    const size_t n = r.size() - 1; // closed ring: n edges
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+        {
+            if (j == i + 1 || (i == 0 && j == n - 1))
+                continue;
+            if (same(r[i], r[i + 1]) || same(r[j], r[j + 1]))
+                continue;
+            if (!segments_touch(r[i], r[i + 1], r[j], r[j + 1]))
+                continue;
+            const double d1 = orient(r[j], r[j + 1], r[i]), d2 = orient(r[j], r[j + 1], r[i + 1]), d3 = orient(r[i], r[i + 1], r[j]),
+                         d4 = orient(r[i], r[i + 1], r[j + 1]);
+            proper = ((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0));
+            ci = i;
+            cj = j;
+            return true;
+        }
+    return false;
+}
+bool dissolve_proper_crossings(Ring& ring) // closed, clockwise in; closed, clockwise, free of crossings out
+{
+    for (int cut = 0; cut < 8; ++cut)
+    {
+        size_t i = 0, j = 0;
+        bool proper = false;
+        if (!first_contact(ring, i, j, proper))
+            return true;
+        if (!proper)
+            return false;
+        const P2 a = ring[i], b = ring[i + 1], c = ring[j], d = ring[j + 1];
+        const double den = (b.x - a.x) * (d.y - c.y) - (b.y - a.y) * (d.x - c.x);
+        const double t = ((c.x - a.x) * (d.y - c.y) - (c.y - a.y) * (d.x - c.x)) / den;
+        const P2 x {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y)};
+        Ring outer(ring.begin(), ring.begin() + (long)i + 1), loop;
+        outer.push_back(x);
+        outer.insert(outer.end(), ring.begin() + (long)j + 1, ring.end()); // ... up to the closing vertex = ring[0]
+        loop.push_back(x);
+        loop.insert(loop.end(), ring.begin() + (long)i + 1, ring.begin() + (long)j + 1);
+        loop.push_back(x);
+        ring = std::fabs(ring_area(loop)) > std::fabs(ring_area(outer)) ? loop : outer;
+        if (ring_area(ring) < 0)
+        {
+            // keep the start vertex: open, reverse the rest, close again
+            ring.pop_back();
+            std::reverse(ring.begin() + 1, ring.end());
+            ring.push_back(ring.front());
+        }
+    }
+    return false;
+}
+
+bool repair_ring(Ring ring, Ring& out, bool& needsDissolve, bool* dissolved = nullptr)
 {
     needsDissolve = false;
     out.clear();
@@ -463,11 +525,22 @@ bool repair_ring(Ring ring, Ring& out, bool& needsDissolve)
     if (!same(ring.front(), ring.back()))
         ring.push_back(ring.front());
     if (ring_area(ring) < 0)
+    {
+        // (reversed around its first vertex: a closed ring reversed as a whole starts at the same vertex again)
         std::reverse(ring.begin(), ring.end());
+    }
     if (!ring_is_simple(ring))
     {
-        needsDissolve = true;
-        return false;
+        if (ring.size() >= 5 && dissolve_proper_crossings(ring) && ring_is_simple(ring))
+        {
+            if (dissolved)
+                *dissolved = true;
+        }
+        else
+        {
+            needsDissolve = true;
+            return false;
+        }
     }
     if (!(std::fabs(ring_area(ring)) > 0.0))
         return false;
@@ -627,9 +700,13 @@ Poly polygon_from_points(const std::vector<V3>& points, const V3& normal, const 
     if (!polygon_is_valid(poly))
     {
         Ring repaired;
-        bool needsDissolve = false;
-        if (repair_ring(poly, repaired, needsDissolve))
+        bool needsDissolve = false, dissolved = false;
+        if (repair_ring(poly, repaired, needsDissolve, &dissolved))
+        {
             poly = repaired;
+            if (dissolved)
+                P.flags |= F_DISSOLVED;
+        }
         else if (needsDissolve)
         {
             P.flags |= F_NEEDS_DISSOLVE;

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpolygon_oracle.so")
 
-VALID, CONVEX_FALLBACK, SIMPLIFIED, THREW, NEEDS_DISSOLVE, HULL_FAILED = 1, 2, 4, 16, 32, 64
+VALID, CONVEX_FALLBACK, SIMPLIFIED, THREW, NEEDS_DISSOLVE, HULL_FAILED, DISSOLVED = 1, 2, 4, 16, 32, 64, 128
 
 _lib = None
 

@@ -24,7 +24,7 @@ P.build()
 gen = torch.Generator(device="cuda").manual_seed(seed)
 B = 64
 tot = dict(planes=0, compared=0, vertex_identical=0, validity_mismatch=0, fallback_mismatch=0, iou_below_0999=0, area_beyond_1e9=0,
-           reference_would_dissolve=0, threw=0, convex_fallbacks=0, simplified=0, climbed_ladder=0, candidates_left_out_by_reference_rule=0,
+           reference_would_dissolve=0, cut_at_crossings=0, cut_verdict_mismatch=0, threw=0, convex_fallbacks=0, simplified=0, climbed_ladder=0, candidates_left_out_by_reference_rule=0,
            pairs=0, pair_area_beyond_1e9=0, frames_matched=0, decision_mismatch_frames=0, decisions=0, overflow_frames=0, skipped_frames=0)
 worst = dict(iou=1.0, area=0.0, pair_area=0.0)
 listing = []
@@ -79,6 +79,10 @@ for scene, cyl in (("room", False), ("tumlike", False), ("tumlike", True), ("tun
                                    f"{'convex fallback' if p['flags'] & cape_amd.POLY_CONVEX_FALLBACK else 'flags %d' % p['flags']}")
                     continue
                 tot["compared"] += 1
+                tot["cut_at_crossings"] += int(bool(ref.flags & P.DISSOLVED))
+                if bool(ref.flags & P.DISSOLVED) != bool(p["flags"] & cape_amd.POLY_DISSOLVED):
+                    tot["cut_verdict_mismatch"] += 1
+                    listing.append(f"CUT        {what}: device flags {p['flags']}, oracle flags {ref.flags}")
                 tot["climbed_ladder"] += int(ref.k_used > 3)
                 dev_valid = bool(p["flags"] & cape_amd.POLY_VALID) and int(p["vertex_count"]) >= 3
                 ref_valid = ref.valid and ref.boundary_length() >= 3
@@ -147,8 +151,9 @@ for scene, cyl in (("room", False), ("tumlike", False), ("tumlike", True), ("tun
     ex.close()
     print(scene, "cylinders" if cyl else "planes only", "->", {k: v for k, v in tot.items() if v}, flush=True)
 print()
-print(f"planes {tot['planes']}: compared {tot['compared']}, the reference would dissolve {tot['reference_would_dissolve']} "
-      f"({100.0 * tot['reference_would_dissolve'] / max(1, tot['planes']):.2f} %), constructor throws {tot['threw']}")
+print(f"planes {tot['planes']}: compared {tot['compared']} -- of them {tot['cut_at_crossings']} hulls that cross themselves and are cut apart at the crossing like the "
+      f"reference's repair does (verdict mismatches {tot['cut_verdict_mismatch']}); left out: {tot['reference_would_dissolve']} hulls that merely touch themselves "
+      f"(the reference re-unites those with Boost set operations: not restated), constructor throws {tot['threw']}")
 print(f"vertex-identical to the oracle: {tot['vertex_identical']} of {tot['compared']} compared "
       f"({100.0 * tot['vertex_identical'] / max(1, tot['compared']):.3f} %)")
 print(f"worst IoU {worst['iou']:.12f}, worst |area ratio - 1| {worst['area']:.3e}, planes with IoU < 0.999: {tot['iou_below_0999']}, "
@@ -163,5 +168,5 @@ print()
 print("LISTING (every disagreement and every plane the comparison leaves out):")
 for line in listing:
     print(" ", line)
-bad = tot["validity_mismatch"] + tot["iou_below_0999"] + tot["decision_mismatch_frames"] + tot["pair_area_beyond_1e9"] + tot["area_beyond_1e9"]
+bad = tot["cut_verdict_mismatch"] + tot["validity_mismatch"] + tot["iou_below_0999"] + tot["decision_mismatch_frames"] + tot["pair_area_beyond_1e9"] + tot["area_beyond_1e9"]
 print("RESULT", "OK" if bad == 0 else "DISAGREEMENTS", tot)

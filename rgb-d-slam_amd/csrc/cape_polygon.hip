@@ -34,6 +34,7 @@ constexpr int kPolyWavesPerGroup = 4;
 // are built by waves that hold 7 KB of LDS each, twenty to a CU; a plane with more goes to the kPolyMaxPoints
 // instance (27 KB per wave) launched right behind.  With one instance sized for the worst case a CU held four waves.
 constexpr int kPolySmallPoints = 256;
+constexpr int kPolyCutPoints = 8;   // crossing points a self-crossing hull may add to its plane's points (finish_polygon)
 constexpr int kPolySortSelect = 5;  // neighbours from which the k-nearest selection sorts the lanes' keys instead of taking k minima
 enum PolyList
 {
@@ -225,6 +226,41 @@ __device__ __forceinline__ bool ring_is_simple(const double2* pts, const unsigne
     if (__any(bad))
         return false;
     return fabs(ring_area_signed(pts, ring, n)) > 0;
+}
+
+// host: first_contact -- the first pair (i, j), i < j, of non-adjacent edges of the open ring that share a point, in (i, j) order
+// (lanes over i, a wave minimum over the packed pair); `proper`: the two edges cross at a point interior to both
+__device__ inline bool first_contact(const double2* pts, const unsigned short* ring, int n, int lane, int& ci, int& cj, bool& proper)
+{
+    unsigned best = 0xFFFFFFFFu;
+    for (int base = 0; base < n; base += 64)
+    {
+        const int i = base + lane;
+        if (i < n)
+        {
+            const double2 a1 = pts[ring[i]], a2 = pts[ring[(i + 1) % n]];
+            for (int j = i + 1; j < n; ++j)
+            {
+                if (j == i + 1 || (i == 0 && j == n - 1))
+                    continue;
+                if (segments_intersect(a1, a2, pts[ring[j]], pts[ring[(j + 1) % n]]))
+                {
+                    const unsigned key = ((unsigned)i << 16) | (unsigned)j;
+                    best = key < best ? key : best;
+                    break;
+                }
+            }
+        }
+    }
+    const unsigned m = 0xFFFFFFFFu - wave_max_u32(0xFFFFFFFFu - best);
+    if (m == 0xFFFFFFFFu)
+        return false;
+    ci = (int)(m >> 16);
+    cj = (int)(m & 0xFFFFu);
+    const double2 a1 = pts[ring[ci]], a2 = pts[ring[(ci + 1) % n]], b1 = pts[ring[cj]], b2 = pts[ring[(cj + 1) % n]];
+    const double d1 = pcross2(b1, b2, a1), d2 = pcross2(b1, b2, a2), d3 = pcross2(a1, a2, b1), d4 = pcross2(a1, a2, b2);
+    proper = ((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0));
+    return true;
 }
 
 // wave-wide arg-min of (a, b, idx) in lexicographic order (a, b: doubles without NaN)
@@ -676,10 +712,61 @@ template <int CAP> __device__ inline void finish_polygon(const PolygonParams& p,
             ring[i] = L.hull[(rev && i > 0) ? m - i : i];
         rn = m;
         CAPE_POLY_SYNC();
-        // A hull that touches or crosses itself is dissolved with Boost set operations in the reference
-        // (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull
+        // A hull that CROSSES itself (the reference's Intersects misses a crossing with an axis-parallel edge by a rounding error:
+        // about one plane in a hundred) is cut apart at the crossing like the reference's repair does
+        // (correct_boost_polygon.hpp:127-160, :199-330; host: dissolve_crossings): the crossing point X becomes a vertex, the ring
+        // falls into r[0..i], X, r[j+1..] and X, r[i+1..j], the piece of greater |area| stays, clockwise -- at most eight cuts.  A
+        // ring that merely touches itself goes the way of a failed hull: the convex hull.
         if (!ring_is_simple(L.pts, ring, rn, lane))
+        {
             haveRing = false;
+            bool cutting = rn >= 4;
+            int extra = 0; // crossing points appended behind the plane's points
+            for (int cut = 0; cut < 8 && cutting; ++cut)
+            {
+                int ci = 0, cj = 0;
+                bool proper = false;
+                if (!first_contact(L.pts, ring, rn, lane, ci, cj, proper))
+                {
+                    haveRing = rn >= 3 && fabs(ring_area_signed(L.pts, ring, rn)) > 0;
+                    break;
+                }
+                if (!proper)
+                    break;
+                const double2 a = L.pts[ring[ci]], b = L.pts[ring[(ci + 1) % rn]], c2 = L.pts[ring[cj]], d = L.pts[ring[(cj + 1) % rn]];
+                const double rx = b.x - a.x, ry = b.y - a.y, sx = d.x - c2.x, sy = d.y - c2.y;
+                const double t = ((c2.x - a.x) * sy - (c2.y - a.y) * sx) / (rx * sy - ry * sx);
+                const int xi = nPts + extra;
+                ++extra;
+                if (lane == 0)
+                    L.pts[xi] = make_double2(a.x + t * rx, a.y + t * ry);
+                // the two pieces, side by side in the hull area (outer: ci + 2 + rn - 1 - cj entries, loop: cj - ci + 1)
+                unsigned short* outer = L.hull;
+                const int no = ci + 1 + 1 + (rn - 1 - cj), nl = 1 + (cj - ci);
+                unsigned short* loop = L.hull + no;
+                for (int k = lane; k < no; k += 64)
+                    outer[k] = k <= ci ? ring[k] : (k == ci + 1 ? (unsigned short)xi : ring[cj + 1 + (k - ci - 2)]);
+                for (int k = lane; k < nl; k += 64)
+                    loop[k] = k == 0 ? (unsigned short)xi : ring[ci + k];
+                CAPE_POLY_SYNC();
+                const bool keepLoop = fabs(ring_area_signed(L.pts, loop, nl)) > fabs(ring_area_signed(L.pts, outer, no));
+                const unsigned short* kept = keepLoop ? loop : outer;
+                const int nk = keepLoop ? nl : no;
+                const bool revk = nk >= 3 && ring_area_signed(L.pts, kept, nk) > 0; // clockwise (correct_boost_polygon.hpp:358-369)
+                for (int k = lane; k < nk; k += 64)
+                    ring[k] = kept[(revk && k > 0) ? nk - k : k];
+                rn = nk;
+                CAPE_POLY_SYNC();
+                if (cut == 7)
+                    cutting = false; // still crossing after eight cuts
+            }
+            if (haveRing)
+            {
+                haveRing = ring_is_simple(L.pts, ring, rn, lane);
+                if (haveRing)
+                    flags |= CAPE_POLY_DISSOLVED;
+            }
+        }
         CAPE_PTICK(2); // simple-ring test of the oriented hull
     }
     if (!haveRing)
@@ -872,9 +959,9 @@ template <int CAP> __device__ inline PolyLds carve_lds(unsigned char* smem)
 {
     PolyLds L;
     L.pts = reinterpret_cast<double2*>(smem);
-    L.hull = reinterpret_cast<unsigned short*>(L.pts + CAP);
-    L.ring = L.hull + CAP + 2;
-    L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2);
+    L.hull = reinterpret_cast<unsigned short*>(L.pts + CAP + kPolyCutPoints);
+    L.ring = L.hull + CAP + 2 + kPolyCutPoints;
+    L.stack = reinterpret_cast<unsigned int*>(L.ring + CAP + 2 + kPolyCutPoints);
     L.used = reinterpret_cast<unsigned char*>(L.stack + CAP);
     L.keep = L.used + CAP;
     return L;
@@ -1334,8 +1421,8 @@ constexpr size_t kPolyQuitSlots = 8192; // room behind the tasks of a queue for 
 
 size_t polygon_lds_bytes(int cap)
 {
-    size_t b = (size_t)cap * 16;            // pts
-    b += 2 * ((size_t)cap + 2) * 2;         // hull, ring
+    size_t b = ((size_t)cap + kPolyCutPoints) * 16;            // pts (+ the crossing points of a dissolved hull)
+    b += 2 * ((size_t)cap + 2 + kPolyCutPoints) * 2;         // hull, ring
     b += (size_t)cap * 4;                   // stack
     b += (size_t)cap + cap + 2;             // used, keep
     return (b + 15) & ~(size_t)15;

@@ -357,6 +357,65 @@ bool ring_is_simple(const std::vector<vector2>& r)
     return std::abs(ring_area_signed(r)) > 0;
 }
 
+// The first pair (i, j), i < j, of non-adjacent edges of an open ring that share a point; `proper`: they cross at a point
+// interior to both (the only kind dissolve_crossings undoes).
+bool first_contact(const std::vector<vector2>& r, size_t& ci, size_t& cj, bool& proper)
+{
+    const size_t n = r.size();
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+        {
+            if (j == i + 1 || (i == 0 && j == n - 1))
+                continue;
+            const vector2 &a1 = r[i], &a2 = r[(i + 1) % n], &b1 = r[j], &b2 = r[(j + 1) % n];
+            if (!segments_intersect(a1, a2, b1, b2))
+                continue;
+            const double d1 = cross2(b1, b2, a1), d2 = cross2(b1, b2, a2), d3 = cross2(a1, a2, b1), d4 = cross2(a1, a2, b2);
+            proper = ((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0));
+            ci = i;
+            cj = j;
+            return true;
+        }
+    return false;
+}
+
+// What the reference's repair does with a hull that CROSSES itself (its own Intersects misses a crossing with an axis-parallel
+// edge by a rounding error: about one plane in a hundred): third_party/correct_boost_polygon.hpp:127-160 makes the crossing point
+// a pseudo-vertex of both edges, :199-330 traces the ring apart there -- the ring that runs on past the crossing and the loop it
+// cuts off -- and the constructor keeps result[0] (polygon.cpp:209-211); the pieces are ordered by decreasing |area| (:371-375),
+// so that is the bigger one.  Restated for PROPER crossings, one at a time (the first in edge order), at most eight; a ring that
+// merely touches itself, or still crosses after eight cuts, goes to the convex hull.  The device runs the same statements.
+bool dissolve_crossings(std::vector<vector2>& r)
+{
+    for (int cut = 0; cut < 8; ++cut)
+    {
+        size_t i = 0, j = 0;
+        bool proper = false;
+        if (!first_contact(r, i, j, proper))
+            return r.size() >= 3 && std::abs(ring_area_signed(r)) > 0;
+        if (!proper)
+            return false;
+        const size_t n = r.size();
+        const vector2 a = r[i], b = r[(i + 1) % n], c = r[j], d = r[(j + 1) % n];
+        const double rx = b[0] - a[0], ry = b[1] - a[1], sx = d[0] - c[0], sy = d[1] - c[1];
+        const double t = ((c[0] - a[0]) * sy - (c[1] - a[1]) * sx) / (rx * sy - ry * sx);
+        const vector2 x {a[0] + t * rx, a[1] + t * ry};
+        std::vector<vector2> outer, loop; // r[0..i], X, r[j+1..]   and   X, r[i+1..j]
+        for (size_t k = 0; k <= i; ++k)
+            outer.push_back(r[k]);
+        outer.push_back(x);
+        for (size_t k = j + 1; k < n; ++k)
+            outer.push_back(r[k]);
+        loop.push_back(x);
+        for (size_t k = i + 1; k <= j; ++k)
+            loop.push_back(r[k]);
+        r = std::abs(ring_area_signed(loop)) > std::abs(ring_area_signed(outer)) ? loop : outer;
+        if (r.size() >= 3 && ring_area_signed(r) > 0)
+            std::reverse(r.begin() + 1, r.end()); // clockwise (correct_boost_polygon.hpp:358-369)
+    }
+    return false;
+}
+
 // Area of the intersection of two simple rings.  The plane is cut into vertical slabs at every vertex and every
 // edge-edge crossing; inside a slab no two edges cross, so each ring is a stack of trapezoids ordered by y and the
 // overlap of the two stacks is a sum of trapezoids.
@@ -523,9 +582,10 @@ Polygon::Polygon(const std::vector<vector3>& points, const vector3& normal, cons
     for (auto it = points.rbegin(); it != points.rend(); ++it) // the reference projects in reverse order
         projected.push_back(get_projected_plan_coordinates(*it, _center, _xAxis, _yAxis));
     _ring = compute_concave_hull(projected);
-    // A hull that touches or crosses itself is dissolved into sub-rings and re-united with Boost set operations in the
-    // reference (correct_boost_polygon.hpp:229-330); here it goes the way of a failed hull: the convex hull (polygon.cpp:200-207)
-    if (!is_valid())
+    // A hull that crosses itself is cut apart at its crossings like the reference's repair does (dissolve_crossings); one that
+    // merely touches itself -- the reference re-unites those pieces with Boost set operations -- goes the way of a failed hull:
+    // the convex hull (polygon.cpp:200-207)
+    if (!is_valid() && !(_ring.size() >= 4 && dissolve_crossings(_ring) && is_valid()))
         _ring = compute_convex_hull(projected);
     _area = area();
     simplify();

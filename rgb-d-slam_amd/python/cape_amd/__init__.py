@@ -99,7 +99,7 @@ class cape_gather_layout(C.Structure):
 POLYGON_DTYPE = np.dtype([
     ("x_axis", "<f8", 3), ("y_axis", "<f8", 3), ("center", "<f8", 3), ("area", "<f8"),
     ("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("flags", "<u4"), ("segment", "<u4")], align=True)
-POLY_VALID, POLY_CONVEX_FALLBACK, POLY_SIMPLIFIED, POLY_OVERFLOW, POLY_REJECTED = 1, 2, 4, 8, 16
+POLY_VALID, POLY_CONVEX_FALLBACK, POLY_SIMPLIFIED, POLY_OVERFLOW, POLY_REJECTED, POLY_DISSOLVED = 1, 2, 4, 8, 16, 32
 assert POLYGON_DTYPE.itemsize == 96
 
 MATCH_DTYPE = np.dtype([
