@@ -1,8 +1,12 @@
 #include "primitive_detection.hpp"
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <exception>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -21,6 +25,110 @@ void block_of(int total, int k, int shards, int& first, int& count)
 }
 } // namespace
 
+// The reference's own find_primitives is multi-threaded (OpenCV's forEach over the cells, parameters.hpp: coreNumber = 8); what is
+// left on the host here is the boundary polygon of every plane of a ONE-frame call -- ~7 us each, ~10 per frame, 70 of the call's
+// 207 us on one core.  A few sleeping workers take them side by side with the calling thread (which never waits for them to wake:
+// it works through the same list); batches build their polygons on the device and never come here.
+struct PolygonPool
+{
+    explicit PolygonPool(unsigned workers)
+    {
+        for (unsigned w = 0; w < workers; ++w)
+            threads.emplace_back([this]() { work(); });
+    }
+    ~PolygonPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (std::thread& t : threads)
+            t.join();
+    }
+    // The caller knows a job is coming (it has just sent the frame to the device): the workers wake up NOW and watch for it
+    // for at most half a millisecond, so that the ~15 us a sleeping thread needs to get going pass under the kernels.
+    void prepare()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            expectUntil = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+            ++hint;
+        }
+        wake.notify_all();
+    }
+    // f(i) for every i in [0, n), on the workers and on the caller
+    void run(int n, const std::function<void(int)>& f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f;
+            count = n;
+            next.store(0, std::memory_order_relaxed);
+            busy = static_cast<int>(threads.size());
+            ++epoch;
+            published.store(epoch, std::memory_order_release);
+        }
+        wake.notify_all();
+        for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;)
+            f(i);
+        std::unique_lock<std::mutex> lk(m);
+        idle.wait(lk, [this]() { return busy == 0; });
+        job = nullptr;
+    }
+
+  private:
+    void work()
+    {
+        unsigned long seen = 0, seenHint = 0;
+        for (;;)
+        {
+            const std::function<void(int)>* f;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                for (;;)
+                {
+                    wake.wait(lk, [&]() { return stop || epoch != seen || hint != seenHint; });
+                    if (stop)
+                        return;
+                    if (epoch != seen)
+                        break;
+                    // a job was announced: watch for it without sleeping, until it comes or the announcement expires
+                    seenHint = hint;
+                    const auto until = expectUntil;
+                    lk.unlock();
+                    while (published.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until)
+                        ;
+                    lk.lock();
+                    if (stop)
+                        return;
+                    if (epoch != seen)
+                        break;
+                }
+                seen = epoch;
+                f = job;
+                n = count;
+            }
+            for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;)
+                (*f)(i);
+            std::lock_guard<std::mutex> lk(m);
+            if (--busy == 0)
+                idle.notify_one();
+        }
+    }
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, idle;
+    const std::function<void(int)>* job = nullptr;
+    int count = 0, busy = 0;
+    unsigned long epoch = 0, hint = 0;
+    std::atomic<unsigned long> published {0};
+    std::chrono::steady_clock::time_point expectUntil {};
+    std::atomic<int> next {0};
+    bool stop = false;
+};
+
 Primitive_Detection::Primitive_Detection(const uint width, const uint height) : _width(width), _height(height)
 {
     Plane_Segment::set_static_members(parameters::detection::depthMapPatchSize_px,
@@ -32,6 +140,7 @@ Primitive_Detection::Primitive_Detection(const uint width, const uint height) : 
 
 Primitive_Detection::~Primitive_Detection()
 {
+    _polygonPool.reset();
     cape_destroy(_single.handle);
     for (Shard& s : _shards)
     {
@@ -117,7 +226,65 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         outputs::log_warning("find_primitives: per-frame capacity exceeded, primitive list truncated");
     planes.reserve(r.header.n_planes);
     const double* bnd = shard.boundary ? shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3 : nullptr;
-    std::vector<vector3> orderedBoundary;
+    // the output planes whose polygon the host class builds (one-frame calls, CAPE_POLY_OVERFLOW planes of a batch): built side
+    // by side when there are several, then emplaced in segment order like the reference's loop (:577-631)
+    struct HostPolygon
+    {
+        int segment;
+        std::unique_ptr<CameraPolygon> polygon; // null: rejected (with `error`)
+        std::string error;
+    };
+    std::vector<HostPolygon> hostPolygons;
+    for (int i = 0; i < r.header.n_plane_segments; ++i)
+    {
+        const cape_plane_segment& s = r.segments[i];
+        const cape_polygon* dp = shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i] : nullptr;
+        if (s.is_output && !(dp && !(dp->flags & CAPE_POLY_OVERFLOW)))
+            hostPolygons.push_back({i, nullptr, std::string()});
+    }
+    auto build_host_polygon = [&](int k) {
+        HostPolygon& hp = hostPolygons[static_cast<size_t>(k)];
+        const cape_plane_segment& s = r.segments[hp.segment];
+        try
+        {
+            if (!bnd)
+            {
+                hp.error = "boundary points of the plane were not read back";
+                return;
+            }
+            const Plane_Segment planeSegment(s);
+            std::vector<vector3> orderedBoundary;
+            orderedBoundary.reserve(s.boundary_count);
+            const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
+            for (uint32_t q = 0; q < s.boundary_count; ++q)
+                orderedBoundary.emplace_back(p[3 * q], p[3 * q + 1], p[3 * q + 2]);
+            // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
+            auto polygon = std::make_unique<CameraPolygon>(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center());
+            std::string debug;
+            if (polygon->is_valid(debug) and polygon->boundary_length() >= 3)
+                hp.polygon = std::move(polygon);
+            else
+                hp.error = debug;
+        }
+        catch (const std::exception& e)
+        {
+            hp.error = e.what();
+        }
+    };
+    // (only the one-frame call: the shards of a batch run collect() on threads of their own, and the pool serves one caller)
+    if (&shard == &_single && hostPolygons.size() >= 3 && std::thread::hardware_concurrency() > 1)
+    {
+        if (!_polygonPool)
+        {
+            const unsigned hw = std::thread::hardware_concurrency();
+            _polygonPool = std::make_unique<PolygonPool>(hw > 4 ? 3u : hw - 1u);
+        }
+        _polygonPool->run(static_cast<int>(hostPolygons.size()), build_host_polygon);
+    }
+    else
+        for (size_t k = 0; k < hostPolygons.size(); ++k)
+            build_host_polygon(static_cast<int>(k));
+    size_t nextHost = 0;
     for (int i = 0; i < r.header.n_plane_segments; ++i)
     {
         const cape_plane_segment& s = r.segments[i];
@@ -128,7 +295,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         {
             // device polygon of this segment, if the batch built them: the ring goes through the reference's
             // Polygon(ring, xAxis, yAxis, center) constructor (polygon.cpp:236-266) -- no hull on the host.  A plane with more
-            // boundary points than the device kernel takes (CAPE_POLY_OVERFLOW) falls through to the host class.
+            // boundary points than the device kernel takes (CAPE_POLY_OVERFLOW) was built by the host class above.
             const cape_polygon* dp = shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i] : nullptr;
             if (dp && !(dp->flags & CAPE_POLY_OVERFLOW))
             {
@@ -148,23 +315,11 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
                 planes.emplace_back(planeSegment, polygon);
                 continue;
             }
-            if (!bnd)
-            {
-                outputs::log_error("Polyfit error: boundary points of the plane were not read back");
-                continue;
-            }
-            orderedBoundary.clear();
-            orderedBoundary.reserve(s.boundary_count);
-            const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
-            for (uint32_t k = 0; k < s.boundary_count; ++k)
-                orderedBoundary.emplace_back(p[3 * k], p[3 * k + 1], p[3 * k + 2]);
-            // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
-            const CameraPolygon polygon(orderedBoundary, planeSegment.get_normal(), planeSegment.get_center());
-            std::string debug;
-            if (polygon.is_valid(debug) and polygon.boundary_length() >= 3)
-                planes.emplace_back(planeSegment, polygon);
+            HostPolygon& hp = hostPolygons[nextHost++];
+            if (hp.polygon)
+                planes.emplace_back(planeSegment, *hp.polygon);
             else
-                outputs::log_error("Polyfit error: " + debug);
+                outputs::log_error("Polyfit error: " + hp.error);
         }
         catch (const std::exception& e)
         {
@@ -382,6 +537,8 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
         }
         const depth_image d = depthImage.isContinuous() ? depthImage : depthImage.clone();
         const auto t0 = std::chrono::steady_clock::now();
+        if (_polygonPool)
+            _polygonPool->prepare(); // the polygon workers wake up while the device works on the frame
         if (!extract_chunk(_single, d.ptr<float>(0), nullptr, 1.0f, 1))
         {
             outputs::log_error("find_primitives: " + _single.error);

@@ -25,6 +25,8 @@
 
 namespace rgbd_slam::features::primitives {
 
+struct PolygonPool; // a few worker threads for the host-side boundary polygons of the one-frame call (primitive_detection.cpp)
+
 class Primitive_Detection
 {
   public:
@@ -156,6 +158,7 @@ class Primitive_Detection
     int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
     int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
+    mutable std::unique_ptr<PolygonPool> _polygonPool; // created at the first frame that shows three or more planes
     mutable std::vector<Shard> _shards;    // batch shards (max_batch = set_chunk_frames each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
 
