@@ -309,7 +309,12 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 // when the walk came back to it, every point once when it ran out of points first.
 // `planeState` (task kernel only, else null): the plane's state word in global memory; a rung gives up as soon as a lower rung
 // has its hull (or the plane is finalised) -- it can no longer win.  Looked at every sixteenth step (a read-modify-write: ~2 us).
-template <int CAP> __device__ inline bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
+#ifdef CAPE_POLY_WALK_NOINLINE
+#define CAPE_WALK_ATTR __attribute__((noinline))
+#else
+#define CAPE_WALK_ATTR inline
+#endif
+template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
                                                         int myRung = 0)
 {
     constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
