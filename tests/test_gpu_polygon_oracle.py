@@ -208,3 +208,36 @@ def test_polygon_matches_against_the_reference_algorithm(P):
                     pairs += 1
         assert pairs > n and decided > n // 2, (pairs, decided)
         ex.close()
+
+
+def test_device_polygons_1280x960_against_the_reference_algorithm(P):
+    """BASELINE.json configs[4] geometry: the 64 x 48 cell grid, whose planes have several hundred boundary candidates -- the
+    1 024-point instance of the device hull (the whole ladder in one wave) -- against the oracle of the reference's algorithm."""
+    import torch
+    from cape_amd import Extractor, synth, synth_gpu
+
+    n = 12
+    stats = new_stats()
+    big = 0
+    for scene in ("room", "tumlike"):
+        base = synth.TUM_FR1_INTRINSICS if scene == "tumlike" else synth.DEFAULT_INTRINSICS
+        intr = {k: v * 2.0 for k, v in base.items()}
+        dev = synth_gpu.stream(scene, 33, n, width=1280, height=960, start=20, device="cuda", chunk=4)
+        ex = Extractor(1280, 960, cylinders=True, max_batch=n, **intr)
+        st = torch.cuda.current_stream().cuda_stream
+        ex.extract_device(dev.data_ptr(), n, st)
+        ex.build_polygons(n, st)
+        res = ex.results(n)
+        pol, ver = ex.polygons(n)
+        for f in range(n):
+            for i, s in enumerate(res.segments(f)):
+                if not s["is_output"]:
+                    continue
+                p = pol[f, i]
+                o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+                big += int(s["boundary_count"] > 256)
+                compare_plane(P, p, ver[f, o:o + c], res.boundary_points(f, s), s["normal"], _center(s), f"1280x960 {scene} frame {f} segment {i}", stats)
+        ex.close()
+    compared = stats["planes"] - stats["threw"] - len(stats["dissolve"])
+    assert big >= 4, "the wide grid must show planes beyond the 256-point task kernel"
+    assert compared >= 2 * n and stats["vertex_identical"] >= 0.98 * compared, stats
