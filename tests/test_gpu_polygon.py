@@ -215,3 +215,29 @@ def test_polygons_1280x960_and_one_frame_handle(host_poly):
                 _same(p, ver[f, o:o + c], host_poly(pts, s["normal"], _center(s)), f"1280x960 frame {f} segment {i} ({len(pts)} points)")
         ex.close()
     assert big > 0, "the wide grid must produce planes beyond the small instance's 256 points"
+
+
+def test_polygon_pass_without_planes_terminates():
+    """The task kernel's waiting waves are sent home by the wave that finishes the last plane: a batch WITHOUT any plane (empty
+    frames), and one-frame / few-plane batches, must return all the same."""
+    import torch
+    from cape_amd import Extractor, synth, synth_gpu
+
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (1, 5, 64):
+        empty = torch.zeros((n, 480, 640), dtype=torch.float32, device="cuda")
+        ex = Extractor(640, 480, cylinders=True, max_batch=max(n, 9), **synth.DEFAULT_INTRINSICS)
+        ex.extract_device(empty.data_ptr(), n, st)
+        ex.build_polygons(n, st)
+        ex.match_polygons(n, 0, st)
+        pol, _ = ex.polygons(n)
+        assert not pol["flags"].any() and not pol["vertex_count"].any()
+        # the same handle, next batch: one frame with planes among empty ones
+        one = synth_gpu.stream("room", 8, 1, start=3, device="cuda", chunk=1)
+        mixed = empty.clone()
+        mixed[n // 2] = one[0]
+        ex.extract_device(mixed.data_ptr(), n, st)
+        ex.build_polygons(n, st)
+        pol, _ = ex.polygons(n)
+        assert (pol["flags"][n // 2] & 1).any() and not np.delete(pol["flags"], n // 2, axis=0).any()
+        ex.close()
