@@ -54,8 +54,16 @@ if os.environ.get("CAPE_POLY_PHASES"):
     print("task kernel: static tasks %d (%.0f ticks each to get), spawned / idle-exit acquisitions %d (%.0f ticks each)" % (
         raw[0, 26], raw[0, 24] / max(1, raw[0, 26]), raw[0, 27], raw[0, 25] / max(1, raw[0, 27])))
     t = ex.debug_cycles(B)[0].astype(np.int64)
-    print("   timeline (ticks from the first wave's start): planes of the batch handed out %d, last polygon %d, last wave leaves %d; busy %.0f ticks per wave (%d waves)" % (
-        t[7] - t[6], t[23] - t[6], t[31] - t[6], float(t[28]) / (ex.compute_units * 16), ex.compute_units * 16))
+    print("   timeline (us after the first wave's start, wall_clock64): planes of the batch handed out %.1f, last polygon %.1f, last wave leaves %.1f; busy %.0f shader ticks per wave (%d waves)" % (
+        (t[7] - t[6]) / 100.0, (t[23] - t[6]) / 100.0, (t[31] - t[6]) / 100.0, float(t[28]) / (ex.compute_units * 16), ex.compute_units * 16))
+if os.environ.get("CAPE_POLY_PHASES"):
+    rawi = ex.debug_cycles(B).astype(np.int64)
+    has = rawi[:, 22] > 0
+    t0 = rawi[0, 6]
+    end = (rawi[:, 22] - t0) / 100.0  # wall_clock64 ticks of 10 ns -> us
+    print("   frames' last polygon finished at (us after the kernel's first wave started): percentiles", {q: int(np.percentile(end[has], q)) for q in (10, 50, 90, 99, 99.9, 100)})
+    for f in np.argsort(np.where(has, end, 0))[-8:]:
+        print("      frame %d: last polygon at %.1f us, %d candidates, winning rung %d (0 = convex fallback)" % (f, end[f], rawi[f, 21], rawi[f, 20] - 1))
 if os.environ.get("CAPE_POLY_PHASES"):
     per = ex.debug_cycles(B).astype(np.float64)
     t = per[:, :6].sum(1)

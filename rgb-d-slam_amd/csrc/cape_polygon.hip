@@ -858,6 +858,7 @@ template <int CAP> __device__ inline void finish_polygon(const PolygonParams& p,
         }
         CAPE_POLY_SYNC();
     }
+    bool knownSimple = haveRing; // the oriented (or cut) hull passed ring_is_simple above; a convex fallback ring was not tested
     CAPE_PTICK(3); // orientation, validity of the oriented ring, convex fallback
     CAPE_PCOUNT(9, rn); // vertices before simplification
     CAPE_PCOUNT(10, nPts); // points
@@ -898,14 +899,9 @@ template <int CAP> __device__ inline void finish_polygon(const PolygonParams& p,
                     bestI = i;
                 }
             }
-            // wave maximum of the distance, smallest index among the equal ones
-            unsigned long long mx = best;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-            {
-                const unsigned long long ob = (unsigned long long)__shfl_xor((long long)mx, o);
-                mx = ob > mx ? ob : mx;
-            }
+            // wave maximum of the distance (on DPP: a __shfl_xor butterfly is six trips through the LDS crossbar), smallest index
+            // among the equal ones
+            const unsigned long long mx = ~wave_min_u64(~best);
             const unsigned mineKey = (bestI != 0x7FFFFFFF && best == mx) ? (unsigned)(0x7FFFFFFF - bestI) : 0u;
             const int idx = 0x7FFFFFFF - (int)wave_max_u32(mineKey);
             const double dmax = __longlong_as_double((long long)mx);
@@ -944,13 +940,16 @@ template <int CAP> __device__ inline void finish_polygon(const PolygonParams& p,
                 rn = cn;
                 area = newArea;
                 flags |= CAPE_POLY_SIMPLIFIED;
+                knownSimple = true;
                 CAPE_POLY_SYNC();
             }
         }
     }
     CAPE_PTICK(4); // area + simplify
     // ---- what Primitive_Detection keeps: a valid polygon of at least three vertices (primitive_detection.cpp:623-631)
-    if (rn >= 3 && ring_is_simple(L.pts, ring, rn, lane))
+    // (a ring that came through the hull's own test, or through the simplification's, is not tested a third time: the verdict
+    //  is a pure function of the ring)
+    if (rn >= 3 && (knownSimple || ring_is_simple(L.pts, ring, rn, lane)))
         flags |= CAPE_POLY_VALID;
     for (int i = lane; i < rn; i += 64)
         vout[i] = L.pts[ring[i]];
@@ -1117,10 +1116,11 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
     if (statList[3] == 0u)
         return; // no plane in the batch: nobody would ever send the waiting waves home
 #ifdef CAPE_POLY_PROFILE
+    // (wall_clock64: the 100 MHz counter the whole device shares -- s_memtime is per XCD, with bases 1e12 ticks apart)
     // frame 0's spare slots: 6 kernel start (min), 7 static list handed out (min), 23 last polygon (max), 31 last wave leaves (max), 28 busy ticks (sum)
     unsigned long long* tl = p.prof;
     if (lane == 0)
-        atomicMin(&tl[6], __builtin_amdgcn_s_memtime());
+        atomicMin(&tl[6], (unsigned long long)wall_clock64());
 #endif
     for (;;)
     {
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
                 {
                     server = true; // the planes of the batch are handed out: from now on this wave serves spawned rungs
 #ifdef CAPE_POLY_PROFILE
-                    atomicMin(&tl[7], __builtin_amdgcn_s_memtime());
+                    atomicMin(&tl[7], (unsigned long long)wall_clock64());
 #endif
                 }
             }
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
         {
 #ifdef CAPE_POLY_PROFILE
             if (lane == 0)
-                atomicMax(&tl[31], __builtin_amdgcn_s_memtime());
+                atomicMax(&tl[31], (unsigned long long)wall_clock64());
 #endif
             break;
         }
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
                 {
                     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
                     atomicAdd(&tl[28], t1 - t0);
-                    atomicMax(&tl[23], t1);
+                    atomicMax(&tl[23], (unsigned long long)wall_clock64());
                 }
             }
         } busyScope {tl, busy0, lane};
@@ -1341,6 +1341,18 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
 #ifdef CAPE_POLY_DEBUG_RUNG
                     if (lane == 0)
                         p.polygons[(size_t)c.frame * CAPE_MAX_PLANES + c.seg].flags |= ((uint32_t)(winner + 1) << 8) | ((uint32_t)r << 12) | (now << 16);
+#endif
+#ifdef CAPE_POLY_PROFILE
+                    if (lane == 0 && p.prof)
+                    {
+                        // per frame: when its last polygon was finished (slot 22), that plane's candidates (21) and winning rung + 1 (20)
+                        const unsigned long long tEnd = (unsigned long long)wall_clock64();
+                        if (atomicMax(&p.prof[(size_t)c.frame * kProfileSlots + 22], tEnd) < tEnd)
+                        {
+                            p.prof[(size_t)c.frame * kProfileSlots + 21] = (unsigned long long)n;
+                            p.prof[(size_t)c.frame * kProfileSlots + 20] = (unsigned long long)(winner + 1);
+                        }
+                    }
 #endif
                     plane_finished(statList, dynList, listCapacity, totalWaves, lane);
                 }
