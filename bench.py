@@ -776,6 +776,39 @@ def main():
                 print(f"bench.py: find_primitives_equivalent results differ from the oracles: {pc4} {fpe['polygon_check']}", file=sys.stderr)
                 raise SystemExit(3)
         ex3.close()
+        # The same three calls per batch on TWO handles, each on a stream of its own, fed alternately: the polygon task kernel
+        # and the cylinder second pass wait most of their cycles (dependent chains), the streaming kernels of the other handle's
+        # batch issue under them.  Same frames, same results (both handles checked), twice the scratch memory.
+        streams2 = [torch.cuda.Stream(device=local_rank) for _ in range(2)]
+        pair = [Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, **intr) for _ in range(2)]
+
+        def full_step_on(i):
+            h, st = pair[i & 1], streams2[i & 1].cuda_stream
+            h.extract_device(depth.data_ptr(), B, st)
+            h.build_polygons(B, st)
+            h.match_polygons(B, 0, st)
+
+        for i in range(4):
+            full_step_on(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k2):
+            full_step_on(i)
+        torch.cuda.synchronize()
+        e5 = time.perf_counter() - t0
+        fpe["two_handles_overlapped"] = {"value": B * k2 / e5, "ms_per_step": 1e3 * e5 / k2,
+                                         "note": "two handles on two streams fed alternately (extract + polygons + matches each): one batch's "
+                                                 "streaming kernels run under the other's polygon walks and cylinder second pass"}
+        if not args.no_parity_check:
+            for h in pair:
+                pc5 = parity_check(h, unique_dev[:16].cpu().numpy(), intr, True, 16)
+                pg5 = polygon_check(h, 32)
+                if not parity_ok(pc5) or not pg5["ok"]:
+                    print(f"bench.py: overlapped find_primitives_equivalent results differ from the oracles: {pc5} {pg5}", file=sys.stderr)
+                    raise SystemExit(3)
+            fpe["two_handles_overlapped"]["parity_check"] = "both handles: 16 / 16 frames bit-exact vs the oracle, 32 frames' polygons + matches vs the polygon oracle"
+        for h in pair:
+            h.close()
         out["find_primitives_equivalent"] = fpe
     if out is not None and polygons_leg is not None:
         out["boundary_polygons"] = polygons_leg

@@ -19,6 +19,7 @@ namespace cape {
 // every launcher returns the error of its own launch(es) (hipGetLastError right behind hipLaunchKernelGGL)
 hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
+hipError_t launch_cell_strips(const StageAParams& p, int nFrames, uint32_t* frameCounters, hipStream_t stream);
 int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side = nullptr, hipEvent_t fork = nullptr,
                        hipEvent_t done = nullptr);
@@ -118,6 +119,11 @@ struct cape_handle_s
     double* cylScratch = nullptr;
     uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
     uint32_t* redoList = nullptr;     // [0] count, [1..] frames that need more than 32 plane-segment slots
+    // one-frame handles (max_batch <= kHostResultFrames): stage A runs as ONE launch of strip workgroups (cape_cell_strip_kernel);
+    // a counter per frame tells the strip that finishes last.  nullptr: the two throughput kernels (debug knob CAPE_STAGE_A=bands)
+    uint32_t* stripCounters = nullptr;
+    bool stripsAlways = false; // CAPE_STAGE_A=strips: also when the frame is read over the link (see launch_chain)
+    bool inputOverLink = false; // the call in flight reads its frames straight from pinned host memory (cape_extract_host)
     uint32_t* resumeList = nullptr;   // [0] count, [1..] frames handed to the cylinder kernel WITH their recorded regions
     unsigned char* growState = nullptr; // max_batch x grow_state_bytes(): the parked state of those frames
     // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
@@ -260,6 +266,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cylScratch);
     (void)hipFree(h->needCylinder);
     (void)hipFree(h->redoList);
+    (void)hipFree(h->stripCounters);
     (void)hipFree(h->resumeList);
     (void)hipFree(h->growState);
     if (h->handedOverHost)
@@ -503,18 +510,35 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         return rc;
     if (t)
         CAPE_HIP_TRY(hipEventRecord(t->e[0], st));
-    CAPE_HIP_TRY(cape::launch_cell_moments(a, frames, st));
-    if (t)
-        CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
     cape::StageAParams a2 = a;
     a2.clear0 = b.redoList;
     a2.clear1 = b.needCylinder;
     a2.clear2 = b.resumeList;
-    CAPE_HIP_TRY(cape::launch_cell_plane(a2, frames, st));
-    if (t)
-        CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
+    // A frame read straight from pinned host memory arrives at the link's pace (~34 us for 1.2 MB): the band kernel streams it in
+    // and the plane kernel's 17 us follow; a strip's tail behind its last pixel is as long, so nothing is gained there (measured,
+    // profiles/r04_single_frame_latency.txt).  With the frame in HBM the one-launch form is 5-10 us faster.
+    const bool strips = h->stripCounters != nullptr && frames <= kHostResultFrames && (!h->inputOverLink || h->stripsAlways);
+    if (strips)
+    {
+        // the latency instance: all of stage A in one launch (timing: booked as the moments kernel, the plane kernel reads 0)
+        CAPE_HIP_TRY(cape::launch_cell_strips(a2, frames, h->stripCounters, st));
+        if (t)
+        {
+            CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
+            CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
+        }
+    }
+    else
+    {
+        CAPE_HIP_TRY(cape::launch_cell_moments(a, frames, st));
+        if (t)
+            CAPE_HIP_TRY(hipEventRecord(t->e[1], st));
+        CAPE_HIP_TRY(cape::launch_cell_plane(a2, frames, st));
+        if (t)
+            CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
+    }
     cape::StageBParams bb = b;
-    bb.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, frames);
+    bb.a2RowsPerTile = strips ? a.vCells : cape::cell_plane_rows_per_tile(a, frames);
     bb.countersCleared = 1;
     if (bb.needCylinder)
     {
@@ -668,6 +692,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     if (const char* e = std::getenv("CAPE_SCHEDULE"))
         if (std::string(e) != "two" && std::string(e) != "single")
             return fail(CAPE_ERR_INVALID_ARGUMENT, "CAPE_SCHEDULE must be two or single");
+    if (const char* e = std::getenv("CAPE_STAGE_A"))
+        if (std::string(e) != "strips" && std::string(e) != "bands")
+            return fail(CAPE_ERR_INVALID_ARGUMENT, "CAPE_STAGE_A must be strips or bands");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -734,6 +761,15 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
+    {
+        const char* stageA = std::getenv("CAPE_STAGE_A");
+        if (cfg->max_batch <= kHostResultFrames && cfg->sub_batches <= 1 && !(stageA && std::string(stageA) == "bands"))
+        {
+            h->stripsAlways = stageA != nullptr; // (validated above: "strips")
+            CAPE_ALLOC(dalloc(h->stripCounters, (size_t)kHostResultFrames));
+            CAPE_ALLOC(hipMemset(h->stripCounters, 0, kHostResultFrames * sizeof(uint32_t)));
+        }
+    }
     CAPE_ALLOC(hipEventCreateWithFlags(&h->workDone, hipEventDisableTiming));
     if ((cfg->flags & CAPE_FLAG_ASYNC_SECOND_PASS) && (cfg->flags & CAPE_FLAG_CYLINDERS) && cfg->max_batch > kHostResultFrames &&
         cfg->sub_batches <= 1)
@@ -1078,7 +1114,12 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
     if (!pinned)
         (void)hipGetLastError(); // an unregistered pointer is not an error here
     if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 16 == 0)
-        return cape_extract(h, static_cast<const float*>(attr.devicePointer), n_frames, stream_);
+    {
+        h->inputOverLink = true;
+        const int rc = cape_extract(h, static_cast<const float*>(attr.devicePointer), n_frames, stream_);
+        h->inputOverLink = false;
+        return rc;
+    }
     const size_t bytes = (size_t)h->cfg.max_batch * frameBytes;
     if (!h->depthStage)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), bytes));
@@ -1128,7 +1169,12 @@ int cape_extract_u16_host(cape_handle h, const uint16_t* depth_host, float scale
     if (!pinned)
         (void)hipGetLastError();
     if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 8 == 0)
-        return cape_extract_u16(h, static_cast<const uint16_t*>(attr.devicePointer), scale, n_frames, stream_);
+    {
+        h->inputOverLink = true;
+        const int rc = cape_extract_u16(h, static_cast<const uint16_t*>(attr.devicePointer), scale, n_frames, stream_);
+        h->inputOverLink = false;
+        return rc;
+    }
     if (!h->depthStage) // (sized for float32 frames: cape_extract_host shares it)
         CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->depthStage), (size_t)h->cfg.max_batch * h->cfg.width * h->cfg.height * sizeof(float)));
     CAPE_HIP_TRY(hipMemcpyAsync(h->depthStage, depth_host, (size_t)n_frames * frameBytes, hipMemcpyHostToDevice, stream));

@@ -75,7 +75,7 @@ def test_create_rejects_unknown_flags_and_knob_values(hip_library):
         "cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 1, 0, 1, 0, 0)\n"
         "h = C.c_void_p()\n"
         "print(L.cape_create(C.byref(cfg), C.byref(h)), L.cape_last_error().decode())\n" % os.path.join(ROOT, "rgb-d-slam_amd", "python"))
-    for knob in ("CAPE_RESUME", "CAPE_SCHEDULE"):
+    for knob in ("CAPE_RESUME", "CAPE_SCHEDULE", "CAPE_STAGE_A"):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "sideways"}), capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-800:]
         rc, msg = out.stdout.strip().split(" ", 1)

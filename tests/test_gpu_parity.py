@@ -78,8 +78,18 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert sorted(map(tuple, _bits(b_gpu).tolist())) == sorted(map(tuple, _bits(b_orc).tolist())), "boundary points"
 
 
+@pytest.fixture(params=["strips", "bands"])
+def stage_a(request, monkeypatch):
+    """One-frame handles (max_batch <= 8) run stage A as ONE launch of strip workgroups (cape_cell_strip_kernel: the strip's
+    workgroup sums, scans and fits its cells, the frame's last workgroup evaluates the cell edges); CAPE_STAGE_A=bands keeps
+    the two throughput kernels on such a handle.  The edge-case tests run on both instances (the knob is read at cape_create)."""
+    monkeypatch.setenv("CAPE_STAGE_A", request.param)
+    return request.param
+
+
+
 @pytest.mark.parametrize("scene,seed,frame", SCENES)
-def test_frame_parity_640(oracle_mod, scene, seed, frame):
+def test_frame_parity_640(oracle_mod, scene, seed, frame, stage_a):
     from cape_amd import Extractor, synth
 
     depth = synth.SCENES[scene](seed=seed, frame=frame)
@@ -93,7 +103,7 @@ def test_frame_parity_640(oracle_mod, scene, seed, frame):
     ex.close()
 
 
-def test_batch_matches_single_frames(oracle_mod):
+def test_batch_matches_single_frames(oracle_mod, stage_a):
     """A batch is frames processed independently: every frame of a mixed batch equals its own oracle run."""
     from cape_amd import Extractor, synth
 
@@ -111,7 +121,7 @@ def test_batch_matches_single_frames(oracle_mod):
     ex.close()
 
 
-def test_edge_inputs(oracle_mod):
+def test_edge_inputs(oracle_mod, stage_a):
     """NaN / negative / huge depths, ragged holes, constant depth (degenerate scatter -> rejected cells)."""
     from cape_amd import Extractor, synth
 
@@ -137,7 +147,7 @@ def test_edge_inputs(oracle_mod):
     ex.close()
 
 
-def test_sparse_invalid_patterns_inside_valid_cells(oracle_mod):
+def test_sparse_invalid_patterns_inside_valid_cells(oracle_mod, stage_a):
     """The streaming kernel accumulates pixels without the reference's `z > 0` test and leaves every cell that holds a
     bit pattern the test would reject (negative, -0, NaN) or that cannot be summed exactly (+inf) to the in-order pass
     of the per-cell kernel.  Sprinkle such values thinly over cells that stay valid (>= 200 good pixels, continuous):
@@ -180,7 +190,7 @@ def test_sparse_invalid_patterns_inside_valid_cells(oracle_mod):
     ex.close()
 
 
-def test_parity_1280x960(oracle_mod):
+def test_parity_1280x960(oracle_mod, stage_a):
     from cape_amd import Extractor, synth
 
     intr = _intr("room", 2.0)
@@ -193,7 +203,7 @@ def test_parity_1280x960(oracle_mod):
     ex.close()
 
 
-def test_inorder_guard_path(oracle_mod):
+def test_inorder_guard_path(oracle_mod, stage_a):
     """Intrinsics with a near-zero column factor force the exactness guard onto the in-order path; still bit-exact."""
     from cape_amd import Extractor, synth
 
@@ -296,7 +306,7 @@ CYL_SCENES = [("tunnel", 0, 0), ("tunnel", 4, 9), ("tunnel", 7, 123), ("tumlike"
 
 
 @pytest.mark.parametrize("scene,seed,frame", CYL_SCENES)
-def test_frame_parity_with_cylinders(oracle_mod, scene, seed, frame):
+def test_frame_parity_with_cylinders(oracle_mod, scene, seed, frame, stage_a):
     """BASELINE.json configs[2]: planes + cylinder RANSAC, RNG stream restarted per frame (mt19937(0))."""
     from cape_amd import Extractor, synth
 
@@ -397,7 +407,7 @@ def test_packed_payload_visible_to_torch_without_copy():
     ex.close()
 
 
-def test_raw_uint16_input_path(oracle_mod):
+def test_raw_uint16_input_path(oracle_mod, stage_a):
     """N4: cape_extract_u16 (device-side convertTo(CV_32F, 1/5)) equals the float path and the oracle, bit for bit."""
     import os
 
@@ -492,7 +502,7 @@ def test_random_frames_property(oracle_mod):
         ex.close()
 
 
-def test_pathological_values_terminate_and_match_labels(oracle_mod):
+def test_pathological_values_terminate_and_match_labels(oracle_mod, stage_a):
     """+inf / NaN / denormal / 1e30 depths: both paths terminate; integer observables still agree (float payloads of
     NaN sums are not compared)."""
     from cape_amd import Extractor, synth
@@ -631,7 +641,7 @@ def test_large_mixed_batch_labels(oracle_mod):
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (800, 600), (1280, 720), (160, 120), (1000, 40)])
-def test_other_grid_shapes(oracle_mod, w, h):
+def test_other_grid_shapes(oracle_mod, w, h, stage_a):
     """Grids that are not 32x24 / 64x48: partial band segments (40 = 32 + 8 cells), odd band counts, u64 rows with
     fewer than 64 columns, a single cell row."""
     from cape_amd import Extractor, synth
@@ -834,3 +844,44 @@ def test_device_rendered_streams_parity(oracle_mod, scene, cyl):
     for f in range(2):
         compare_frame(orc.run(as_f32[f]), ex, res, f, check_cells=False)
     ex.close()
+
+
+def test_stage_a_instances_agree_on_pinned_and_device_input(oracle_mod, monkeypatch):
+    """The latency instance of stage A (strips) and the throughput kernels (bands) leave the same bits for the grow kernel,
+    whichever way the frame arrives: pageable (staged copy -> strips), pinned (read over the link -> bands unless forced),
+    resident in HBM.  Checked on the cell statistics, the edge predicates as the seed sequence / label grids show them, and
+    against the oracle; several calls in a row (the per-frame strip counter is handed back at zero)."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    intr = _intr("tumlike")
+    frames = np.stack([synth.tumlike(seed=4, frame=i * 3) for i in range(3)])
+    frames[1, 200:260, 100:400] = 0.0
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    want = [orc.run(f) for f in frames]
+    for mode in (None, "strips", "bands"):
+        if mode:
+            monkeypatch.setenv("CAPE_STAGE_A", mode)
+        else:
+            monkeypatch.delenv("CAPE_STAGE_A", raising=False)
+        ex = Extractor(640, 480, cylinders=True, max_batch=2, **intr)
+        pinned = ex.host_alloc((2, 480, 640))
+        dev = torch.from_numpy(frames).cuda()
+        for rep in range(2):
+            for k in range(3):
+                # pageable
+                n = ex.extract_host(frames[k])
+                compare_frame(want[k], ex, ex.results(n), 0)
+                # pinned: two frames in one call
+                pinned[0] = frames[k]
+                pinned[1] = frames[(k + 1) % 3]
+                n = ex.extract_host(pinned)
+                res = ex.results(n)
+                compare_frame(want[k], ex, res, 0)
+                compare_frame(want[(k + 1) % 3], ex, res, 1)
+                # resident in HBM
+                ex.extract_device(dev[k].data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                compare_frame(want[k], ex, ex.results(1), 0)
+        ex.host_free(pinned)
+        ex.close()
