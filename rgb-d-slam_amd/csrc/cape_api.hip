@@ -514,6 +514,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     a2.clear0 = b.redoList;
     a2.clear1 = b.needCylinder;
     a2.clear2 = b.resumeList;
+    a2.clear2Buckets = b.resumeList ? b.resumeBucketStride : 0u;
     // A frame read straight from pinned host memory arrives at the link's pace (~34 us for 1.2 MB): the band kernel streams it in
     // and the plane kernel's 17 us follow; a strip's tail behind its last pixel is as long, so nothing is gained there (measured,
     // profiles/r04_single_frame_latency.txt).  With the frame in HBM the one-launch form is 5-10 us faster.
@@ -752,8 +753,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         const char* resumeEnv = std::getenv("CAPE_RESUME");
         if (!(resumeEnv && std::string(resumeEnv) == "off") && !std::getenv("CAPE_NO_RESUME"))
         {
-            CAPE_ALLOC(dalloc(h->resumeList, 2 * B + 2));
-            CAPE_ALLOC(hipMemset(h->resumeList, 0, (2 * B + 2) * sizeof(uint32_t)));
+            // the list + its cost-class lists (StageBParams::resumeBucketStride), one stride apart
+            CAPE_ALLOC(dalloc(h->resumeList, (1 + cape::kResumeClasses) * (2 * B + 2)));
+            CAPE_ALLOC(hipMemset(h->resumeList, 0, (1 + cape::kResumeClasses) * (2 * B + 2) * sizeof(uint32_t)));
             CAPE_ALLOC(dalloc(h->growState, B * cape::grow_state_bytes(h->cells)));
         }
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->handedOverHost), 2 * sizeof(uint32_t)));
@@ -913,6 +915,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.needCylinder = h->needCylinder;
     b.redoList = h->redoList;
     b.resumeList = h->resumeList;
+    b.resumeBucketStride = h->resumeList ? (uint32_t)(2 * B + 2) : 0u;
     b.growState = h->growState;
     b.growStateStride = (uint32_t)cape::grow_state_bytes(h->cells);
     b.ldsLimitBytes = h->ldsLimit;
@@ -1073,6 +1076,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
             a.clear0 = b.redoList;
             a.clear1 = b.needCylinder;
             a.clear2 = b.resumeList;
+            a.clear2Buckets = b.resumeList ? b.resumeBucketStride : 0u;
             CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));

@@ -513,7 +513,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
         if (p.clear1)
             *p.clear1 = 0u;
         if (p.clear2)
+        {
             *p.clear2 = 0u;
+            if (p.clear2Buckets)
+                for (int c = 1; c <= kResumeClasses; ++c)
+                    p.clear2[(size_t)c * p.clear2Buckets] = 0u;
+        }
     }
     const int HC = p.hCells, VC = p.vCells;
     const int rowsPerTile = THREADS / HC > 0 ? THREADS / HC : 1;
@@ -652,7 +657,12 @@ template <bool U16> __global__ __launch_bounds__(kStripThreads) void cape_cell_s
         if (p.clear1)
             *p.clear1 = 0u;
         if (p.clear2)
+        {
             *p.clear2 = 0u;
+            if (p.clear2Buckets)
+                for (int c = 1; c <= kResumeClasses; ++c)
+                    p.clear2[(size_t)c * p.clear2Buckets] = 0u;
+        }
     }
     const int HC = p.hCells, VC = p.vCells;
     const int stripsPerRow = (HC + kStripCells - 1) / kStripCells;

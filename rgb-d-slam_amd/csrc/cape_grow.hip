@@ -52,9 +52,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
     else if (RESUME)
     {
         // second pass, frames parked with their state: wave k takes the k-th of them
-        if (frame >= (int)p.resumeList[0])
+        frame = resume_pick(p, frame);
+        if (frame < 0)
             return;
-        frame = (int)p.resumeList[1 + frame];
     }
     else if (CYL && p.twoPass)
     {
@@ -654,8 +654,25 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
                             glist[i] = s_list[i];
                         for (int i = lane; i < C; i += 64)
                             glab[i] = s_lab[i];
+                        // cost class of what is left to do: the cells of the records that will go to cylinder_fitting
+                        int candCells = 0;
+                        if (lane < pendCount - j)
+                        {
+                            const double* rs = s_pend + (j + lane) * kSegDoubles;
+                            const int cellsOf = (int)(s_adj[j + lane] >> 32);
+                            if (rs[19] != 0.0 && !(rs[18] > 100) && cellsOf > 5)
+                                candCells = cellsOf;
+                        }
+                        candCells = wave_sum_i32(candCells);
                         if (lane == 0)
+                        {
                             p.resumeList[1 + atomicAdd(&p.resumeList[0], 1u)] = (uint32_t)frame;
+                            if (p.resumeBucketStride)
+                            {
+                                uint32_t* bl = p.resumeList + (size_t)(1 + resume_cost_class(candCells, C)) * p.resumeBucketStride;
+                                bl[1 + atomicAdd(&bl[0], 1u)] = (uint32_t)frame;
+                            }
+                        }
                     }
                     else if (lane == 0)
                         p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
@@ -881,7 +898,8 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
         if (!p.countersCleared)
             CAPE_LAUNCH_TRY(hipMemsetAsync(p.needCylinder, 0, sizeof(uint32_t), stream));
         if (p.resumeList && !p.countersCleared)
-            CAPE_LAUNCH_TRY(hipMemsetAsync(p.resumeList, 0, sizeof(uint32_t), stream));
+            for (int c = 0; c <= (p.resumeBucketStride ? kResumeClasses : 0); ++c)
+                CAPE_LAUNCH_TRY(hipMemsetAsync(p.resumeList + (size_t)c * p.resumeBucketStride, 0, sizeof(uint32_t), stream));
         CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
         if (side)
         {

@@ -185,6 +185,28 @@ __host__ __device__ constexpr size_t grow_state_list_off() { return grow_state_a
 __host__ __device__ inline size_t grow_state_lab_off(int cells) { return grow_state_list_off() + (((size_t)cells + 4) * 2 + 7) / 8 * 8; }
 __host__ __device__ inline size_t grow_state_bytes_(int cells) { return (grow_state_lab_off(cells) + (size_t)cells + 15) / 16 * 16; }
 
+// ---- the parked frames by cost class (StageBParams::resumeBucketStride): the k-th frame of the finisher, dearest class first
+__device__ __forceinline__ int resume_cost_class(int candidateCells, int cells)
+{
+    // cells that will go through cylinder_fitting (RANSAC + ordered sums), in eighths of the grid: whole walls ... a patch
+    const int c = candidateCells * kResumeClasses / (cells > 0 ? cells : 1);
+    return c < kResumeClasses ? c : kResumeClasses - 1;
+}
+__device__ __forceinline__ int resume_pick(const StageBParams& p, int k)
+{
+    if (!p.resumeBucketStride)
+        return k < (int)p.resumeList[0] ? (int)p.resumeList[1 + k] : -1;
+    for (int c = kResumeClasses; c >= 1; --c)
+    {
+        const uint32_t* bl = p.resumeList + (size_t)c * p.resumeBucketStride;
+        const int n = (int)bl[0];
+        if (k < n)
+            return (int)bl[1 + k];
+        k -= n;
+    }
+    return -1;
+}
+
 // Everything after the seed loop / the record -> segment conversion, for ONE wave (lane r owns grid row r): merge_planes,
 // boundary candidates, the segment records, the cylinder morphology, label grids and the frame header.  Shared by the grow
 // kernel and by the cylinder group kernel (cape_resume.hip), whose wave 0 runs it.

@@ -19,6 +19,7 @@ namespace cape {
 constexpr int kSumStride = 10;
 constexpr int kFastPlanes = 32;     // plane segments the everyday grow-kernel instances hold in LDS (CAPE_MAX_PLANES = 64 in the redo instance)
 constexpr int kProfileSlots = 32;   // phase counters per frame of a -DCAPE_B_PROFILE build (cape_debug_cycles)
+constexpr int kResumeClasses = 8;  // cost classes of the parked frames (StageBParams::resumeBucketStride)
 constexpr int kCylStride = 8;       // doubles per cell of the cylinder scratch: projected normal[3], projected centroid[3], their dot product, pad
 constexpr int kPlaneStride = 8;
 constexpr uint32_t kFlagPlanar = 1u << 31;
@@ -66,6 +67,7 @@ struct StageAParams
     uint32_t* clear0; // hand-over counters of the grow kernel (redo list, cylinder list, resume list): zeroed by one thread of
     uint32_t* clear1; // stage A2, which always runs right before it on the same stream -- instead of memset nodes per call
     uint32_t* clear2;
+    uint32_t clear2Buckets; // words between the resume list and each of its kResumeClasses cost-class lists (0: none), zeroed with clear2
     double cosMergeA; // cos(18 * pi / 180), plane_segment.cpp:324 (the edge predicates of stage A2)
     int smallBatchFrames; // host side: batches up to this many frames run the latency-oriented kernel instances
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
@@ -107,6 +109,10 @@ struct StageBParams
     // appends the frame to resumeList; the RESUME instance of the cylinder kernel picks the frame up at that region instead
     // of growing it again from the first seed (grow_state_bytes() per frame; nullptr: always the full redo).
     uint32_t* resumeList;
+    // the parked frames once more, by cost class (cells of their cylinder candidates): list c starts (c + 1) * resumeBucketStride words
+    // behind resumeList, same layout.  The finisher takes the dearest class first -- its pass lasts as long as its slowest frame, so
+    // the long ones must not start last (0: no class lists, frames in the order they were parked)
+    uint32_t resumeBucketStride;
     unsigned char* growState;
     uint32_t growStateStride;
     int resumeMode;          // how parked frames are finished: 2 = one workgroup per frame (cape_resume.hip), 1 = one wavefront

@@ -747,9 +747,9 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x >= p.resumeList[0])
-        return; // the grid is sized for the worst case; the k-th workgroup takes the k-th parked frame
-    const int frame = (int)p.resumeList[1 + blockIdx.x];
+    const int frame = resume_pick(p, (int)blockIdx.x); // the grid is sized for the worst case; the k-th workgroup takes the k-th parked frame
+    if (frame < 0)
+        return;
     constexpr int MAXP = kFastPlanes;
     const int C = p.cells;
     const size_t cellBase = (size_t)frame * C;
