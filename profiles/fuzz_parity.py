@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Long randomised GPU-vs-oracle parity sweep (not part of the test suite: minutes, not seconds).
-usage: fuzz_parity.py [n_frames=512] [seed=1] [width=640] [height=480]   -- every observable of every frame must be bit-identical."""
+usage: fuzz_parity.py [n_frames=512] [seed=1] [width=640] [height=480]   -- every observable of every frame must be bit-identical.
+FUZZ_BATCH=n: frames per call (n <= 8: one-frame handles, i.e. the latency instance of stage A and results in pinned memory);
+FUZZ_CELLS=1: the per-cell statistics are compared as well."""
 import os
 import sys
 
@@ -18,7 +20,8 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 480
 names = ["room", "tumlike", "tunnel", "facets", "facets", "tunnel"]
 intr = {k: v * W / 640.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
-B = 64 if W * H <= 640 * 480 else 16
+B = int(os.environ.get("FUZZ_BATCH", 64 if W * H <= 640 * 480 else 16))
+check_cells = os.environ.get("FUZZ_CELLS") == "1"
 bad = 0
 stats = {"cyl_labels": 0, "planes": 0, "merged": 0, "cyl_frames": 0}
 orc = {c: O.Oracle(W, H, cylinders=c, **intr) for c in (False, True)}
@@ -57,7 +60,7 @@ while done < n_total:
                 assert len(r.segments) > 64 or len(r.cylinders) >= 0
                 continue
             try:
-                compare_frame(r, ex[cyl], res, k, check_cells=False)
+                compare_frame(r, ex[cyl], res, k, check_cells=check_cells)
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH batch@{done} frame {k} cylinders={cyl}: {str(e)[:200]}", flush=True)
