@@ -167,6 +167,7 @@ struct cape_handle_s
     // resultsOnHost: a one-thread kernel behind every chain stores a sequence number into this pinned word; whoever reads
     // the results spins on it instead of going through the runtime's stream synchronisation (wait_results)
     uint32_t* doneFlag = nullptr;
+    uint32_t* doneCounter = nullptr; // device: the one-frame chain's grow kernel counts its waves out and stores the number itself
     uint32_t doneSeq = 0;      // sequence number of the last chain enqueued
     bool doneArmed = false;    // a chain with a signal behind it is (or was) in flight
     // host staging for cape_extract_host
@@ -267,6 +268,7 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->needCylinder);
     (void)hipFree(h->redoList);
     (void)hipFree(h->stripCounters);
+    (void)hipFree(h->doneCounter);
     (void)hipFree(h->resumeList);
     (void)hipFree(h->growState);
     if (h->handedOverHost)
@@ -541,6 +543,17 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     cape::StageBParams bb = b;
     bb.a2RowsPerTile = strips ? a.vCells : cape::cell_plane_rows_per_tile(a, frames);
     bb.countersCleared = 1;
+    // The one-frame chain: stage A, then ONE grow kernel -- the 64-segment instance on every frame of the call, no
+    // 32-segment pass in front, no redo pass and no one-thread signal kernel behind: its last wave stores the sequence number the
+    // host spins on.  Two launches instead of four or five on the path the reference calls (CAPE_STAGE_A=bands: the classic chain).
+    const bool oneFrameChain = h->resultsOnHost && h->doneFlag && h->doneCounter && frames <= kHostResultFrames;
+    if (oneFrameChain)
+    {
+        bb.allFrames = 1;
+        bb.doneFlag = h->doneFlag;
+        bb.doneCounter = h->doneCounter;
+        bb.doneSeq = ++h->doneSeq;
+    }
     if (bb.needCylinder)
     {
         // Cost model, in rounds of the cylinder kernel (one round = cylSlots resident frames, ~0.25 ms at 640x480):
@@ -593,8 +606,11 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         CAPE_HIP_TRY(hipEventRecord(t->e[3], h->sidePending ? h->sideStream : st));
     if (h->resultsOnHost && h->doneFlag)
     {
-        hipLaunchKernelGGL(cape_signal_kernel, dim3(1), dim3(1), 0, st, h->doneFlag, ++h->doneSeq);
-        CAPE_HIP_TRY(hipGetLastError());
+        if (!oneFrameChain)
+        {
+            hipLaunchKernelGGL(cape_signal_kernel, dim3(1), dim3(1), 0, st, h->doneFlag, ++h->doneSeq);
+            CAPE_HIP_TRY(hipGetLastError());
+        }
         h->doneArmed = true;
     }
     return CAPE_OK;
@@ -768,6 +784,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         if (cfg->max_batch <= kHostResultFrames && cfg->sub_batches <= 1 && !(stageA && std::string(stageA) == "bands"))
         {
             h->stripsAlways = stageA != nullptr; // (validated above: "strips")
+            CAPE_ALLOC(dalloc(h->doneCounter, 1));
+            CAPE_ALLOC(hipMemset(h->doneCounter, 0, sizeof(uint32_t)));
             CAPE_ALLOC(dalloc(h->stripCounters, (size_t)kHostResultFrames));
             CAPE_ALLOC(hipMemset(h->stripCounters, 0, kHostResultFrames * sizeof(uint32_t)));
         }

@@ -31,8 +31,9 @@ namespace cape {
 // their fits, the cell lists and the label grid) and carries on from that region: the rest of the record -> segment
 // conversion with cylinder_fitting, then merge_planes, boundaries and records like every other instance.  Without the
 // histogram, the edge masks, the MSE registers and the seed loop this instance is compiled for two waves per SIMD.
+// (the kernel's body; the __global__ function below adds the completion signal of the one-frame chain behind it)
 template <typename MaskT, bool CYL, int MAXP, bool RESUME>
-__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_WAVES : 1) : CAPE_B_PLANE_WAVES) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
+__device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFrames, int ldsPerWave)
 {
     static_assert(!RESUME || (CYL && MAXP == kFastPlanes), "only the 32-segment cylinder instance resumes parked frames");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -44,10 +45,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
     constexpr bool kRedo = MAXP > kFastPlanes;
     if (kRedo)
     {
-        // third pass: wave k takes the k-th frame that ran out of segment slots in one of the 32-segment instances
-        if (frame >= (int)p.redoList[0])
-            return;
-        frame = (int)p.redoList[1 + frame];
+        // third pass: wave k takes the k-th frame that ran out of segment slots in one of the 32-segment instances -- or, on the
+        // one-frame chain (p.allFrames), frame k itself: this instance is then the only grow kernel of the call
+        if (!p.allFrames)
+        {
+            if (frame >= (int)p.redoList[0])
+                return;
+            frame = (int)p.redoList[1 + frame];
+        }
     }
     else if (RESUME)
     {
@@ -770,6 +775,28 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
 #endif
 }
 
+template <typename MaskT, bool CYL, int MAXP, bool RESUME>
+__global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_WAVES : 1) : CAPE_B_PLANE_WAVES) void cape_grow_kernel(StageBParams p, int nFrames, int ldsPerWave)
+{
+    grow_frame_wave<MaskT, CYL, MAXP, RESUME>(p, nFrames, ldsPerWave);
+    // One-frame handles keep their results in pinned host memory and the caller spins on a sequence number there
+    // (cape_host_results).  The 64-segment instance is the LAST kernel of such a chain -- with p.allFrames the only grow kernel --,
+    // so its waves count themselves out and the last one stores the number: no one-thread kernel behind the chain.
+    if constexpr (MAXP > kFastPlanes)
+    {
+        if (p.doneFlag && (threadIdx.x & 63) == 0)
+        {
+            __threadfence_system(); // this wave's records, label grids and boundary points first
+            const unsigned total = gridDim.x * (blockDim.x >> 6);
+            if (atomicAdd(p.doneCounter, 1u) == total - 1u)
+            {
+                atomicExch(p.doneCounter, 0u); // ready for the next chain
+                __hip_atomic_store(p.doneFlag, p.doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes, bool resume)
 {
     size_t b = 0;
@@ -874,6 +901,15 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
         if (e_ != hipSuccess)              \
             return e_;                     \
     } while (0)
+    if (p.allFrames)
+    {
+        // the one-frame chain: the 64-segment instance grows every frame of the call itself (and signals the host, see the kernel)
+        if (cyl)
+            CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));
+        else
+            CAPE_LAUNCH_TRY((launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream)));
+        return hipSuccess;
+    }
     // counters of the two hand-over lists ([0] = count, [1..] = frames)
     if (p.redoList && !p.countersCleared)
         CAPE_LAUNCH_TRY(hipMemsetAsync(p.redoList, 0, sizeof(uint32_t), stream));

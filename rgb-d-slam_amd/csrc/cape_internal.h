@@ -123,6 +123,12 @@ struct StageBParams
     int a2RowsPerTile;       // cell rows per workgroup of stage A2: the vertical edges into rows k * a2RowsPerTile are evaluated here
     uint16_t* seed_sequence; // [frames][cells] seed cells in the order the seed loop tried them (first n_seeds entries valid)
     int ldsLimitBytes;       // host side only: LDS one workgroup may ask for on the handle's device (queried at cape_create)
+    // the one-frame chain (handles of max_batch <= 8, results in pinned host memory): ONE grow kernel -- the 64-segment instance on
+    // every frame of the call (allFrames) -- whose last wave stores the call's sequence number into the pinned word the host spins on
+    int allFrames;
+    uint32_t* doneFlag;      // pinned, device-mapped ; nullptr: nobody to signal
+    uint32_t* doneCounter;   // device: waves of the signalling kernel that are through
+    uint32_t doneSeq;
 };
 
 // N3: Depth_Map_Transformation::rectify_depth

@@ -80,9 +80,12 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
 
 @pytest.fixture(params=["strips", "bands"])
 def stage_a(request, monkeypatch):
-    """One-frame handles (max_batch <= 8) run stage A as ONE launch of strip workgroups (cape_cell_strip_kernel: the strip's
-    workgroup sums, scans and fits its cells, the frame's last workgroup evaluates the cell edges); CAPE_STAGE_A=bands keeps
-    the two throughput kernels on such a handle.  The edge-case tests run on both instances (the knob is read at cape_create)."""
+    """One-frame handles (max_batch <= 8) run the ONE-FRAME CHAIN: stage A as one launch of strip workgroups
+    (cape_cell_strip_kernel: the strip's workgroup sums, scans and fits its cells, the frame's last workgroup evaluates the
+    cell edges) and ONE grow kernel, the 64-segment instance on every frame, whose last wave signals the host.
+    CAPE_STAGE_A=bands keeps the classic chain on such a handle: the two streaming kernels of stage A, the 32-segment grow
+    kernel, the redo pass for frames with more segments and the one-thread signal kernel.  The edge-case tests run on both
+    (the knob is read at cape_create)."""
     monkeypatch.setenv("CAPE_STAGE_A", request.param)
     return request.param
 
@@ -344,7 +347,7 @@ def test_cylinder_ordered_sum_fallback():
     assert " passed" in out.stdout and "failed" not in out.stdout
 
 
-def test_cylinders_noisy_and_1280(oracle_mod):
+def test_cylinders_noisy_and_1280(oracle_mod, stage_a):
     """Harder RANSAC inputs: bumpy tunnel (several sub-segments / plane-vs-cylinder model selection) and 1280x960."""
     from cape_amd import Extractor, synth
 
@@ -448,7 +451,7 @@ FACET_CASES = [(11, 33, True), (22, 66, True), (0, 0, True), (13, 39, True), (4,
                (31, 93, False), (34, 102, True)]
 
 
-def test_faceted_scenes_batch(oracle_mod):
+def test_faceted_scenes_batch(oracle_mod, stage_a):
     """Faceted surfaces + foreground slabs: 5-9 regions per frame, failed seeds, cylinder branch, and (seeds 11, 22)
     plane segments that merge_planes() fuses -- the one path the room / tunnel scenes never reach."""
     from cape_amd import Extractor, synth
@@ -793,7 +796,7 @@ def test_sub_batch_pipeline_matches_single_chain(oracle_mod, cyl):
         ex.close()
 
 
-def test_more_than_32_plane_segments(oracle_mod):
+def test_more_than_32_plane_segments(oracle_mod, stage_a):
     """The everyday kernels keep 32 plane segments in LDS; a frame that needs more is redone by the 64-segment
     instance.  This 1280x960 room frame (depth scaled x2.13: noisy far walls, dozens of cylinder-branch regions whose
     inliers fit planes better) yields 34 segments in the reference algorithm; it sits between ordinary frames."""
