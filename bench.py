@@ -673,6 +673,8 @@ def main():
         # The headline workload once more on TWO handles, each on a stream of its own, fed alternately (outside the timed region of
         # `value`, which stays one handle, one stream): the per-cell fits and the one-wave-per-frame grow kernel of one batch issue
         # under the streaming kernel of the next.  What a caller with a continuous stream of batches gets for twice the scratch memory.
+        # (ONE pair of streams for every overlapped leg of this run: the runtime maps streams onto a few hardware queues in
+        #  creation order, and two streams that land on the same queue do not overlap at all)
         streams0 = [torch.cuda.Stream(device=local_rank) for _ in range(2)]
         pair0 = [Extractor(W, H, cylinders=False, device=local_rank, max_batch=B_max, **intr) for _ in range(2)]
         k0 = max(10, min(args.steps, 40))
@@ -806,7 +808,7 @@ def main():
         # The same three calls per batch on TWO handles, each on a stream of its own, fed alternately: the polygon task kernel
         # and the cylinder second pass wait most of their cycles (dependent chains), the streaming kernels of the other handle's
         # batch issue under them.  Same frames, same results (both handles checked), twice the scratch memory.
-        streams2 = [torch.cuda.Stream(device=local_rank) for _ in range(2)]
+        streams2 = streams0
         pair = [Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, **intr) for _ in range(2)]
 
         def full_step_on(i):

@@ -480,7 +480,13 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
 /* Handles created with max_batch <= 8 (the reference's call pattern: one frame per call) keep records, label grids and
  * boundary points in pinned, device-mapped HOST memory: the kernels write them over PCIe directly and no device-to-host
  * copy exists on the latency path.  cape_host_results waits for the handle's stream and returns pointers to that memory
- * (valid until the next call / destroy); CAPE_ERR_UNSUPPORTED for larger handles, whose results live in HBM. */
+ * (valid until the next call / destroy); CAPE_ERR_UNSUPPORTED for larger handles, whose results live in HBM.
+ * Such a handle also runs the ONE-FRAME CHAIN: stage A as one launch of strip workgroups whenever the frame is in
+ * device memory (a device pointer, or the staged copy of a pageable host frame; a frame read in place from pinned memory keeps the
+ * two streaming kernels), then ONE grow kernel whose last wave stores the completion number cape_host_results spins on -- two or
+ * three launches per call instead of five.  Same results bit for bit; the debug knob CAPE_STAGE_A=bands (read and validated at
+ * cape_create, like CAPE_RESUME / CAPE_SCHEDULE) keeps the batch kernels on such a handle, CAPE_STAGE_A=strips forces the strip
+ * kernel for pinned input too. */
 int cape_host_results(cape_handle h, const cape_frame_record** records, const int32_t** plane_labels,
                       const int32_t** cyl_labels, const double** boundary);
 
