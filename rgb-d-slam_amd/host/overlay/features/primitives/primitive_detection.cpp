@@ -1,6 +1,5 @@
 #include "primitive_detection.hpp"
 
-#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -278,10 +277,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         if (!_polygonPool)
         {
             const unsigned hw = std::thread::hardware_concurrency();
-            unsigned workers = hw > 4 ? 3u : hw - 1u;
-            if (const char* e = std::getenv("CAPE_POLYGON_WORKERS")) // experiments: how many sleeping workers pay off
-                workers = static_cast<unsigned>(std::max(1, std::atoi(e)));
-            _polygonPool = std::make_unique<PolygonPool>(workers);
+            _polygonPool = std::make_unique<PolygonPool>(hw > 4 ? 3u : hw - 1u);
         }
         _polygonPool->run(static_cast<int>(hostPolygons.size()), build_host_polygon);
     }
