@@ -888,3 +888,45 @@ def test_stage_a_instances_agree_on_pinned_and_device_input(oracle_mod, monkeypa
                 compare_frame(want[k], ex, ex.results(1), 0)
         ex.host_free(pinned)
         ex.close()
+
+
+def test_one_frame_chain_many_calls_in_a_row(monkeypatch):
+    """The one-frame chain hands work between workgroups inside a launch (a strip's planes -> the frame's last workgroup, across
+    the XCDs' L2 caches: release fence + counter + acquire fence) and signals the host from the grow kernel's last wave.  2 000
+    calls in a row on one handle, alternating frames of different scenes and one- and three-frame calls: every call's label
+    grids, seed counts and segment records equal the classic chain's (CAPE_STAGE_A=bands) for the same frame, bit for bit."""
+    from cape_amd import Extractor, synth
+
+    intr = _intr("room")
+    frames = np.stack([synth.room(seed=2, frame=5), synth.tumlike(seed=1, frame=3), synth.tunnel(seed=0, frame=2), synth.facets(seed=4, frame=0),
+                       synth.room(seed=7, frame=40)])
+    frames[3, 100:180, 300:420] = 0.0
+    monkeypatch.setenv("CAPE_STAGE_A", "bands")
+    ref = Extractor(640, 480, cylinders=True, max_batch=8, **intr)
+    n = ref.extract_host(frames)
+    want = ref.results(n)
+    want_labels = want.plane_labels.copy()
+    want_cyl = want.cyl_labels.copy()
+    want_rec = want.records.copy()
+    ref.close()
+    monkeypatch.delenv("CAPE_STAGE_A")
+    ex = Extractor(640, 480, cylinders=True, max_batch=3, **intr)
+
+    def same(res, f, k):
+        assert np.array_equal(res.plane_labels[f], want_labels[k]) and np.array_equal(res.cyl_labels[f], want_cyl[k])
+        assert res.records["header"][f].tobytes() == want_rec["header"][k].tobytes()
+        ns = int(want_rec["header"][k]["n_plane_segments"])
+        assert res.records["segments"][f][:ns].tobytes() == want_rec["segments"][k][:ns].tobytes()
+
+    for call in range(2000):
+        k = (call * 3 + call // 7) % 5
+        if call % 5 == 4:
+            ks = [k, (k + 1) % 5, (k + 3) % 5]
+            n = ex.extract_host(frames[ks])
+            res = ex.results(n, with_boundary=False)
+            for f, kk in enumerate(ks):
+                same(res, f, kk)
+        else:
+            n = ex.extract_host(frames[k])
+            same(ex.results(n, with_boundary=False), 0, k)
+    ex.close()
