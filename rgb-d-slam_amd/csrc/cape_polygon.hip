@@ -1037,7 +1037,7 @@ constexpr int kParkRungs = 6;       // rungs 2 .. 7 park; rung 0 never waits for
 #define CAPE_POLY_MID 100
 #endif
 #ifndef CAPE_POLY_ALL
-#define CAPE_POLY_ALL 130
+#define CAPE_POLY_ALL 256 // (= never: with the chains prioritised the seven-at-once start of the biggest planes only costs throughput)
 #endif
 constexpr int kPolyMidPoints = CAPE_POLY_MID; // from here on the six remaining rungs start together
 constexpr int kPolyAllPoints = CAPE_POLY_ALL; // from here on all seven rungs start together
@@ -1204,6 +1204,25 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
         } busyScope {tl, busy0, lane};
 #endif
         const int rung = (int)(task & 7u);
+#ifndef CAPE_POLY_PRIO
+#define CAPE_POLY_PRIO 1
+#endif
+        // A spawned rung sits on its plane's critical CHAIN of walks (the pass used to end with the last of a few three-walk chains:
+        // rung 0 all around a 100-point outline at ~3.6 us per step on a full SIMD, then k = 5 .. 11, then 13 .. 21), a plane of the
+        // batch does not: the chains get the SIMD's issue slots first (s_setprio).  k = 5 wins 85 % of the climbs, so it goes first,
+        // k = 7 next; the higher rungs run behind them and give up as soon as a lower one has its hull.  Room stream 1.43 -> 1.17 ms
+        // per 4 096 frames, TUM-like 1.00 -> 0.89 (with the all-seven-at-once start dropped: profiles/r04_polygon_tasks.txt).
+        if (CAPE_POLY_PRIO)
+        {
+            if (isStatic)
+                __builtin_amdgcn_s_setprio(0);
+            else if (rung <= 2)
+                __builtin_amdgcn_s_setprio(3);
+            else if (rung == 3)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(1);
+        }
         const PlaneCtx c = plane_context(p, (int)(task >> 11), (int)((task >> 3) & 255u));
 #ifdef CAPE_POLY_PROFILE
         const int frame = c.frame;
