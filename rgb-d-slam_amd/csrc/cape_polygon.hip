@@ -314,10 +314,14 @@ __device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int 
 #else
 #define CAPE_WALK_ATTR inline
 #endif
-template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
-                                                        int myRung = 0)
+// SLOTS: points a lane owns (i = lane + 64 j, j < SLOTS).  EXACT: the caller guarantees 64 (SLOTS - 1) < n <= 64 SLOTS, so no
+// pass asks whether a slot exists -- the task kernel picks the instance by the plane's size (a median plane has 74 candidates:
+// two slots, not four with two of them switched off by uniform masks in every loop of every step).
+template <int CAP, int SLOTS, bool EXACT>
+__device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr,
+                                              int myRung = 0)
 {
-    constexpr int kPolyPerLane = CAP / 64; // points a lane owns in the lane-parallel passes
+    constexpr int kPolyPerLane = SLOTS; // points a lane owns in the lane-parallel passes
     const double2* pts = L.pts;
     if (n < 3)
     {
@@ -346,7 +350,7 @@ template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& 
         for (int j = 0; j < (kInRegs ? kPolyPerLane : 1); ++j)
         {
             const int i = lane + 64 * j;
-            myPts[j] = (64 * j < n && i < n) ? pts[i] : make_double2(0.0, 0.0);
+            myPts[j] = ((EXACT || 64 * j < n) && i < n) ? pts[i] : make_double2(0.0, 0.0);
         }
     }
     auto my_point = [&](int j) { return kInRegs ? myPts[kInRegs ? j : 0] : pts[lane + 64 * j]; };
@@ -401,13 +405,15 @@ template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& 
         {
             const int i = lane + 64 * j;
             key[j] = ~0ull;
-            if (64 * j >= n)
+            if (!EXACT && 64 * j >= n)
                 continue; // (uniform: a plane of 150 points uses three of the sixteen slots)
-            if (i < n && !((myUsed >> j) & 1u))
             {
+                // (no branch around the arithmetic: a select at the end -- the exec-mask bookkeeping of four predicated blocks cost
+                //  more than the five f64 instructions they guarded)
                 const double2 q = my_point(j);
                 const double dx = cur.x - q.x, dy = cur.y - q.y;
-                key[j] = ((unsigned long long)__double_as_longlong(dx * dx + dy * dy) & ~1023ull) | (unsigned long long)i;
+                const unsigned long long kq = ((unsigned long long)__double_as_longlong(dx * dx + dy * dy) & ~1023ull) | (unsigned long long)i;
+                key[j] = (i < n && !((myUsed >> j) & 1u)) ? kq : ~0ull;
             }
         }
         const int cnt = n - usedCount;
@@ -426,7 +432,7 @@ template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& 
             unsigned long long head = ~0ull, second = ~0ull;
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
-                if (64 * j < n)
+                if (EXACT || 64 * j < n)
                 {
                     const unsigned long long kj = key[j];
                     if (kj < head)
@@ -459,13 +465,13 @@ template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& 
             unsigned long long best = ~0ull;
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
-                if (64 * j < n && key[j] < best)
+                if ((EXACT || 64 * j < n) && key[j] < best)
                     best = key[j];
-            const unsigned long long m = wave_min_u64(best);
+            const unsigned long long m = wave_min_u64_lead(best);
             const int idx = (int)(m & 1023ull);
 #pragma unroll
             for (int j = 0; j < kPolyPerLane; ++j)
-                if (64 * j < n && key[j] == m)
+                if ((EXACT || 64 * j < n) && key[j] == m)
                     key[j] = ~0ull; // taken (keys are unique: they carry the index)
             const double2 q = point_of(idx);
             if (lane == c)
@@ -544,13 +550,32 @@ template <int CAP> __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& 
     for (int j = 0; j < kPolyPerLane; ++j)
     {
         const int i = lane + 64 * j;
-        if (64 * j < n && i < n && !((myUsed >> j) & 1u) && i != first && !point_in_hull(my_point(j), pts, L.hull, hs))
+        if ((EXACT || 64 * j < n) && i < n && !((myUsed >> j) & 1u) && i != first && !point_in_hull(my_point(j), pts, L.hull, hs))
             outside = true;
     }
     if (__any(outside))
         return false;
     hsOut = hs;
     return true;
+}
+
+// the instance of the walk for a plane of n candidates (n uniform)
+template <int CAP>
+__device__ __forceinline__ bool concave_hull(const PolyLds& L, int n, int first, int k, int lane, int& hsOut, const uint32_t* planeState = nullptr, int myRung = 0)
+{
+    if constexpr (CAP == kPolySmallPoints && kPolySmallPoints == 256)
+    {
+        const int slots = __builtin_amdgcn_readfirstlane((n + 63) >> 6);
+        if (slots <= 1)
+            return concave_hull_k<CAP, 1, true>(L, n, first, k, lane, hsOut, planeState, myRung);
+        if (slots == 2)
+            return concave_hull_k<CAP, 2, true>(L, n, first, k, lane, hsOut, planeState, myRung);
+        if (slots == 3)
+            return concave_hull_k<CAP, 3, true>(L, n, first, k, lane, hsOut, planeState, myRung);
+        return concave_hull_k<CAP, 4, true>(L, n, first, k, lane, hsOut, planeState, myRung);
+    }
+    else
+        return concave_hull_k<CAP, CAP / 64, false>(L, n, first, k, lane, hsOut, planeState, myRung);
 }
 
 // host: find_min_y_point = FindMinYPoint of concave_fitting.cpp:231-243: std::min_element under (y ascending, x DESCENDING) with
@@ -1009,7 +1034,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, 4) void cape_polygon_large
                 break; // the next k exceeds the point count (concave_fitting.cpp:86-87)
             if (a == 1)
                 continue; // (the second rung repeats the first: a run is a pure function of the points and k)
-            haveRing = concave_hull_k<CAP>(L, n, first, k, lane, hs);
+            haveRing = concave_hull<CAP>(L, n, first, k, lane, hs);
         }
         finish_polygon<CAP>(p, c, L, haveRing, hs, lane);
     }
@@ -1291,7 +1316,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
             int hs = 0;
             CAPE_PCOUNT(8, 1); // hull attempts
             // (rung 0 cannot be overruled, so it never looks at the state word while it walks)
-            const bool ok = concave_hull_k<CAP>(L, n, first, kLadderK[r], lane, hs, r > 0 ? state : nullptr, r);
+            const bool ok = concave_hull<CAP>(L, n, first, kLadderK[r], lane, hs, r > 0 ? state : nullptr, r);
             CAPE_PTICK(1); // hull walks (incl. the all-points-inside check)
             uint32_t old = 0;
             if (lane == 0)

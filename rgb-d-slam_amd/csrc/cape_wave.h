@@ -89,6 +89,22 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ((unsigned long long)mh << 32) | ml;
 }
 
+// the same minimum for keys that nearly always differ in their high words (a squared distance's leading bits): when exactly one
+// lane holds the smallest high word -- one ballot tells -- its low word is taken out with one v_readlane instead of a second
+// reduction; ties take the second reduction.  Same result as wave_min_u64 for every input.
+__device__ __forceinline__ unsigned long long wave_min_u64_lead(unsigned long long v)
+{
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned long long tie = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(tie) == 1)
+        ml = readlane_u32(lo, __ffsll((long long)tie) - 1);
+    else
+        ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
 // ---- the 64 lanes' keys in ascending order, lane i <- the i-th smallest: a bitonic network of 21 compare-exchange steps.
 // The partner lane ^ STRIDE comes through DPP (strides 1, 2), ds_swizzle (4, 8, 16: within each half) or ds_bpermute (32).
 template <int STRIDE> __device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane)
