@@ -1,0 +1,283 @@
+// Stage A -- fused back-projection + per-cell PCA for gfx950, as two kernels:
+//
+//   A1 cape_cell_moments_kernel : the HBM/FP64-issue bound streaming pass.  Reads the row-major depth image once,
+//      back-projects on the fly and leaves, per cell, the nine moment sums + count, the result of the continuity
+//      cross scan and the exactness verdict.  Replaces Depth_Map_Transformation::get_organized_cloud_array
+//      (reference src/features/primitives/depth_map_transformation.cpp:89-142) and the scan + accumulation part of
+//      Plane_Segment::init_plane_segment (plane_segment.cpp:44-152).  The 3.7 MB organised cloud is never built.
+//   A2 cape_cell_plane_kernel   : one lane per cell, every lane busy: validity gates, Plane_Segment::fit_plane
+//      (plane_segment.cpp:155-168, 205-284), the merge tolerance of init_planar_cell_fitting
+//      (primitive_detection.cpp:201-220) and the histogram bin of init_histogram (primitive_detection.cpp:253-254 +
+//      histogram.hpp:48-54).  Splitting it off keeps the long dependent f64 chains (eigen-solver, div, sqrt) out of
+//      the streaming workgroups, whose LDS and wave slots are then released as soon as the band is summed.
+//
+// A1 mapping: one 320-thread workgroup = two "bands" (band = 20 image rows x 640 pixels = 32 cells).  Thread t owns
+// float4 column q = t % 160 of band t / 160 and walks the band's 20 rows, so every wave-level load is a contiguous
+// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded five
+// at a time, one group ahead of the arithmetic.  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
+// The sums are exact in f64 for ANY summation order when the addends' exponent span is < 21 bits;
+// a per-cell z-range guard decides whether that holds, otherwise A2 redoes the cell in the reference's pixel order.
+//
+// This file holds A1 only and is compiled with -fno-slp-vectorize (Makefile): left to itself the SLP vectoriser pairs the six
+// f32 products of a pixel into v_pk_mul_f32, which costs as much as the two v_mul_f32_e32 it replaces on gfx950
+// (profiles/r02_valu_rates.txt: 4.5 against 2 x 2.3 cycles) PLUS the v_mov_b32 / v_pk_mov_b32 that build its register pairs
+// (36 moves per 16 pixels; 94 -> 84 VGPRs without them).  A2 and the strip kernel (cape_cell_fit.hip) keep the vectoriser:
+// A2 measured 2 % slower without it.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "cape_cell_acc.h"
+
+namespace cape {
+
+template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
+{
+    // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
+    __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
+    __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
+    __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
+    __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
+
+    const int t = threadIdx.x;
+    const int frame = blockIdx.x / p.pairsPerFrame;
+    const int pair = blockIdx.x - frame * p.pairsPerFrame;
+    const size_t frameOff = (size_t)frame * p.W * p.H;
+
+    const int bsel = t / kBandThreads;
+    const int q = t - bsel * kBandThreads;
+    const int band = pair * 2 + bsel;
+    const int cellRow = band / p.segsPerRow;
+    const int seg = band - cellRow * p.segsPerRow;
+    const int col0 = seg * 640 + q * 4;
+    const bool active = (band < p.bandsPerFrame) && (col0 < p.W);
+    const int cseg = q / 5;          // cell within the band segment
+    const int j = q - cseg * 5;      // float4 within the cell row
+    const int lcell = bsel * 32 + cseg;
+
+    // ------------------------------------------------------------------ streaming accumulation
+    PxAcc A;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        A.S[k] = 0.0;
+    A.n = 0;
+    A.zminBits1 = 0xFFFFFFFFu;
+    A.zmaxBits = 0u;
+    if (active)
+    {
+        const double a0 = p.acol[col0], a1 = p.acol[col0 + 1], a2 = p.acol[col0 + 2], a3 = p.acol[col0 + 3];
+        // addresses = one base per FRAME (uniform: it lives in scalar registers and advances row by row with scalar adds)
+        // + one 32-bit element offset per thread (its column inside the frame): no 64-bit vector address arithmetic per load
+        const uint32_t pixOff32 = (uint32_t)(cellRow * kCell) * (uint32_t)p.W + (uint32_t)col0;
+        const float* frameBase = p.depth + frameOff;                 // float32 millimetres
+        const uint16_t* frameBase16 = p.depth_u16 + frameOff;        // raw sensor units (U16 variant)
+        const float scale16 = p.u16_scale;
+        const double* brow = p.brow + cellRow * kCell;
+        const size_t W = (size_t)p.W;
+
+        // rows in groups of kGroup, ping-pong buffered: the loads of group g+1 are in flight while group g is summed
+        constexpr int kGroup = CAPE_A_GROUP, kGroups = kCell / kGroup;
+        static_assert(kCell % kGroup == 0 && kGroups % 2 == 0, "the ping-pong loop consumes two groups per trip");
+        // the buffers hold what was LOADED (float4, or the raw ushort4 of the U16 variant): converting at load time would
+        // make every load wait for its data on the spot and serialise the prefetch with the arithmetic
+        using Raw = typename std::conditional<U16, ushort4, float4>::type;
+        Raw bufA[kGroup], bufB[kGroup];
+        auto load_group = [&](Raw (&buf)[kGroup], int g) {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+            {
+                const size_t rowOff = (size_t)(kGroup * g + i) * W; // uniform
+                if constexpr (U16)
+                    buf[i] = *reinterpret_cast<const ushort4*>((frameBase16 + rowOff) + pixOff32);
+                else
+                    buf[i] = *reinterpret_cast<const float4*>((frameBase + rowOff) + pixOff32);
+            }
+        };
+        auto to_f4 = [&](const Raw& rw) {
+            if constexpr (U16)
+            {
+                // N4: the PNG payload of the TUM / CAPE datasets, converted exactly like
+                // cv::Mat::convertTo(CV_32F, scale) does (examples/main_TUM.cpp:242): float(raw) * float(scale)
+                // one v_mul_f32 each, spelled out: left to itself the SLP vectoriser pairs them into v_pk_mul_f32, which
+                // costs two issue slots on gfx950's 32-wide SIMDs plus the moves that build the register pairs
+                // (measured: 2.00 ms per 4 096 frames packed, 1.54 ms scalar)
+                auto mul1 = [](float a, float b) {
+                    float r;
+                    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+                    return r;
+                };
+                return make_float4(mul1((float)rw.x, scale16), mul1((float)rw.y, scale16), mul1((float)rw.z, scale16),
+                                   mul1((float)rw.w, scale16));
+            }
+            else
+            {
+                return rw;
+            }
+        };
+        auto sum_group = [&](const Raw (&rawbuf)[kGroup], int g) {
+            float4 buf[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+                buf[i] = to_f4(rawbuf[i]);
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+            {
+                const int r = kGroup * g + i;
+                acc_f4(buf[i], a0, a1, a2, a3, brow[r], A);
+                // samples for the continuity cross scan and the tolerance corners
+                if (r == kCell / 2)
+                    *reinterpret_cast<float4*>(&s_row[lcell * kCell + 4 * j]) = buf[i];
+                if (j == 2)
+                    s_col[lcell * kCell + r] = buf[i].z; // pixel column 10 of the cell
+                if (r == 0 && j == 0)
+                    s_corner[lcell * 3] = buf[i].x;
+                if (r == kCell - 1 && j == 4)
+                    s_corner[lcell * 3 + 1] = buf[i].w;
+                if (r == kCell / 2 && j == 2)
+                    s_corner[lcell * 3 + 2] = buf[i].z;
+            }
+        };
+        load_group(bufA, 0);
+#if CAPE_A_PEEL
+        // the last trip is peeled: with the `if (g + 2 < kGroups)` inside, the loop carried both buffers through copies
+        // (eight v_mov_b64 per trip)
+#pragma unroll 1
+        for (int g = 0; g < kGroups - 2; g += 2)
+        {
+            load_group(bufB, g + 1);
+            sum_group(bufA, g);
+            load_group(bufA, g + 2);
+            sum_group(bufB, g + 1);
+        }
+        load_group(bufB, kGroups - 1);
+        sum_group(bufA, kGroups - 2);
+        sum_group(bufB, kGroups - 1);
+#else
+#pragma unroll 1
+        for (int g = 0; g < kGroups; g += 2)
+        {
+            load_group(bufB, g + 1);
+            sum_group(bufA, g);
+            if (g + 2 < kGroups)
+                load_group(bufA, g + 2);
+            sum_group(bufB, g + 1);
+        }
+#endif
+    }
+    {
+        double* dst = s_part + t * kPartStride;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            dst[k] = A.S[k];
+        dst[9] = (double)A.n;
+        reinterpret_cast<uint2*>(dst + 10)[0] = make_uint2(A.zminBits1, A.zmaxBits);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 5 partials -> one cell (exact, any order)
+    // 64 cells x 10 quantities = 640 tasks over 320 threads; results go straight to HBM (AoS [cell][10])
+#pragma unroll
+    for (int e = t; e < 640; e += kThreadsA)
+    {
+        const int cell = e / 10;
+        const int m = e - cell * 10;
+        const int cb = cell >> 5, cs = cell & 31;
+        const int bnd = pair * 2 + cb;
+        const int cr = bnd / p.segsPerRow;
+        const int sg = bnd - cr * p.segsPerRow;
+        const int cc = sg * 32 + cs;
+        if (bnd < p.bandsPerFrame && cc < p.hCells)
+        {
+            const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
+            double acc = src[0];
+            acc += src[kPartStride];
+            acc += src[2 * kPartStride];
+            acc += src[3 * kPartStride];
+            acc += src[4 * kPartStride];
+            p.cell_sums[((size_t)frame * p.cells + cr * p.hCells + cc) * kSumStride + m] = acc;
+        }
+    }
+
+    // ------------------------------------------------------------------ per-cell scans: wave 0, one lane per cell
+    // (Round 3 spread the 37 steps of a cell's cross scan over all five waves as independent tests -- a step only needs the
+    // latest valid depth before it -- to release the workgroup's LDS earlier.  Bit-exact, and slower: 1.68 ms against 1.46 ms
+    // per 4 096 frames.  One lane per cell runs a step in ~12 instructions for 64 cells at once; one lane per TEST pays the
+    // index arithmetic, the look-back loop and its branches per test, ~5x the wave-instructions, and this kernel is bound by
+    // VALU issue, not by the LDS it holds.  A persistent form -- 1 024 .. 4 096 workgroups looping over the band pairs, to save
+    // the gaps between a workgroup's end and its successor's start -- was slower still: 2.1-2.6 ms; the loop costs 38 VGPRs and
+    // with them the fifth wave per SIMD.)
+    if (t >= 64)
+        return;
+    const int fb = t >> 5, fs = t & 31;
+    const int fband = pair * 2 + fb;
+    if (fband >= p.bandsPerFrame)
+        return;
+    const int fRow = fband / p.segsPerRow;
+    const int fSeg = fband - fRow * p.segsPerRow;
+    const int fCol = fSeg * 32 + fs;
+    if (fCol >= p.hCells)
+        return;
+
+    bool continuous = true;
+    // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219
+    {
+        const float* zr = &s_row[t * kCell];
+        float last = std_maxf(zr[0], zr[1]);
+        if (last <= 0)
+            continuous = false;
+#pragma unroll
+        for (int i = 1; i < kCell; ++i)
+            continuous = continuous && is_continuous(zr[i], last);
+    }
+    // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
+    {
+        const float* zc = &s_col[t * kCell];
+        float last = std_maxf(zc[0], zc[1]);
+        if (last <= 0)
+            continuous = false;
+#pragma unroll
+        for (int i = 1; i < kCell - 1; ++i)
+            continuous = continuous && is_continuous(zc[i], last);
+    }
+    // exactness guard: all addends of every sum within 2^20 of each other (see header)
+    uint32_t zminBits1 = 0xFFFFFFFFu, zmaxBits = 0u;
+    uint32_t n = 0;
+    {
+        const int pbase = fb * kBandThreads + fs * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+        {
+            const uint2 zr = reinterpret_cast<const uint2*>(s_part + (pbase + k) * kPartStride + 10)[0];
+            zminBits1 = min(zminBits1, zr.x);
+            zmaxBits = max(zmaxBits, zr.y);
+            n += (uint32_t)s_part[(pbase + k) * kPartStride + 9];
+        }
+    }
+    // back to depths: with n > 0 at least one pixel was valid, so the minimum is a real pattern - 1
+    const float zmin = __uint_as_float(zminBits1 + 1u), zmax = __uint_as_float(zmaxBits);
+    const float rab = fmaxf(p.ratio_col[fCol], p.ratio_row[fRow]);
+    // all pixels +0 or positive and finite (acc_px_fast's precondition), and their range within the exactness bound
+    const bool exact_ok = zmaxBits <= 0x7F7FFFFFu && ((n == 0) || (zmax * rab <= 512.0f * zmin));
+
+    const size_t gcell = (size_t)frame * p.cells + fRow * p.hCells + fCol;
+    CellAux aux;
+    aux.z0 = s_corner[t * 3];
+    aux.z399 = s_corner[t * 3 + 1];
+    aux.flags = (n & kCountMask) | (continuous ? kAuxContinuous : 0u) | (exact_ok ? kAuxExact : 0u);
+    aux.zc = s_corner[t * 3 + 2];
+    p.cell_aux[gcell] = aux;
+}
+
+// every launch helper reports its own failure: hipGetLastError() right behind the launch (a later runtime call would
+// overwrite the sticky-free error state on ROCm < 7)
+hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t stream)
+{
+    const int grid = nFrames * p.pairsPerFrame;
+    if (p.depth)
+        hipLaunchKernelGGL(cape_cell_moments_kernel<false>, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    else
+        hipLaunchKernelGGL(cape_cell_moments_kernel<true>, dim3(grid), dim3(kThreadsA), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace cape
