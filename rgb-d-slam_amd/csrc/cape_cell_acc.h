@@ -20,10 +20,6 @@ namespace cape {
 #define CAPE_A_WAVES 4   // __launch_bounds__ waves per SIMD of the streaming kernel (measured: 4 -> 1.46 ms, 5 -> 1.49 ms, 3 -> 2.6 ms)
 #endif
 
-#ifndef CAPE_A_PEEL
-#define CAPE_A_PEEL 1
-#endif
-
 constexpr int kThreadsA = 320;
 constexpr int kBandThreads = 160;
 [[maybe_unused]] constexpr int kPartStride = 11; // 10 f64 per thread, padded against LDS bank conflicts
@@ -69,23 +65,9 @@ __device__ __forceinline__ float acc_px(float zr, double a, double b, PxAcc& A)
 // and redone by A2 with acc_px in the reference's order.  What is left to count is the non-zero pixels: v_min_u32 + v_add_u32.
 // The count can only be too HIGH in a cell the guard rejects, never too low, so A2's "enough points for the in-order
 // pass?" test errs on the side of redoing the cell.  Returns the bit pattern for the guard.
-// The six f32 products are spelled as single v_mul_f32_e32: left to itself the SLP vectoriser pairs them into v_pk_mul_f32,
-// which costs as much as the two e32 forms it replaces on gfx950 (profiles/r02_valu_rates.txt: 4.5 against 2 x 2.3 cycles) PLUS
-// the v_mov_b32 / v_pk_mov_b32 that build its register pairs (36 moves per 16 pixels in the round-4 binary).
-#ifndef CAPE_A_MUL_ASM
-#define CAPE_A_MUL_ASM 0   // measured: the asm form pins the schedule and spills (128 VGPRs + scratch); -fno-slp-vectorize (Makefile) does the job
-#endif
-__device__ __forceinline__ float mul_f32(float a, float b)
-{
-#if CAPE_A_MUL_ASM
-    float r;
-    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a * b;
-#endif
-}
-
+// (The six f32 products stay plain C: spelled as inline v_mul_f32_e32 they pin the schedule and the kernel spills -- 128 VGPRs +
+// scratch.  What keeps the SLP vectoriser from pairing them into v_pk_mul_f32 + register-pair moves is -fno-slp-vectorize on
+// cape_cell_moments.hip, see its header.)
 __device__ __forceinline__ uint32_t acc_px_fast(float z, double a, double b, PxAcc& A)
 {
     const uint32_t bits = __float_as_uint(z);
@@ -96,12 +78,12 @@ __device__ __forceinline__ uint32_t acc_px_fast(float z, double a, double b, PxA
     A.S[0] += (double)x;
     A.S[1] += (double)y;
     A.S[2] += zd;
-    A.S[3] += (double)mul_f32(x, x);
-    A.S[4] += (double)mul_f32(y, y);
-    A.S[5] += (double)mul_f32(z, z);
-    A.S[6] += (double)mul_f32(x, y);
-    A.S[7] += (double)mul_f32(y, z);
-    A.S[8] += (double)mul_f32(x, z);
+    A.S[3] += (double)(x * x);
+    A.S[4] += (double)(y * y);
+    A.S[5] += (double)(z * z);
+    A.S[6] += (double)(x * y);
+    A.S[7] += (double)(y * z);
+    A.S[8] += (double)(x * z);
     return bits;
 }
 
@@ -130,6 +112,17 @@ __device__ __forceinline__ bool is_continuous(float pixelDepth, float& last)
         return false;
     }
     return true;
+}
+
+// The same step as straight-line code for a scan that runs every step on every lane: once a step has failed the scan's verdict
+// is false whatever follows (the reference's `&&` stops calling the function there), so the later values of `last` are never
+// observed and nothing needs to branch.
+__device__ __forceinline__ bool is_continuous_flat(float pixelDepth, float& last)
+{
+    const bool positive = pixelDepth > 0; // NaN: not positive -> the step passes, like the reference's `if`
+    const bool close = (double)fabsf(pixelDepth - last) <= 4.0 * depth_quantization((double)pixelDepth);
+    last = (positive & close) ? pixelDepth : last;
+    return !positive | close;
 }
 
 } // namespace cape

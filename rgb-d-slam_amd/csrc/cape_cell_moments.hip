@@ -37,7 +37,8 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
-    __shared__ float s_corner[64 * 3];   // first, last and centre pixel of every cell
+    __shared__ float s_corner[64 * 2];   // first and last pixel of every cell (the centre pixel is s_row[.. + 10])
+    __shared__ float s_trash[kThreadsA + kCell]; // where the lanes that do not hold a cell's centre column send their row's store
 
     const int t = threadIdx.x;
     const int frame = blockIdx.x / p.pairsPerFrame;
@@ -114,7 +115,13 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
                 return rw;
             }
         };
-        auto sum_group = [&](const Raw (&rawbuf)[kGroup], int g) {
+        // samples for the continuity cross scan and the tolerance corners.  The centre column is one store per row by EVERY
+        // lane -- the lane that holds pixel column 10 of its cell (j == 2) into s_col, the others into a trash slot of their
+        // own: a predicated store costs the wave an exec-mask round trip per row.  First / last pixel of the cell come from
+        // the peeled first / last trip (compile-time rows), the centre row from the trip that holds row 10.
+        float* const colp = (j == 2) ? &s_col[lcell * kCell] : &s_trash[t];
+        auto sum_group = [&](const Raw (&rawbuf)[kGroup], int g, auto where) {
+            constexpr int kWhere = decltype(where)::value; // 0: first trip, 1: loop, 2: last trip
             float4 buf[kGroup];
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
@@ -124,45 +131,37 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             {
                 const int r = kGroup * g + i;
                 acc_f4(buf[i], a0, a1, a2, a3, brow[r], A);
-                // samples for the continuity cross scan and the tolerance corners
-                if (r == kCell / 2)
+                colp[r] = buf[i].z; // pixel column 10 of the cell (lanes j == 2)
+                if (kWhere == 1 && r == kCell / 2)
                     *reinterpret_cast<float4*>(&s_row[lcell * kCell + 4 * j]) = buf[i];
-                if (j == 2)
-                    s_col[lcell * kCell + r] = buf[i].z; // pixel column 10 of the cell
-                if (r == 0 && j == 0)
-                    s_corner[lcell * 3] = buf[i].x;
-                if (r == kCell - 1 && j == 4)
-                    s_corner[lcell * 3 + 1] = buf[i].w;
-                if (r == kCell / 2 && j == 2)
-                    s_corner[lcell * 3 + 2] = buf[i].z;
+                if (kWhere == 0 && i == 0 && g == 0 && j == 0)
+                    s_corner[lcell * 2] = buf[i].x;
+                if (kWhere == 2 && r == kCell - 1 && j == 4)
+                    s_corner[lcell * 2 + 1] = buf[i].w;
             }
         };
+        using First = std::integral_constant<int, 0>;
+        using Loop = std::integral_constant<int, 1>;
+        using Last = std::integral_constant<int, 2>;
+        static_assert(kGroups >= 6 && (kCell / 2) / kGroup >= 2 && (kCell / 2) / kGroup < kGroups - 2, "row 10 belongs to a trip of the loop");
         load_group(bufA, 0);
-#if CAPE_A_PEEL
-        // the last trip is peeled: with the `if (g + 2 < kGroups)` inside, the loop carried both buffers through copies
-        // (eight v_mov_b64 per trip)
+        // first and last trip peeled: compile-time rows for the corner samples, and no `if (g + 2 < kGroups)` inside the loop
+        // (with it the loop carried both buffers through copies, eight v_mov_b64 per trip)
+        load_group(bufB, 1);
+        sum_group(bufA, 0, First{});
+        load_group(bufA, 2);
+        sum_group(bufB, 1, First{});
 #pragma unroll 1
-        for (int g = 0; g < kGroups - 2; g += 2)
+        for (int g = 2; g < kGroups - 2; g += 2)
         {
             load_group(bufB, g + 1);
-            sum_group(bufA, g);
+            sum_group(bufA, g, Loop{});
             load_group(bufA, g + 2);
-            sum_group(bufB, g + 1);
+            sum_group(bufB, g + 1, Loop{});
         }
         load_group(bufB, kGroups - 1);
-        sum_group(bufA, kGroups - 2);
-        sum_group(bufB, kGroups - 1);
-#else
-#pragma unroll 1
-        for (int g = 0; g < kGroups; g += 2)
-        {
-            load_group(bufB, g + 1);
-            sum_group(bufA, g);
-            if (g + 2 < kGroups)
-                load_group(bufA, g + 2);
-            sum_group(bufB, g + 1);
-        }
-#endif
+        sum_group(bufA, kGroups - 2, Last{});
+        sum_group(bufB, kGroups - 1, Last{});
     }
     {
         double* dst = s_part + t * kPartStride;
@@ -198,47 +197,40 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
         }
     }
 
-    // ------------------------------------------------------------------ per-cell scans: wave 0, one lane per cell
-    // (Round 3 spread the 37 steps of a cell's cross scan over all five waves as independent tests -- a step only needs the
-    // latest valid depth before it -- to release the workgroup's LDS earlier.  Bit-exact, and slower: 1.68 ms against 1.46 ms
-    // per 4 096 frames.  One lane per cell runs a step in ~12 instructions for 64 cells at once; one lane per TEST pays the
-    // index arithmetic, the look-back loop and its branches per test, ~5x the wave-instructions, and this kernel is bound by
-    // VALU issue, not by the LDS it holds.  A persistent form -- 1 024 .. 4 096 workgroups looping over the band pairs, to save
-    // the gaps between a workgroup's end and its successor's start -- was slower still: 2.1-2.6 ms; the loop costs 38 VGPRs and
-    // with them the fifth wave per SIMD.)
-    if (t >= 64)
+    // ------------------------------------------------------------------ per-cell scans: waves 0 and 1, one band each
+    // Lanes 0..31 of a wave run the horizontal scan of the band's 32 cells, lanes 32..63 the vertical scan of the same cells, as
+    // straight-line steps (is_continuous_flat); the two verdicts meet through one cross-lane read.  (Through round 4 wave 0 ran
+    // both scans of all 64 cells one behind the other, 37 branching steps on a lone wave while the workgroup's LDS and wave
+    // slots were held: 5 % of the kernel by ablation, profiles/r04_a1_phases.txt.  Round 3's other extreme -- one lane per TEST
+    // on all five waves -- measured slower: ~5x the wave-instructions in a kernel bound by VALU issue.)
+    if (t >= 128)
         return;
-    const int fb = t >> 5, fs = t & 31;
+    const int fb = t >> 6;              // band of the pair = wave
+    const int fs = t & 31;              // cell of the band
+    const bool vertical = (t & 32) != 0;
+    const int c64 = fb * 32 + fs;       // cell of the workgroup (= lcell of the lanes that streamed it)
+    bool continuous;
+    {
+        // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219;
+        // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
+        const float* zs = (vertical ? s_col : s_row) + c64 * kCell;
+        float last = std_maxf(zs[0], zs[1]);
+        continuous = !(last <= 0);
+#pragma unroll
+        for (int i = 1; i < kCell - 1; ++i)
+            continuous &= is_continuous_flat(zs[i], last);
+        const bool lastStep = is_continuous_flat(zs[kCell - 1], last);
+        continuous &= vertical | lastStep;
+        continuous &= __shfl_xor((int)continuous, 32) != 0;
+    }
     const int fband = pair * 2 + fb;
-    if (fband >= p.bandsPerFrame)
+    if (vertical || fband >= p.bandsPerFrame)
         return;
     const int fRow = fband / p.segsPerRow;
     const int fSeg = fband - fRow * p.segsPerRow;
     const int fCol = fSeg * 32 + fs;
     if (fCol >= p.hCells)
         return;
-
-    bool continuous = true;
-    // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219
-    {
-        const float* zr = &s_row[t * kCell];
-        float last = std_maxf(zr[0], zr[1]);
-        if (last <= 0)
-            continuous = false;
-#pragma unroll
-        for (int i = 1; i < kCell; ++i)
-            continuous = continuous && is_continuous(zr[i], last);
-    }
-    // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
-    {
-        const float* zc = &s_col[t * kCell];
-        float last = std_maxf(zc[0], zc[1]);
-        if (last <= 0)
-            continuous = false;
-#pragma unroll
-        for (int i = 1; i < kCell - 1; ++i)
-            continuous = continuous && is_continuous(zc[i], last);
-    }
     // exactness guard: all addends of every sum within 2^20 of each other (see header)
     uint32_t zminBits1 = 0xFFFFFFFFu, zmaxBits = 0u;
     uint32_t n = 0;
@@ -261,10 +253,10 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
 
     const size_t gcell = (size_t)frame * p.cells + fRow * p.hCells + fCol;
     CellAux aux;
-    aux.z0 = s_corner[t * 3];
-    aux.z399 = s_corner[t * 3 + 1];
+    aux.z0 = s_corner[c64 * 2];
+    aux.z399 = s_corner[c64 * 2 + 1];
     aux.flags = (n & kCountMask) | (continuous ? kAuxContinuous : 0u) | (exact_ok ? kAuxExact : 0u);
-    aux.zc = s_corner[t * 3 + 2];
+    aux.zc = s_row[c64 * kCell + kCell / 2];
     p.cell_aux[gcell] = aux;
 }
 
