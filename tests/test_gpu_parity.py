@@ -78,6 +78,65 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert sorted(map(tuple, _bits(b_gpu).tolist())) == sorted(map(tuple, _bits(b_orc).tolist())), "boundary points"
 
 
+def _scan_boundary_frames():
+    """Depth jumps placed on single steps of the continuity cross scan (plane_segment.cpp:62-100): the horizontal scan walks local row 10,
+    idx 200..219, seeded with max(z[200], z[201]); the vertical one local column 10, idx 10, 30, .., 370 -- it stops BEFORE idx 390 --,
+    seeded with max(z[10], z[30]).  A jump on the last horizontal step breaks the cell, one on idx 390 must not; jumps / holes on the
+    seed pixels and on the step behind a hole exercise `last`."""
+    from cape_amd import synth
+
+    base = synth.room(seed=5, frame=4).astype(np.float32)
+    rng = np.random.default_rng(23)
+    frames = []
+    spots = {
+        "h_last": (10, 19), "v_ignored": (19, 10), "v_last": (18, 10), "h_seed0": (10, 0), "h_seed1": (10, 1),
+        "v_seed0": (0, 10), "v_seed1": (1, 10), "centre": (10, 10), "h_mid": (10, 7), "v_mid": (7, 10),
+    }
+    for kind in ("jump", "hole", "hole_then_jump"):
+        f = base.copy()
+        for ci, (name, (r, c)) in enumerate(spots.items()):
+            # a different block of cells for every spot, a few cells each
+            for k in range(6):
+                cy, cx = (2 * ci + k // 3) % 24, (3 * ci + 5 * k + ci // 4) % 32
+                y, x = cy * 20 + r, cx * 20 + c
+                if kind == "jump":
+                    f[y, x] = f[y, x] + 400.0 + 50.0 * rng.random()
+                elif kind == "hole":
+                    f[y, x] = 0.0
+                else:
+                    f[y, x] = 0.0
+                    yy, xx = (y + 1, x) if name.startswith("v") and r < 19 else (y, min(x + 1, cx * 20 + 19))
+                    f[yy, xx] = f[yy, xx] + 300.0
+        frames.append(f)
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_continuity_scan_boundary_steps(oracle_mod, batch, monkeypatch):
+    """Every step of both scans against the oracle, on the one-frame instances (strips / bands) and on the batch kernels."""
+    from cape_amd import Extractor
+
+    frames = _scan_boundary_frames()
+    intr = _intr("room")
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    refs = [orc.run(f) for f in frames]
+    # the spots really decide cells: the three frames do not give the same validity map
+    assert not np.array_equal(refs[0].planar, refs[1].planar) or not np.array_equal(refs[0].n, refs[1].n)
+    for mode in (("strips", "bands") if batch == 1 else ("bands",)):
+        monkeypatch.setenv("CAPE_STAGE_A", mode)
+        ex = Extractor(640, 480, cylinders=False, max_batch=(1 if batch == 1 else 16), **intr)
+        if batch == 1:
+            for i, f in enumerate(frames):
+                n = ex.extract_host(f)
+                compare_frame(refs[i], ex, ex.results(n), 0)
+        else:
+            n = ex.extract_host(frames)
+            res = ex.results(n)
+            for i in range(n):
+                compare_frame(refs[i], ex, res, i)
+        ex.close()
+
+
 @pytest.fixture(params=["strips", "bands"])
 def stage_a(request, monkeypatch):
     """One-frame handles (max_batch <= 8) run the ONE-FRAME CHAIN: stage A as one launch of strip workgroups
