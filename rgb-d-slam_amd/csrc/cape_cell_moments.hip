@@ -173,58 +173,86 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
     }
     __syncthreads();
 
-    // ------------------------------------------------------------------ 5 partials -> one cell (exact, any order)
-    // 64 cells x 10 quantities = 640 tasks over 320 threads; results go straight to HBM (AoS [cell][10])
-#pragma unroll
-    for (int e = t; e < 640; e += kThreadsA)
+    // ------------------------------------------------------------------ behind the barrier: wave 4 sums, waves 0..3 scan
+    // The workgroup's LDS and wave slots are held until its last wave leaves, so the work behind the last pixel is spread for
+    // LATENCY: the 5-partials sums on one wave beside the scans, the scans cut in four (below) -- profiles/r04_a1_phases.txt.
+    if (t >= 256)
     {
-        const int cell = e / 10;
-        const int m = e - cell * 10;
-        const int cb = cell >> 5, cs = cell & 31;
-        const int bnd = pair * 2 + cb;
-        const int cr = bnd / p.segsPerRow;
-        const int sg = bnd - cr * p.segsPerRow;
-        const int cc = sg * 32 + cs;
-        if (bnd < p.bandsPerFrame && cc < p.hCells)
+        // 5 partials -> one cell (exact, any order): 64 cells x 10 quantities = 640 tasks, ten per lane, consecutive lanes store
+        // consecutive doubles (AoS [cell][10])
+        const int l = t - 256;
+        size_t base[2];
+        int lim[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
         {
-            const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
-            double acc = src[0];
-            acc += src[kPartStride];
-            acc += src[2 * kPartStride];
-            acc += src[3 * kPartStride];
-            acc += src[4 * kPartStride];
-            p.cell_sums[((size_t)frame * p.cells + cr * p.hCells + cc) * kSumStride + m] = acc;
+            const int bnd = pair * 2 + cb;
+            const int cr = bnd / p.segsPerRow;
+            const int sg = bnd - cr * p.segsPerRow;
+            base[cb] = (size_t)frame * p.cells + cr * p.hCells + sg * 32;
+            lim[cb] = bnd < p.bandsPerFrame ? p.hCells - sg * 32 : 0; // cells of the band that exist
         }
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+        {
+            const int e = l + 64 * k;
+            const int cell = e / 10;
+            const int m = e - cell * 10;
+            const int cb = cell >> 5, cs = cell & 31;
+            if (cs < (cb ? lim[1] : lim[0]))
+            {
+                const double* src = s_part + (cb * kBandThreads + cs * 5) * kPartStride + m;
+                double acc = src[0];
+                acc += src[kPartStride];
+                acc += src[2 * kPartStride];
+                acc += src[3 * kPartStride];
+                acc += src[4 * kPartStride];
+                p.cell_sums[((cb ? base[1] : base[0]) + cs) * kSumStride + m] = acc;
+            }
+        }
+        return;
     }
 
-    // ------------------------------------------------------------------ per-cell scans: waves 0 and 1, one band each
-    // Lanes 0..31 of a wave run the horizontal scan of the band's 32 cells, lanes 32..63 the vertical scan of the same cells, as
-    // straight-line steps (is_continuous_flat); the two verdicts meet through one cross-lane read.  (Through round 4 wave 0 ran
-    // both scans of all 64 cells one behind the other, 37 branching steps on a lone wave while the workgroup's LDS and wave
-    // slots were held: 5 % of the kernel by ablation, profiles/r04_a1_phases.txt.  Round 3's other extreme -- one lane per TEST
-    // on all five waves -- measured slower: ~5x the wave-instructions in a kernel bound by VALU issue.)
-    if (t >= 128)
-        return;
-    const int fb = t >> 6;              // band of the pair = wave
-    const int fs = t & 31;              // cell of the band
-    const bool vertical = (t & 32) != 0;
-    const int c64 = fb * 32 + fs;       // cell of the workgroup (= lcell of the lanes that streamed it)
+    // Continuity cross scans, four lane-tasks per cell, sixteen cells per wave: lane = (task, cell) with task = horizontal /
+    // vertical x first / second half of the scan's steps; the four verdicts meet through two cross-lane reads.
+    //   is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219, steps 1..19
+    //   is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, .., 370: steps 1..18 (the loop stops before idx 390)
+    // A step only needs `last`, the latest depth that passed.  If the first half (seed test, steps 1..9) passes, every positive
+    // depth in it has become `last` in turn, so the second half (steps 10..) starts from the last positive depth among steps
+    // 1..9, else from the seed max(z[0], z[1]) -- and if the first half fails the cell is discontinuous whatever the second
+    // half says.  The steps are straight-line code (is_continuous_flat), so all four tasks are one instruction stream of ten
+    // steps.  (Through round 4 wave 0 ran both scans of all 64 cells one behind the other, 37 branching steps on a lone wave;
+    // round 3's other extreme -- one lane per TEST on all five waves, a look-back loop per test -- measured slower.)
+    const int w = t >> 6, l = t & 63;
+    const int c64 = w * 16 + (l & 15);   // cell of the workgroup (= lcell of the lanes that streamed it)
+    const bool vertical = (l & 32) != 0;
+    const bool second = (l & 16) != 0;
     bool continuous;
     {
-        // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219;
-        // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
         const float* zs = (vertical ? s_col : s_row) + c64 * kCell;
-        float last = std_maxf(zs[0], zs[1]);
-        continuous = !(last <= 0);
+        const float seed = std_maxf(zs[0], zs[1]);
+        float last = seed;
 #pragma unroll
-        for (int i = 1; i < kCell - 1; ++i)
-            continuous &= is_continuous_flat(zs[i], last);
-        const bool lastStep = is_continuous_flat(zs[kCell - 1], last);
-        continuous &= vertical | lastStep;
+        for (int i = 1; i <= 9; ++i)
+        {
+            const float z = zs[i];
+            last = (second && z > 0) ? z : last;
+        }
+        continuous = second || !(seed <= 0);
+        const float* zt = zs + (second ? 10 : 1);
+        const int steps = second ? (vertical ? 9 : 10) : 9;
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+        {
+            const bool pass = is_continuous_flat(zt[k], last);
+            continuous &= pass | (k >= steps);
+        }
+        continuous &= __shfl_xor((int)continuous, 16) != 0;
         continuous &= __shfl_xor((int)continuous, 32) != 0;
     }
+    const int fb = c64 >> 5, fs = c64 & 31;
     const int fband = pair * 2 + fb;
-    if (vertical || fband >= p.bandsPerFrame)
+    if ((l >> 4) != 0 || fband >= p.bandsPerFrame)
         return;
     const int fRow = fband / p.segsPerRow;
     const int fSeg = fband - fRow * p.segsPerRow;
