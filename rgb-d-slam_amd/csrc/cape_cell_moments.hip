@@ -99,16 +99,10 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             {
                 // N4: the PNG payload of the TUM / CAPE datasets, converted exactly like
                 // cv::Mat::convertTo(CV_32F, scale) does (examples/main_TUM.cpp:242): float(raw) * float(scale)
-                // one v_mul_f32 each, spelled out: left to itself the SLP vectoriser pairs them into v_pk_mul_f32, which
-                // costs two issue slots on gfx950's 32-wide SIMDs plus the moves that build the register pairs
-                // (measured: 2.00 ms per 4 096 frames packed, 1.54 ms scalar)
-                auto mul1 = [](float a, float b) {
-                    float r;
-                    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-                    return r;
-                };
-                return make_float4(mul1((float)rw.x, scale16), mul1((float)rw.y, scale16), mul1((float)rw.z, scale16),
-                                   mul1((float)rw.w, scale16));
+                // (one v_mul_f32_e32 each: this file is compiled without the SLP vectoriser, which used to pair them into
+                // v_pk_mul_f32 + register-pair moves -- 2.00 ms per 4 096 frames packed against 1.54 ms; through round 4 they
+                // were inline asm for that reason)
+                return make_float4((float)rw.x * scale16, (float)rw.y * scale16, (float)rw.z * scale16, (float)rw.w * scale16);
             }
             else
             {
