@@ -23,6 +23,9 @@ namespace cape {
 
 namespace {
 
+#ifndef CAPE_RECTIFY_FLAT
+#define CAPE_RECTIFY_FLAT 1
+#endif
 constexpr int kTileThreads = 1024;
 constexpr int kFallbackThreads = 256;
 constexpr int kFallbackChunk = kFallbackThreads * 4; // pixels per work item of the fallback kernels
@@ -57,6 +60,30 @@ __device__ __forceinline__ bool rectify_target(const RectifyParams& p, int row, 
     trow = (int)fy_;
     zOut = (float)p2;
     return true;
+}
+
+// The same as straight-line code for the tile kernel, which evaluates four pixels side by side: every value is computed whatever
+// the pixel is (an invalid depth or an absurd matrix gives garbage that the returned predicate rejects; nothing here can trap)
+// and the tests are ANDed at the end -- one predicate per pixel instead of four nested exec-mask regions.
+__device__ __forceinline__ bool rectify_target_flat(const RectifyParams& p, float xpre, float ypre, float originalZ, int& trow, int& tcol, float& zOut)
+{
+    const double o0 = (double)(xpre * originalZ);
+    const double o1 = (double)(ypre * originalZ);
+    const double o2 = (double)originalZ;
+    const double p0 = ((p.T[0] * o0 + p.T[1] * o1) + p.T[2] * o2) + p.T[3];
+    const double p1 = ((p.T[4] * o0 + p.T[5] * o1) + p.T[6] * o2) + p.T[7];
+    const double p2 = ((p.T[8] * o0 + p.T[9] * o1) + p.T[10] * o2) + p.T[11];
+    const double u = p.fx * p0 + p.cx * p2;
+    const double v = p.fy * p1 + p.cy * p2;
+    const double s = 1.0 / p2;
+    const double sx = s * u, sy = s * v;
+    const double fx_ = floor(sx), fy_ = floor(sy);
+    // NaN fails every ordered comparison, so `isnan(sx) || isnan(sy)` is covered by the range test
+    const bool ok = (originalZ > 0) & (fx_ > 0.0) & (fy_ > 0.0) & (fx_ < (double)p.W) & (fy_ < (double)p.H);
+    tcol = (int)fx_;
+    trow = (int)fy_;
+    zOut = (float)p2;
+    return ok;
 }
 
 // the registered depth of the target whose winner is source pixel `src` of the frame (0: nothing landed)
@@ -102,6 +129,40 @@ __global__ __launch_bounds__(kTileThreads) void cape_rectify_tile_kernel(Rectify
         const int c4 = cq << 2, rowBase = __mul24(r - s0, p.W);
         const float4 z4 = *reinterpret_cast<const float4*>(in + (size_t)r * p.W + c4);
         const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
+#if CAPE_RECTIFY_FLAT
+        const float4 xp4 = *reinterpret_cast<const float4*>(p.xpre + c4);
+        const float xps[4] = {xp4.x, xp4.y, xp4.z, xp4.w};
+        const float yp = p.ypre[r];
+        int trow[4], tcol[4];
+        float z[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            ok[k] = rectify_target_flat(p, xps[k], yp, zs[k], trow[k], tcol[k], z[k]);
+        bool outside[4]; // landed, not in my band, and moved by more than the prediction: rare
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const bool mine = ok[k] & (trow[k] >= t0) & (trow[k] < t1);
+            if (mine)
+                atomicMax(&s_keys[__mul24(trow[k] - t0, p.W) + tcol[k]],
+                          ((unsigned long long)((unsigned)(rowBase + c4 + k) + 1u) << 32) | (unsigned long long)__float_as_uint(z[k]));
+            const int dr = trow[k] - r;
+            outside[k] = ok[k] & !mine & ((dr < lo) | (dr > hi));
+        }
+        if (outside[0] | outside[1] | outside[2] | outside[3])
+        {
+            // does the band that owns the target scan this row?  (Inside the prediction it does by construction; every row is
+            // scanned by somebody, so somebody asks.)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const int ob = trow[k] >> log2R, o0 = ob << log2R, o1 = (o0 + R < p.H) ? o0 + R : p.H;
+                const int os0 = (ob == 0 || o0 - hi < 0) ? 0 : o0 - hi, os1 = (ob == bands - 1 || o1 - lo > p.H) ? p.H : o1 - lo;
+                escaped |= outside[k] & ((r < os0) | (r >= os1));
+            }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
@@ -122,6 +183,7 @@ __global__ __launch_bounds__(kTileThreads) void cape_rectify_tile_kernel(Rectify
                     escaped = true;
             }
         }
+#endif
         r += stepRows;
         cq += stepQuads;
         if (cq >= quadsPerRow)
