@@ -31,6 +31,7 @@ for name, M in (("identity", np.eye(4)), ("25 mm baseline, 0.5 deg yaw", T)):
     valid = float((dev > 0).float().mean())
     px = B * 640 * 480
     alg = px * (4 + 4)
+    print("flagged frames (general kernels): %d" % ex.rectify_flagged())
     print("%-28s %8.3f ms per %d frames = %.2f M frames/s ; algorithmic %.1f MB -> %.0f GB/s (%.1f %% of 8 TB/s); valid source pixels %.1f %%, targets hit %.1f %%" % (
         name, ms, B, B / ms / 1e3, alg / 1e6, alg / ms / 1e6, 100 * alg / ms / 1e6 / 8000, 100 * valid, 100 * float((out > 0).float().mean())))
 if "--chunks" in sys.argv:  # does the key buffer's residency between the two kernels matter?  the same batch in sub-batches

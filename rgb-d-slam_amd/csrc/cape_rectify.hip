@@ -266,7 +266,9 @@ hipError_t launch_rectify(const RectifyParams& p, int nFrames, int computeUnits,
             ;
     // ... of THIS device: 96 KB of the 160 KB a gfx950 workgroup may have, never more than the device reports (ADVICE r3:
     // a 64 KB device got an 80 KB launch and failed instead of taking a smaller band)
-    const size_t ldsLimit = p.ldsLimitBytes > 0 ? (size_t)p.ldsLimitBytes : 64 * 1024;
+    // (minus the few bytes __syncthreads_or keeps in static LDS: a band of exactly the device's limit -- CAPE_RECTIFY_BAND=32 at
+    // W = 640 on gfx950 -- aborted the queue with HSA_STATUS_ERROR_INVALID_ALLOCATION instead of taking a smaller band)
+    const size_t ldsLimit = (p.ldsLimitBytes > 0 ? (size_t)p.ldsLimitBytes : 64 * 1024) - 256;
     const size_t budget = ldsLimit < 96 * 1024 ? ldsLimit : 96 * 1024;
     while (log2R > 1 && ((size_t)p.W * 8 << log2R) > (p.bandRows <= 0 ? budget : ldsLimit))
         --log2R;
