@@ -618,6 +618,33 @@ def test_rectify_depth_1280x960(oracle_mod):
     ex.close()
 
 
+@pytest.mark.parametrize("band", ["8", "32", "64"])
+def test_rectify_band_override_never_exceeds_lds(oracle_mod, monkeypatch, band):
+    """CAPE_RECTIFY_BAND asks for a band height; 32 rows x 640 x 8 B is exactly the 160 KB a gfx950 workgroup may have and does not fit
+    beside the kernel's static LDS (the launch used to abort the queue): the launcher has to take the next smaller band, same bits."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    monkeypatch.setenv("CAPE_RECTIFY_BAND", band)
+    intr = _intr("room")
+    frames = np.stack([synth.room(seed=2, frame=i) for i in range(2)]).astype(np.float32)
+    a = np.deg2rad(0.4)
+    T = np.eye(4)
+    T[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    T[:3, 3] = [-20.0, 2.0, 0.5]
+    orc = oracle_mod.Oracle(640, 480, cylinders=False, **intr)
+    ex = Extractor(640, 480, cylinders=False, max_batch=2, **intr)
+    din = torch.from_numpy(frames).cuda()
+    dout = torch.empty_like(din)
+    ex.rectify_device(din.data_ptr(), dout.data_ptr(), 2, T, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dout.cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f].view(np.uint32), orc.rectify(frames[f], T).view(np.uint32))
+    assert ex.rectify_flagged() == 0
+    ex.close()
+
+
 def test_rectify_depth_parity(oracle_mod):
     """N3: device rectify_depth == oracle (deterministic last-writer-wins), then the rectified image through the path."""
     import torch
