@@ -3,6 +3,7 @@
 // compiled with -ffp-contract=off so no mul+add pair is fused, and f64 div/sqrt expand to the correctly
 // rounded sequences.  Comparisons mirror std::max/std::min argument order so NaN/-0 behave the same.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -229,64 +230,73 @@ __device__ inline void self_adjoint_eigen3(double m00, double m10, double m11, d
                 mu -= e2 / (td + (td > 0.0 ? h : -h));
         }
 
-        // k = start: ONE rotation on (k, k + 1), k in {0, 1}, on selected operands -- the reference's generic loop body; the lanes of
-        // a wave sit in different (start, end) blocks, and three unrolled copies of it used to run one after the other
-        const bool k1 = start != 0;
-        const double dk = k1 ? d1 : d0, sk = k1 ? s1 : s0, dk1 = k1 ? d2 : d1;
-        double x = dk - mu;
-        double z = sk;
-        if (z != 0.0)
-        {
-            double c, s;
-            make_givens(x, z, c, s);
-            const double sdk = s * dk + c * sk;
-            const double dkp1 = s * sk + c * dk1;
-            const double ndk = c * (c * dk - s * sk) - s * (c * sk - s * dk1);
-            const double ndk1 = s * sdk + c * dkp1;
-            const double nsk = c * sdk - s * dkp1;
-            // q.applyOnTheRight(k, k + 1, rot)
+        // k = start: ONE rotation on (k, k + 1), k in {0, 1} -- the reference's generic loop body.  The lanes of a wave sit in
+        // different (start, end) blocks, and three unrolled copies of it used to run one after the other; the body works on
+        // SELECTED operands (SEL) when some lane of the wave is in block [1,2], and as plain k = 0 code -- no selects -- when
+        // none is, which is the rule: the shift makes the bottom of the matrix deflate first, so start stays 0.
+        auto qr_first = [&](auto sel) {
+            constexpr bool SEL = decltype(sel)::value;
+            const bool k1 = SEL ? (start != 0) : false;
+            const double dk = k1 ? d1 : d0, sk = k1 ? s1 : s0, dk1 = k1 ? d2 : d1;
+            double x = dk - mu;
+            double z = sk;
+            if (z != 0.0)
+            {
+                double c, s;
+                make_givens(x, z, c, s);
+                const double sdk = s * dk + c * sk;
+                const double dkp1 = s * sk + c * dk1;
+                const double ndk = c * (c * dk - s * sk) - s * (c * sk - s * dk1);
+                const double ndk1 = s * sdk + c * dkp1;
+                const double nsk = c * sdk - s * dkp1;
+                // q.applyOnTheRight(k, k + 1, rot)
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-            {
-                const double xi = k1 ? Q[r][1] : Q[r][0], yi = k1 ? Q[r][2] : Q[r][1];
-                const double nx = c * xi - s * yi, ny = s * xi + c * yi;
-                Q[r][0] = k1 ? Q[r][0] : nx;
-                Q[r][1] = k1 ? nx : ny;
-                Q[r][2] = k1 ? ny : Q[r][2];
-            }
-            if (k1)
-            {
-                d1 = ndk;
-                d2 = ndk1;
-                s1 = nsk;
-            }
-            else
-            {
-                d0 = ndk;
-                d1 = ndk1;
-                s0 = nsk;
-                x = s0;
-                if (0 < end - 1)
+                for (int r = 0; r < 3; ++r)
                 {
-                    z = -s * s1;
-                    s1 = c * s1;
+                    const double xi = k1 ? Q[r][1] : Q[r][0], yi = k1 ? Q[r][2] : Q[r][1];
+                    const double nx = c * xi - s * yi, ny = s * xi + c * yi;
+                    Q[r][0] = k1 ? Q[r][0] : nx;
+                    Q[r][1] = k1 ? nx : ny;
+                    Q[r][2] = k1 ? ny : Q[r][2];
                 }
-                // k = 1 (only when start == 0 and end == 2)
-                if (end == 2 && z != 0.0)
+                if (k1)
                 {
-                    double c2, s2;
-                    make_givens(x, z, c2, s2);
-                    const double sdk2 = s2 * d1 + c2 * s1;
-                    const double dkp12 = s2 * s1 + c2 * d2;
-                    const double nd1 = c2 * (c2 * d1 - s2 * s1) - s2 * (c2 * s1 - s2 * d2);
-                    d2 = s2 * sdk2 + c2 * dkp12;
-                    s1 = c2 * sdk2 - s2 * dkp12;
-                    d1 = nd1;
-                    s0 = c2 * s0 - s2 * z; // k > start
-                    qr_rotate(Q, 1, c2, s2);
+                    d1 = ndk;
+                    d2 = ndk1;
+                    s1 = nsk;
+                }
+                else
+                {
+                    d0 = ndk;
+                    d1 = ndk1;
+                    s0 = nsk;
+                    x = s0;
+                    if (0 < end - 1)
+                    {
+                        z = -s * s1;
+                        s1 = c * s1;
+                    }
+                    // k = 1 (only when start == 0 and end == 2)
+                    if (end == 2 && z != 0.0)
+                    {
+                        double c2, s2;
+                        make_givens(x, z, c2, s2);
+                        const double sdk2 = s2 * d1 + c2 * s1;
+                        const double dkp12 = s2 * s1 + c2 * d2;
+                        const double nd1 = c2 * (c2 * d1 - s2 * s1) - s2 * (c2 * s1 - s2 * d2);
+                        d2 = s2 * sdk2 + c2 * dkp12;
+                        s1 = c2 * sdk2 - s2 * dkp12;
+                        d1 = nd1;
+                        s0 = c2 * s0 - s2 * z; // k > start
+                        qr_rotate(Q, 1, c2, s2);
+                    }
                 }
             }
-        }
+        };
+        if (__any(start != 0))
+            qr_first(std::true_type{});
+        else
+            qr_first(std::false_type{});
     }
 
     if (iter <= 90)
