@@ -88,10 +88,19 @@ template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void c
             for (int i = 0; i < kGroup; ++i)
             {
                 const size_t rowOff = (size_t)(kGroup * g + i) * W; // uniform
+                // non-temporal: the image is read exactly once, nothing of it is worth a cache line (1 % by interleaved A/B runs)
                 if constexpr (U16)
-                    buf[i] = *reinterpret_cast<const ushort4*>((frameBase16 + rowOff) + pixOff32);
+                {
+                    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                    const u16x4 v = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>((frameBase16 + rowOff) + pixOff32));
+                    buf[i] = make_ushort4(v.x, v.y, v.z, v.w);
+                }
                 else
-                    buf[i] = *reinterpret_cast<const float4*>((frameBase + rowOff) + pixOff32);
+                {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((frameBase + rowOff) + pixOff32));
+                    buf[i] = make_float4(v.x, v.y, v.z, v.w);
+                }
             }
         };
         auto to_f4 = [&](const Raw& rw) {
