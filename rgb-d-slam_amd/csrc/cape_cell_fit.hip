@@ -440,22 +440,37 @@ template <bool U16> __global__ __launch_bounds__(kStripThreads) void cape_cell_s
             s_range[cell * 2 + 1] = zmaxBits;
         }
     }
-    else if (t >= 192 && t < 192 + 2 * kStripCells)
+    else if (t >= 192 && t < 192 + 4 * kStripCells)
     {
-        const int l = t - 192, c = l & (kStripCells - 1), vscan = l >> 3;
-        // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219
-        // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370 (the loop stops before 390)
+        // four lane-tasks per cell like in the streaming kernel (cape_cell_moments.hip): horizontal / vertical x first / second half of the
+        // scan's steps, straight-line steps, the second half starting from the last positive depth of the first; the scans are the longest
+        // chain between the two barriers (19 branching steps on 16 lanes through round 4)
+        const int l = t - 192, c = l & (kStripCells - 1);
+        const bool second = (l & kStripCells) != 0, vscan = (l & (2 * kStripCells)) != 0;
+        // is_cell_horizontal_continuous (plane_segment.cpp:82-100): local row 10, idx 200..219, steps 1..19
+        // is_cell_vertical_continuous (:62-80): local column 10, idx 10, 30, ..., 370: steps 1..18 (the loop stops before 390)
         const float* zs = (vscan ? s_col : s_row) + c * kCell;
-        bool continuous = true;
-        float last = std_maxf(zs[0], zs[1]);
-        if (last <= 0)
-            continuous = false;
+        const float seed = std_maxf(zs[0], zs[1]);
+        float last = seed;
 #pragma unroll
-        for (int i = 1; i < kCell - 1; ++i)
-            continuous = continuous && is_continuous(zs[i], last);
-        if (!vscan)
-            continuous = continuous && is_continuous(zs[kCell - 1], last);
-        s_cont[l] = continuous ? 1u : 0u;
+        for (int i = 1; i <= 9; ++i)
+        {
+            const float z = zs[i];
+            last = (second && z > 0) ? z : last;
+        }
+        bool continuous = second || !(seed <= 0);
+        const float* zt = zs + (second ? 10 : 1);
+        const int steps = second ? (vscan ? 9 : 10) : 9;
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+        {
+            const bool pass = is_continuous_flat(zt[k], last);
+            continuous &= pass | (k >= steps);
+        }
+        continuous &= __shfl_xor((int)continuous, kStripCells) != 0;
+        continuous &= __shfl_xor((int)continuous, 2 * kStripCells) != 0;
+        if (l < 2 * kStripCells)
+            s_cont[l] = continuous ? 1u : 0u;
     }
     __syncthreads();
 
