@@ -13,8 +13,8 @@
 //
 // A1 mapping: one 320-thread workgroup = two "bands" (band = 20 image rows x 640 pixels = 32 cells).  Thread t owns
 // float4 column q = t % 160 of band t / 160 and walks the band's 20 rows, so every wave-level load is a contiguous
-// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded five
-// at a time, one group ahead of the arithmetic.  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
+// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded two
+// at a time (CAPE_A_GROUP), ping-pong buffered, one group ahead of the arithmetic (non-temporal: the image is read once).  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
 // The sums are exact in f64 for ANY summation order when the addends' exponent span is < 21 bits;
 // a per-cell z-range guard decides whether that holds, otherwise A2 redoes the cell in the reference's pixel order.
 // (A1 itself: cape_cell_moments.hip, compiled without the SLP vectoriser; the shared accumulators: cape_cell_acc.h.)

@@ -13,8 +13,8 @@
 //
 // A1 mapping: one 320-thread workgroup = two "bands" (band = 20 image rows x 640 pixels = 32 cells).  Thread t owns
 // float4 column q = t % 160 of band t / 160 and walks the band's 20 rows, so every wave-level load is a contiguous
-// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded five
-// at a time, one group ahead of the arithmetic.  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
+// 16 B/lane segment of the row-major image; a float4 never straddles a cell (20 = 5 float4).  Rows are loaded two
+// at a time (CAPE_A_GROUP), ping-pong buffered, one group ahead of the arithmetic (non-temporal: the image is read once).  Per-thread partial sums (f64) meet in LDS; 5 partials = one cell.
 // The sums are exact in f64 for ANY summation order when the addends' exponent span is < 21 bits;
 // a per-cell z-range guard decides whether that holds, otherwise A2 redoes the cell in the reference's pixel order.
 //
@@ -33,7 +33,7 @@ namespace cape {
 
 template <bool U16> __global__ __launch_bounds__(kThreadsA, CAPE_A_WAVES) void cape_cell_moments_kernel(StageAParams p)
 {
-    // LDS: per-thread partials, then reused for the 64 cells' centre row / centre column samples
+    // LDS: per-thread partials (written behind the row loop) and the 64 cells' centre row / centre column samples (written in it)
     __shared__ double s_part[kThreadsA * kPartStride]; // [thread][9 sums, count, (zmin,zmax) packed in the pad slot]
     __shared__ float s_row[64 * kCell];  // local row 10 of every cell (idx 200..219)
     __shared__ float s_col[64 * kCell];  // local column 10 of every cell (idx 10, 30, ..., 390)
