@@ -529,6 +529,10 @@ int cape_debug_eval(int op, const double* a, const double* b, double* out, int n
 int cape_debug_cycles(cape_handle h, int32_t n_frames, unsigned long long* out);
 /* frames of the last cape_rectify_depth that its band kernel handed to the general kernels (tests; synchronises) */
 int cape_debug_rectify_flagged(cape_handle h, int32_t* count);
+/* the task queue of the last cape_build_polygons (tests; synchronises): slots reserved by spawned tasks and quit marks, tickets
+ * taken, and the slots the call could use.  reserved > slots means the queue overflowed and waves walked rungs they could not
+ * enqueue -- impossible in the shipped library (the queue holds every task a batch can spawn), forced by a test build. */
+int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* tickets, uint32_t* slots);
 
 const char* cape_last_error(void);
 const char* cape_version(void);

@@ -2112,6 +2112,26 @@ int cape_debug_rectify_flagged(cape_handle h, int32_t* count)
     return CAPE_OK;
 }
 
+int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* tickets, uint32_t* slots)
+{
+    if (!h || !reserved || !tickets || !slots)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    *reserved = *tickets = *slots = 0;
+    if (!h->polyLadder || h->polygonFrames <= 0)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    cape::PolygonParams p;
+    cape::polygon_bind_scratch(p, h->polyLadder, (size_t)h->cfg.max_batch, h->boundaryCap);
+    uint32_t hd[2] = {0, 0};
+    CAPE_HIP_TRY(hipMemcpy(hd, p.queue, sizeof hd, hipMemcpyDeviceToHost));
+    *reserved = hd[0];
+    *tickets = hd[1];
+    const size_t wanted = cape::polygon_queue_slots((size_t)h->polygonFrames);
+    *slots = (uint32_t)(wanted < (size_t)p.queueCapacity ? wanted : (size_t)p.queueCapacity);
+    return CAPE_OK;
+}
+
 int cape_enable_timing(cape_handle h, int32_t enable)
 {
     if (!h)

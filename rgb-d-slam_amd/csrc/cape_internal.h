@@ -206,8 +206,10 @@ struct PolygonParams
     cape_polygon* polygons;  // frames x CAPE_MAX_PLANES
     double2* vertices;       // frames x boundaryCapacity plane-frame vertices (a plane's ring starts at its boundary_offset)
     int boundaryCapacity;
-    uint32_t* lists;          // three work lists of listStride words (kPolyListHeader words, then entries): the planes of up to 256
-    uint32_t listStride;      // candidates, the queue of spawned (plane, rung) tasks, the planes of 257 .. 1 024 candidates
+    uint32_t* lists;          // two work lists of listStride words (kPolyListHeader words, then entries): the planes of up to 256
+    uint32_t listStride;      // candidates, the planes of 257 .. 1 024 candidates
+    uint32_t* queue;          // the task kernel's queue of spawned (plane, rung) tasks: kPolyListHeader words ([0] tail, [1] head), then
+    uint32_t queueCapacity;   // queueCapacity slots = polygon_queue_slots(frames the scratch was sized for)
     uint32_t* state;          // frames x CAPE_MAX_PLANES state words of the task kernel (done mask | hull mask << 8 | finalised << 16)
     unsigned short* park;     // frames x 6 rungs x parkStride: hulls waiting for the verdict of lower rungs
     uint32_t parkStride;      // boundaryCapacity + 2 * CAPE_MAX_PLANES (a plane's hull: length + at most count + 1 indices)
@@ -216,6 +218,7 @@ struct PolygonParams
     unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
 
+size_t polygon_queue_slots(size_t frames);
 size_t polygon_scratch_bytes(size_t frames, int boundaryCapacity);
 void polygon_bind_scratch(PolygonParams& p, void* base, size_t frames, int boundaryCapacity);
 

@@ -39,9 +39,8 @@ constexpr int kPolySortSelect = 5;  // neighbours from which the k-nearest selec
 enum PolyList
 {
     kPolyFirstRung = 0, // list 0: the planes of up to 256 candidates (static list of the task kernel)
-    kPolyLadder = 1,    // list 1: the task kernel's dynamic queue of spawned (plane, rung) tasks
-    kPolyFull = 2       // list 2: planes of 257 .. 1 024 candidates (the large instance: the whole ladder in one wave)
-};
+    kPolyFull = 1       // list 1: planes of 257 .. 1 024 candidates (the large instance: the whole ladder in one wave)
+};                      // (the task kernel's queue of spawned (plane, rung) tasks has a region of its own: PolygonParams::queue)
 
 #ifdef CAPE_POLY_PROFILE
 #define CAPE_PTICK(k)                                                                     \
@@ -1121,15 +1120,17 @@ __device__ inline void plane_finished(uint32_t* statList, uint32_t* dynList, uns
 #ifndef CAPE_POLY_OCC
 #define CAPE_POLY_OCC 4
 #endif
-__global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_polygon_task_kernel(PolygonParams p, int nFrames, int ldsPerWave)
+__global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_polygon_task_kernel(PolygonParams p, int nFrames, int ldsPerWave, unsigned queueLen)
 {
     constexpr int CAP = kPolySmallPoints;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* statList = p.lists + (size_t)kPolyFirstRung * p.listStride; // [0] front count [1] back count [2] next [3] planes not finished
-    uint32_t* dynList = p.lists + (size_t)kPolyLadder * p.listStride;     // [0] tail [1] head
+    uint32_t* dynList = p.queue;                                          // [0] tail [1] head
     const unsigned nStatic = statList[0];
-    const unsigned listCapacity = p.listStride - kPolyListHeader;
+    // the slots launch_polygons marked "not written yet" for this call: the same length bounds the tickets, the spawned tasks
+    // and the quit marks (a bound taken from the scratch's capacity let a ticket read a slot of an earlier call)
+    const unsigned listCapacity = queueLen;
     const PolyLds L = carve_lds<CAP>(smem_all + (size_t)wave * ldsPerWave);
     // One wave in four serves the spawned rungs from the start (they sit on some plane's critical chain of walks and must not
     // queue behind the planes of the batch); the others take planes of the batch and become servers when those are handed out.
@@ -1189,7 +1190,8 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
                     task = t;
                 }
                 else
-                    task = kTaskQuit; // (cannot happen: the queue holds a slot per possible task and per wave)
+                    task = kTaskQuit; // (only a -DCAPE_POLY_QUEUE_LEN test build gets here: the queue holds a slot per possible
+                                      // task and per wave.  Leaving is safe: a wave walks the rungs it could not enqueue itself)
             }
         }
         task = (unsigned)__builtin_amdgcn_readfirstlane((int)task);
@@ -1274,8 +1276,12 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
         }
         const uint32_t exist = rungs_that_exist(n);
         auto spawn = [&](uint32_t rungs) {
-            // lane 0: append one task per rung; a queue that is full (never on the test streams: it holds 64 tasks per frame)
-            // sends the rungs back to the caller, which walks them itself
+            // lane 0: append one task per rung.  The queue holds a slot for every rung every plane of the call can spawn (six per
+            // plane: each rung is spawned at most once, the state word's spawned mask) and one quit mark per wave, so it cannot
+            // fill up; a test build with a tiny queue (-DCAPE_POLY_QUEUE_LEN=16) shows what happens if it did: EVERY reserved
+            // slot below the capacity is written (a ticket may be watching it), the rungs beyond come back to the caller, which
+            // walks them itself, and tickets beyond the capacity leave.  (Through round 4 a rung refused below the capacity left
+            // its slot unwritten behind the moved tail: the ticket that landed on it would have spun for ever)
             uint32_t left = rungs;
             if (lane == 0 && rungs)
             {
@@ -1285,7 +1291,7 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
                 for (int a = 0; a < 8; ++a)
                     if ((rungs >> a) & 1u)
                     {
-                        if (at + k + totalWaves < listCapacity)
+                        if (at + k < listCapacity)
                         {
                             __hip_atomic_store(&dynList[kPolyListHeader + at + k], ((unsigned)c.frame << 11) | ((unsigned)c.seg << 3) | (unsigned)a, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1478,7 +1484,20 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
         listL[kPolyListHeader + s_base[kSizeBuckets] + myPos] = entry;
 }
 
-constexpr size_t kPolyQuitSlots = 8192; // room behind the tasks of a queue for one kTaskQuit per wave of the task kernel's grid
+#ifndef CAPE_POLY_QUIT_SLOTS
+#define CAPE_POLY_QUIT_SLOTS 8192
+#endif
+#ifndef CAPE_POLY_QUEUE_PER_FRAME
+#define CAPE_POLY_QUEUE_PER_FRAME (6 * CAPE_MAX_PLANES)
+#endif
+constexpr size_t kPolyQuitSlots = CAPE_POLY_QUIT_SLOTS;          // one kTaskQuit per wave of the task kernel's grid behind the last task
+constexpr size_t kPolyQueuePerFrame = CAPE_POLY_QUEUE_PER_FRAME; // rungs 2 .. 7 of every plane of a frame: each is spawned at most once
+#ifdef CAPE_POLY_QUEUE_LEN
+// test build: a queue of CAPE_POLY_QUEUE_LEN slots whatever the batch, so that spawned rungs overflow it (the grid keeps its size)
+size_t polygon_queue_slots(size_t) { return CAPE_POLY_QUEUE_LEN; }
+#else
+size_t polygon_queue_slots(size_t frames) { return frames * kPolyQueuePerFrame + kPolyQuitSlots; }
+#endif
 
 size_t polygon_lds_bytes(int cap)
 {
@@ -1492,7 +1511,7 @@ size_t polygon_lds_bytes(int cap)
 // scratch of a polygon pass over `frames` frames: three work lists, the state words, the parking area
 size_t polygon_scratch_bytes(size_t frames, int boundaryCapacity)
 {
-    const size_t lists = 3 * (frames * CAPE_MAX_PLANES + kPolyListHeader + kPolyQuitSlots) * sizeof(uint32_t);
+    const size_t lists = (2 * (frames * CAPE_MAX_PLANES + kPolyListHeader) + kPolyListHeader + polygon_queue_slots(frames)) * sizeof(uint32_t);
     const size_t state = frames * CAPE_MAX_PLANES * sizeof(uint32_t);
     const size_t park = frames * kParkRungs * ((size_t)boundaryCapacity + 2 * CAPE_MAX_PLANES) * sizeof(unsigned short);
     return lists + state + park + 64;
@@ -1500,21 +1519,26 @@ size_t polygon_scratch_bytes(size_t frames, int boundaryCapacity)
 void polygon_bind_scratch(PolygonParams& p, void* base, size_t frames, int boundaryCapacity)
 {
     p.lists = static_cast<uint32_t*>(base);
-    p.listStride = (uint32_t)(frames * CAPE_MAX_PLANES + kPolyListHeader + kPolyQuitSlots);
-    p.state = p.lists + 3 * (size_t)p.listStride;
+    p.listStride = (uint32_t)(frames * CAPE_MAX_PLANES + kPolyListHeader);
+    p.queue = p.lists + 2 * (size_t)p.listStride;
+    p.queueCapacity = (uint32_t)polygon_queue_slots(frames);
+    p.state = p.queue + kPolyListHeader + p.queueCapacity;
     p.park = reinterpret_cast<unsigned short*>(p.state + frames * CAPE_MAX_PLANES);
     p.parkStride = (uint32_t)(boundaryCapacity + 2 * CAPE_MAX_PLANES);
 }
 
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    // the headers of the three work lists (list m at p.lists + m * listStride), and the dynamic queue's "not written yet" marks
-    for (int m = 0; m < 3; ++m)
+    // the headers of the two work lists (list m at p.lists + m * listStride) and of the queue, and the queue's "not written yet"
+    // marks: ONE length -- what nFrames frames can spawn plus a quit mark per wave -- for the memset and for the kernel's bounds
+    for (int m = 0; m < 2; ++m)
         if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
             return e;
-    const size_t wanted = (size_t)nFrames * CAPE_MAX_PLANES + kPolyQuitSlots;
-    const size_t queue = wanted < (size_t)(p.listStride - kPolyListHeader) ? wanted : (size_t)(p.listStride - kPolyListHeader);
-    if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)kPolyLadder * p.listStride + kPolyListHeader, 0xFF, queue * sizeof(uint32_t), stream); e != hipSuccess)
+    if (const hipError_t e = hipMemsetAsync(p.queue, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
+        return e;
+    const size_t wanted = polygon_queue_slots((size_t)nFrames);
+    const size_t queue = wanted < (size_t)p.queueCapacity ? wanted : (size_t)p.queueCapacity;
+    if (const hipError_t e = hipMemsetAsync(p.queue + kPolyListHeader, 0xFF, queue * sizeof(uint32_t), stream); e != hipSuccess)
         return e;
     if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
         return e;
@@ -1530,7 +1554,7 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
     const int gridSmall = std::min(std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * CAPE_POLY_OCC), (int)(kPolyQuitSlots / kPolyWavesPerGroup));
     const int gridLarge = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits);
     hipLaunchKernelGGL(cape_polygon_task_kernel, dim3(gridSmall), dim3(64 * kPolyWavesPerGroup), (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,
-                       nFrames, ldsSmall);
+                       nFrames, ldsSmall, (unsigned)queue);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     if (p.boundaryCapacity > kPolySmallPoints) // a plane cannot hold more boundary points than the frame

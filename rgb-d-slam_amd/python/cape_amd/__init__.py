@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "cape_match_polygons", "cape_match_polygons_pose", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
+    "cape_debug_polygon_queue",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -409,6 +410,12 @@ class Extractor:
         n = C.c_int32(0)
         _check(self.L, self.L.cape_debug_rectify_flagged(self.h, C.byref(n)), "cape_debug_rectify_flagged")
         return n.value
+
+    def polygon_queue(self):
+        """(slots reserved, tickets taken, slots usable) of the task queue of the last build_polygons (tests)."""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self.L, self.L.cape_debug_polygon_queue(self.h, C.byref(a), C.byref(b), C.byref(c)), "cape_debug_polygon_queue")
+        return a.value, b.value, c.value
 
     # ---- timing --------------------------------------------------------------------------------
     def enable_timing(self, on=True):

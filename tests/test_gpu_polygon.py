@@ -241,3 +241,101 @@ def test_polygon_pass_without_planes_terminates():
         pol, _ = ex.polygons(n)
         assert (pol["flags"][n // 2] & 1).any() and not np.delete(pol["flags"], n // 2, axis=0).any()
         ex.close()
+
+
+def _ragged_batch(n, seed=3):
+    """Device-rendered room frames with dropped pixels, noise and dropped blocks: ragged outlines whose rung 0 often has no hull."""
+    import torch
+    from cape_amd import synth_gpu
+
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    dev = synth_gpu.stream("room", seed, n, start=17, device="cuda", chunk=16).clone()
+    q = n // 3
+    dev[:q][torch.rand(dev[:q].shape, device="cuda", generator=gen) < 0.05] = 0
+    dev[q:2 * q] += torch.randn(dev[q:2 * q].shape, device="cuda", generator=gen) * 3.0 * (dev[q:2 * q] > 0)
+    for _ in range(6):
+        y, x = int(torch.randint(0, 400, (1,), generator=gen, device="cuda")), int(torch.randint(0, 560, (1,), generator=gen, device="cuda"))
+        dev[2 * q:, y:y + 80, x:x + 80] = 0
+    return dev
+
+
+def _check_batch_against_host(ex, n, host_poly, what):
+    res = ex.results(n)
+    pol, ver = ex.polygons(n)
+    planes = 0
+    for f in range(n):
+        for i, s in enumerate(res.segments(f)):
+            if not s["is_output"]:
+                continue
+            p = pol[f, i]
+            pts = res.boundary_points(f, s)
+            o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+            _same(p, ver[f, o:o + c], host_poly(pts, s["normal"], _center(s)), f"{what} frame {f} segment {i} ({len(pts)} points)")
+            planes += 1
+    return planes
+
+
+def test_polygon_task_queue_holds_every_task(host_poly):
+    """the queue of spawned (plane, rung) tasks is sized for what a batch can spawn (six rungs per plane + a quit mark
+    per wave), and the memset, the tickets and the spawns are bounded by the SAME length -- also when a small batch follows a big
+    one on a handle made for more frames (a ticket must never read a slot an earlier call left behind)."""
+    import torch
+    from cape_amd import Extractor, synth
+
+    st = torch.cuda.current_stream().cuda_stream
+    ex = Extractor(640, 480, cylinders=False, max_batch=96, **synth.DEFAULT_INTRINSICS)
+    dev = _ragged_batch(96)
+    spawned = 0
+    for n in (96, 6, 48, 1):
+        ex.extract_device(dev.data_ptr(), n, st)
+        ex.build_polygons(n, st)
+        reserved, tickets, slots = ex.polygon_queue()
+        assert slots == n * 6 * 64 + 8192, "one slot per rung a plane can spawn + one quit mark per wave of the grid"
+        assert reserved <= slots and tickets <= reserved, (reserved, tickets, slots)
+        planes = int(ex.results(n).records["header"]["n_planes"].sum())
+        assert reserved - min(reserved, 8192) <= 6 * max(planes, 1)
+        spawned += reserved
+        if n in (6, 1):
+            assert _check_batch_against_host(ex, n, host_poly, f"batch of {n}") > 0
+    assert spawned > 4 * 1024, "the ragged frames must make planes climb the ladder (spawned rungs)"
+    ex.close()
+
+
+def test_polygon_task_queue_overflow_worker(host_poly):
+    """Runs only inside test_polygon_task_queue_overflow's subprocess, on the twin library whose queue has 16 slots."""
+    if not os.environ.get("CAPE_EXPECT_QUEUE_OVERFLOW"):
+        pytest.skip("driven by test_polygon_task_queue_overflow")
+    import torch
+    from cape_amd import Extractor, synth
+
+    st = torch.cuda.current_stream().cuda_stream
+    n = 48
+    ex = Extractor(640, 480, cylinders=False, max_batch=n, **synth.DEFAULT_INTRINSICS)
+    dev = _ragged_batch(n)
+    for rep in range(3):
+        ex.extract_device(dev.data_ptr(), n, st)
+        ex.build_polygons(n, st)
+        reserved, tickets, slots = ex.polygon_queue()
+        assert slots == 16 and reserved > slots, f"the twin's queue must overflow: reserved {reserved}, slots {slots}"
+    assert _check_batch_against_host(ex, n, host_poly, "overflowing queue") > n
+    ex.close()
+
+
+def test_polygon_task_queue_overflow():
+    """through round 4 a spawned rung that did not fit the queue left its reserved slot unwritten behind the
+    moved tail, and the ticket that landed on that slot would have spun for ever.  The twin library (16 slots for any batch)
+    overflows on every call: every reserved slot below the capacity is written, the rungs beyond it are walked by the wave that
+    could not enqueue them, tickets beyond it leave -- the polygons stay bit-identical to the host class and nothing hangs."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    twin = os.path.join(root, "rgb-d-slam_amd", "lib", "libcape_hip_cyl_exact.so")
+    if not os.path.exists(twin):
+        subprocess.check_call(["make", "-C", os.path.join(root, "rgb-d-slam_amd", "csrc"), "variants"])
+    env = dict(os.environ, CAPE_HIP_LIB=twin, CAPE_EXPECT_QUEUE_OVERFLOW="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                          "queue_overflow_worker or polygons_of_extracted_planes or pass_without_planes_terminates"],
+                         env=env, capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout and "skipped" not in out.stdout
