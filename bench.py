@@ -310,14 +310,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # CAPE_BENCH_BACKEND=gloo: the N > 1 code paths of this file (sharding, budget all-reduce, the torch gather, max over ranks,
+    # per-rank parity) with several ranks SHARING the visible GPU(s) -- RCCL refuses two ranks on one device, gloo does not care.
+    # Validation of the launcher path on a one-GPU box; the line says so and is not a scaling measurement.
+    backend = os.environ.get("CAPE_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"bench.py: CAPE_BENCH_BACKEND={backend}: nccl (RCCL, default) or gloo")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    coll_dev = "cuda" if backend == "nccl" else "cpu"  # where the tensors of the small collectives live
+    torch.cuda.set_device(dev_index)
     # CAPE_BENCH_FORCE_GATHER=1 exercises the multi-GPU exchange on a single GPU (world 1; validation only)
     force = os.environ.get("CAPE_BENCH_FORCE_GATHER") == "1"
     multi = world > 1 or force
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H = args.width, args.height
     scene = args.scene or ("tumlike" if multi else "room")
@@ -352,10 +360,13 @@ def main():
     depth = unique_dev if reps == 1 else unique_dev.repeat(reps, 1, 1)[:B].contiguous()
     torch.cuda.synchronize()
 
-    ex = Extractor(W, H, cylinders=args.cylinders, device=local_rank, max_batch=B_max, sub_batches=args.sub_batches, **intr)
+    ex = Extractor(W, H, cylinders=args.cylinders, device=dev_index, max_batch=B_max, sub_batches=args.sub_batches, **intr)
     stream = torch.cuda.current_stream().cuda_stream
     gather = args.gather if multi else "none"
     gather_note = ""
+    if gather == "native" and backend == "gloo" and world > 1:
+        gather = "torch"
+        gather_note = "CAPE_BENCH_BACKEND=gloo: ranks share a device, which RCCL refuses -- the packed lists travel through torch.distributed (gloo, staged through the host)"
     lay, recv, works, local_view = None, None, [None, None], [None, None]
     planes_budget, budget_note = 16, "default"
     if gather != "none":
@@ -365,8 +376,8 @@ def main():
         # region; planes_per_frame = 64 can never overflow)
         ex.extract_device(depth.data_ptr(), B, stream) if not args.u16 else ex.extract_device_u16(depth.data_ptr(), 0.2, B, stream)
         n_pl0, n_cy0, _ = ex.count_primitives(B)  # cape_count_primitives: a device-side reduction over the batch's headers
-        cnt = torch.tensor([float(n_pl0), float(n_cy0), float(B)], dtype=torch.float64, device="cuda")
-        mx = torch.tensor([n_pl0 / B, n_cy0 / B], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([float(n_pl0), float(n_cy0), float(B)], dtype=torch.float64, device=coll_dev)
+        mx = torch.tensor([n_pl0 / B, n_cy0 / B], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(cnt)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         if args.planes_per_frame > 0:
@@ -380,18 +391,18 @@ def main():
         if args.gather_root and gather == "native" and rank != 0:
             recv = [None, None]  # ncclGather: only the root receives
         else:
-            recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device="cuda") for _ in range(2)]
+            recv = [torch.empty(world * lay["bytes_per_rank"], dtype=torch.uint8, device=coll_dev) for _ in range(2)]
         if gather == "native":
             # The C layer's communicator (librccl through dlopen, ncclCommInitRank).  If that does not come up on every
             # rank -- a library that cannot be resolved, an init that fails -- all ranks agree to route the same packed
             # bytes through torch.distributed instead, and the JSON line says which path ran.
             err = ""
             try:
-                uid = cdist.broadcast_unique_id(ex.comm_unique_id, rank, device="cuda")
+                uid = cdist.broadcast_unique_id(ex.comm_unique_id, rank, device=coll_dev)
                 ex.comm_init(uid, rank, world)
             except Exception as e:  # noqa: BLE001 -- whatever went wrong, the bench must still report a number
                 err = f"{type(e).__name__}: {e}"
-            okflag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            okflag = torch.tensor([0 if err else 1], dtype=torch.int32, device=coll_dev)
             dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
             if int(okflag.item()) == 0:
                 gather = "torch"
@@ -422,6 +433,8 @@ def main():
                 works[k].wait()
             ptr = ex.pack(B, first, stream)
             local_view[k] = torch.as_tensor(_DevMem(ptr, lay["bytes_per_rank"]), device="cuda")
+            if backend == "gloo":
+                local_view[k] = local_view[k].cpu()  # (synchronises: gloo gathers host tensors)
             works[k] = dist.all_gather_into_tensor(recv[k], local_view[k], async_op=True)
 
     def drain():
@@ -454,7 +467,7 @@ def main():
         """(max, min, list) of a per-rank scalar"""
         if not multi:
             return v, v, [v]
-        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        t = torch.tensor([v], dtype=torch.float64, device=coll_dev)
         allv = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allv, t)
         vals = [float(x.item()) for x in allv]
@@ -561,6 +574,32 @@ def main():
                                       "profiles/collect.sh over this same command -- not measured by this run")
             except Exception:
                 traffic = None
+        # The bound that actually holds the dominant kernel: A1 moves 1.0001 x its algorithmic bytes at about half the
+        # HBM peak because the ONE VALU port of a SIMD is busy.  profiles/valu_issue.py counts the vector instructions of the
+        # shipped ISA per class, prices them with the issue costs measured on gfx950 (profiles/r02_valu_rates.txt), and checks
+        # the count against a rocprofv3 --pmc SQ_INSTS_VALU pass of this command; the fraction below uses THIS run's launch time.
+        valu_issue = None
+        vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
+        if dom == "cape_cell_moments_kernel" and os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath))
+                vv = vj["variants"]["u16" if args.u16 else "f32"]
+                if vj.get("width") == W and vj.get("height") == H:
+                    sc = fpl / vj["frames_per_launch"]
+                    valu_issue = {"floor_ms": vv["floor_ms"] * sc, "frac_of_issue_floor": vv["floor_ms"] * sc / dom_ms,
+                                  "f64_rate_insts_per_launch": vv["f64_rate_insts_per_launch"] * sc,
+                                  "other_valu_insts_per_launch": vv["other_insts_per_launch"] * sc,
+                                  "f64_rate_share_of_floor": vv["f64_rate_share_of_floor"],
+                                  "valu_insts_per_wave": vv["valu_per_wave"], "waves_per_launch": vj["waves_per_launch"] * sc,
+                                  "pmc_SQ_INSTS_VALU_per_launch": (vv.get("pmc") or {}).get("SQ_INSTS_VALU_per_launch"),
+                                  "ns_per_wave_instruction": vj["rate_ns_per_wave_instruction"],
+                                  "source": "profiles/valu_issue.json (profiles/valu_issue.py: ISA of the shipped kernel x the measured issue costs of "
+                                            "profiles/r02_valu_rates.txt, checked against the SQ_INSTS_VALU pass " +
+                                            str((vv.get("pmc") or {}).get("source")) + "); static, the fraction uses this run's launch_ms",
+                                  "note": "one VALU port per SIMD: f64-rate and other vector instructions of different waves add up "
+                                          "(profiles/r02_valu_mix.txt); the f64 conversions and adds are the reference's operand types"}
+            except Exception:
+                valu_issue = None
         e2e_bytes_per_frame = W * H * (2 if args.u16 else 4) + 2 * cells * 4 + 32 * 128  # 1 239 040 B at 640x480
         if multi:
             workload = (f"{W}x{H} synthetic TUM-like depth stream of {total} frames sharded in contiguous blocks over {world} GPU(s), "
@@ -592,6 +631,8 @@ def main():
                 "sub_batches": args.sub_batches, "frames_rendered_on": "host (numpy)" if args.host_synth else "device (torch)",
                 "sharding": "contiguous frame blocks per GPU (cape_amd.dist.shard_range)" +
                             (f", packed primitive lists all-gathered once per step ({gather})" if gather != "none" else ""),
+                **({"backend": f"gloo: {world} ranks on {torch.cuda.device_count()} visible device(s) -- a dry run of the N > 1 code "
+                               "paths, NOT a scaling measurement (CAPE_BENCH_BACKEND)"} if backend == "gloo" else {}),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
@@ -599,6 +640,7 @@ def main():
                 # also against the 6.29 TB/s a streaming kernel can actually reach (MI355X_MICROARCH.md)
                 "frac_of_achievable_6p29TBps": achieved * 1e9 / 6.29e12,
                 "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": dom_ms,
+                "valu_issue": valu_issue,
                 "kernel_ms": {"cape_cell_moments_kernel": a1_ms, "cape_cell_plane_kernel": a2_ms, "cape_grow_kernel": b_ms},
                 "stage_b": {"us_per_frame": 1e3 * b_ms / fpl, "frames_in_flight": ex.grow_frames_per_cu * ex.compute_units,
                             "note": "one wavefront per frame, latency bound; ~0 HBM bytes beyond the 112 B/cell it reads"},
@@ -675,8 +717,40 @@ def main():
         # under the streaming kernel of the next.  What a caller with a continuous stream of batches gets for twice the scratch memory.
         # (ONE pair of streams for every overlapped leg of this run: the runtime maps streams onto a few hardware queues in
         #  creation order, and two streams that land on the same queue do not overlap at all)
-        streams0 = [torch.cuda.Stream(device=local_rank) for _ in range(2)]
-        pair0 = [Extractor(W, H, cylinders=False, device=local_rank, max_batch=B_max, **intr) for _ in range(2)]
+        # Row N4 beside it: the SAME frames as raw uint16 sensor units (half the bytes per pixel).  If A1 were HBM-bound this
+        # launch would take about half the time; it takes the same -- the kernel is bound by what it issues per pixel.
+        exu = Extractor(W, H, cylinders=False, device=dev_index, max_batch=B_max, **intr)
+        raw16 = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+        for c0 in range(0, B, 256):
+            raw16[c0:c0 + 256] = torch.clamp(torch.round(depth[c0:c0 + 256] * 5.0), 0, 65535).to(torch.int32).to(torch.int16)
+        for _ in range(3):
+            exu.extract_device_u16(raw16.data_ptr(), 0.2, B, stream)
+        torch.cuda.synchronize()
+        exu.reset_timings()
+        exu.enable_timing(True)
+        ku = max(5, min(args.steps, 20))
+        for _ in range(ku):
+            exu.extract_device_u16(raw16.data_ptr(), 0.2, B, stream)
+        torch.cuda.synchronize()
+        exu.enable_timing(False)
+        tu = exu.timings()
+        a1u_ms = 1e3 * tu["cell_moments_s"] / max(1, tu["calls"])
+        bytes_u = B * (W * H * 2 + cells * 96)
+        out["roofline"]["u16_launch"] = {"kernel": "cape_cell_moments_kernel<u16>", "launch_ms": a1u_ms, "algorithmic_bytes_per_launch": bytes_u,
+                                         "achieved": bytes_u / (a1u_ms * 1e-3) / 1e9, "frac": bytes_u / (a1u_ms * 1e-3) / HBM_PEAK_BYTES_S,
+                                         "note": "the same frames fed as raw uint16 (cape_extract_u16, row N4): half the bytes per pixel in the same "
+                                                 "launch time -- A1 is bound by VALU issue (roofline.valu_issue), not by HBM"}
+        try:
+            vju = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
+            if vju.get("width") == W and vju.get("height") == H:
+                fl = vju["variants"]["u16"]["floor_ms"] * B / vju["frames_per_launch"]
+                out["roofline"]["u16_launch"]["valu_issue"] = {"floor_ms": fl, "frac_of_issue_floor": fl / a1u_ms}
+        except Exception:
+            pass
+        exu.close()
+        del raw16
+        streams0 = [torch.cuda.Stream(device=dev_index) for _ in range(2)]
+        pair0 = [Extractor(W, H, cylinders=False, device=dev_index, max_batch=B_max, **intr) for _ in range(2)]
         k0 = max(10, min(args.steps, 40))
         for i in range(4):
             pair0[i & 1].extract_device(depth.data_ptr(), B, streams0[i & 1].cuda_stream)
@@ -701,7 +775,7 @@ def main():
             h0.close()
         # The reference has no plane-only switch: its cylinder branch is unconditional (primitive_detection.cpp:385-388).
         # Same stream, same frames, cylinders enabled -- outside the main timed region, reported next to `value`.
-        ex2 = Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, sub_batches=args.sub_batches, **intr)
+        ex2 = Extractor(W, H, cylinders=True, device=dev_index, max_batch=B_max, sub_batches=args.sub_batches, **intr)
         k2 = max(10, min(args.steps, 20))
         for _ in range(3):
             ex2.extract_device(depth.data_ptr(), B, stream)
@@ -732,7 +806,7 @@ def main():
         # The second pass lasts as long as its slowest frame and leaves the device nearly idle meanwhile.  TWO handles fed
         # alternately, each with its second pass on a stream of its own (CAPE_FLAG_ASYNC_SECOND_PASS): the streaming kernels
         # of one batch run under the tail of the other.  Same frames, same results (checked), twice the scratch memory.
-        pair = [Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, async_second_pass=True, **intr) for _ in range(2)]
+        pair = [Extractor(W, H, cylinders=True, device=dev_index, max_batch=B_max, async_second_pass=True, **intr) for _ in range(2)]
         for i in range(4):
             pair[i & 1].extract_device(depth.data_ptr(), B, stream)
         for e in pair:
@@ -761,7 +835,7 @@ def main():
         # What Primitive_Detection::find_primitives RETURNS (primitive_detection.cpp:119-166, ending in add_planes_to_primitives
         # :562-648): planes WITH their boundary polygons, the cylinder branch on -- plus the consumer's next step on them,
         # MapPlane::find_matches between consecutive frames.  ONE timed region: extract + polygons + matches per step.
-        ex3 = Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, **intr)
+        ex3 = Extractor(W, H, cylinders=True, device=dev_index, max_batch=B_max, **intr)
 
         def full_step():
             ex3.extract_device(depth.data_ptr(), B, stream)
@@ -809,7 +883,7 @@ def main():
         # and the cylinder second pass wait most of their cycles (dependent chains), the streaming kernels of the other handle's
         # batch issue under them.  Same frames, same results (both handles checked), twice the scratch memory.
         streams2 = streams0
-        pair = [Extractor(W, H, cylinders=True, device=local_rank, max_batch=B_max, **intr) for _ in range(2)]
+        pair = [Extractor(W, H, cylinders=True, device=dev_index, max_batch=B_max, **intr) for _ in range(2)]
 
         def full_step_on(i):
             h, st = pair[i & 1], streams2[i & 1].cuda_stream

@@ -55,3 +55,39 @@ def test_default_workload_proves_its_work():
     assert cyl["value"] > 0 and cyl["parity_check"]["labels_equal"] and cyl["parity_check"]["cylinders_bitwise"]
     assert set(cyl["kernel_ms"]) == {"cape_cell_moments_kernel", "cape_cell_plane_kernel", "cape_grow_kernel"}
     assert out["roofline"]["frac"] > 0.05 and out["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_share_the_gpu_through_gloo(scaling):
+    """the N > 1 branches of bench.py (shard arithmetic, the budget all-reduce, the torch gather, max over
+    ranks, per-rank parity, weak / strong stream sizes) had never run with world > 1.  CAPE_BENCH_BACKEND=gloo lets two ranks
+    share the one GPU of this box (RCCL refuses that); the line is a dry run of the code paths, not a scaling number."""
+    out = _run(["--gpus", "2", "--gather", "torch", "--scaling", scaling, "--steps", "3", "--warmup", "1", "--frames", "128",
+                "--no-cpu-baseline"], {"CAPE_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    total = 8 * 128 if scaling == "strong" else 2 * 128
+    assert out["config"]["stream_frames"] == total and out["config"]["frames_per_step_per_gpu"] == total // 2
+    assert "gloo" in out["config"]["backend"]
+    assert out["ranks"]["launcher"].startswith("self-spawned") and len(out["ranks"]["ms_per_step"]) == 2
+    assert out["ranks"]["ms_per_step_max"] >= out["ranks"]["ms_per_step_min"] > 0
+    g = out["gather"]
+    assert g["ok"] and g["frames"] == total and g["overflow"] == 0 and g["path"].startswith("torch")
+    assert "exposed_ms_per_step" in g and g["planes"] > 0
+    pc = out["parity_check"]
+    assert pc["ranks_checked"] == 2 and pc["all_ranks_ok"] and pc["labels_equal"] and pc["segments_bitwise"]
+    assert abs(out["value"] - total * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out and "cylinders_on" not in out  # rank 0 at N = 1 only
+
+
+def test_default_line_names_the_bound_that_holds():
+    """the driver-visible line says that A1 sits at about half the HBM peak AND at about its VALU-issue floor,
+    with the raw-uint16 launch (half the bytes, same time) beside it."""
+    out = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-polygons", "--no-parity-check"])
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "cape_cell_moments_kernel"
+    v = r["valu_issue"]
+    assert v is not None and 0.5 < v["frac_of_issue_floor"] <= 1.05, v
+    assert v["f64_rate_insts_per_launch"] > v["other_valu_insts_per_launch"] * 0.5
+    u = r["u16_launch"]
+    assert 0.8 < u["launch_ms"] / r["launch_ms"] < 1.25, "half the bytes in about the same time"
+    assert u["frac"] < 0.7 * r["frac"]
