@@ -66,8 +66,14 @@ enum
     CAPE_FRAME_BIN_NEAR_EDGE = 1u << 3,     /* a cell's histogram angle fell within 1e-9 of a bin edge (libm tie risk) */
     CAPE_FRAME_INORDER_CELLS = 1u << 4,     /* >=1 cell took the in-order accumulation path (exactness guard) */
     CAPE_FRAME_RNG_EXHAUSTED = 1u << 5,     /* RANSAC asked for more draws than the precomputed mt19937 table */
-    CAPE_FRAME_SEED_LIMIT = 1u << 6         /* the seed loop hit its iteration guard (4 * cells + 1024; provably unreachable) */
+    CAPE_FRAME_SEED_LIMIT = 1u << 6,        /* the seed loop hit its iteration guard (4 * cells + 1024; provably unreachable) */
+    CAPE_FRAME_INVALID_SEED = 1u << 7       /* the seed loop ended on "Could not find a single plane segment: invalid seed"
+                                               (log_warning, primitive_detection.cpp:299-304) */
 };
+/* bits 8..15 of the status: how many times the frame logged "Plane segment is not planar after merge" (primitive_detection.cpp:374
+ * for a grown region, :497 for a cylinder sub-segment), saturating at 255 */
+#define CAPE_FRAME_NOT_PLANAR_SHIFT 8
+#define CAPE_FRAME_NOT_PLANAR_COUNT(status) (((status) >> CAPE_FRAME_NOT_PLANAR_SHIFT) & 0xFFu)
 
 /*
  * Replaces: Depth_Map_Transformation(width,height,cellSize) + Primitive_Detection(width,height) constructors
@@ -248,6 +254,19 @@ typedef struct cape_timings
     double total_s;
     uint64_t frames;
     uint64_t calls;         /* number of cape_extract calls folded into the sums (= launches of each kernel) */
+    /* The reference's five buckets, one to one (find_primitives, primitive_detection.cpp:126-160; show_statistics :69-117):
+     *   reset_s       _resetTime : reset_data().  Nothing persists between frames here (row A14) and the hand-over counters are
+     *                 cleared by a thread of stage A2: there is no reset pass to time, the bucket is 0 by construction
+     *   init_s        _initTime  : init_planar_cell_fitting + init_histogram = kernels A1 + A2 (= cell_fit_s; the histogram's
+     *                 bins are A2's, its counting is the first microseconds of the grow kernel)
+     *   grow_phase_s  _growTime  : grow_planes_and_cylinders (seed loop, region growing, cylinder_fitting)
+     *   merge_s       _mergeTime : merge_planes
+     *   refine_s      _refineTime: add_planes_to_primitives + add_cylinders_to_primitives WITHOUT the boundary polygon (that is
+     *                 cape_build_polygons or the host class; the overlay adds its own clock for it)
+     * grow / merge / refine share the stage-B kernels: every frame's wave books the shader-clock ticks it spends in each of the
+     * three (three atomics per frame, only while timing is on) and grow_s -- the kernels' HIP-event time -- is split in those
+     * proportions: grow_phase_s + merge_s + refine_s == grow_s. */
+    double reset_s, init_s, grow_phase_s, merge_s, refine_s;
 } cape_timings;
 
 typedef struct cape_layout
@@ -533,6 +552,23 @@ int cape_debug_rectify_flagged(cape_handle h, int32_t* count);
  * taken, and the slots the call could use.  reserved > slots means the queue overflowed and waves walked rungs they could not
  * enqueue -- impossible in the shipped library (the queue holds every task a batch can spawn), forced by a test build. */
 int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* tickets, uint32_t* slots);
+
+/* outputs::log / log_warning / log_error of the path (the reference's src/outputs/logger.hpp), for a caller that wants the
+ * reference's own lines: level 0 = log, 1 = log_warning, 2 = log_error.  The messages find_primitives prints on the hot path,
+ *   "Could not find a single plane segment: invalid seed"                      (warning, primitive_detection.cpp:302)
+ *   "Plane segment is not planar after merge"                                  (log, :374 and :497; once per occurrence)
+ *   "Could not find a correct boundary polygon, rejecting plane segment"       (warning, :618: a planar merge root with fewer than
+ *                                                                               three boundary points)
+ * are decided on the device and travel in the frame record (CAPE_FRAME_INVALID_SEED, CAPE_FRAME_NOT_PLANAR_COUNT, the segments'
+ * boundary counts); the callback gets them when a batch's records first reach the host -- cape_copy_results with a records
+ * pointer, or cape_host_results -- once per extracted batch, frame by frame, on the calling thread.  The library's own
+ * capacity warnings (CAPE_FRAME_*_OVERFLOW) come the same way.  (:631 "Polyfit error" belongs to the polygon constructor:
+ * a consumer of cape_copy_polygons sees CAPE_POLY_REJECTED.)  fn == NULL removes the callback; nothing is ever printed. */
+typedef void (*cape_log_fn)(int32_t level, const char* message, int32_t frame, void* user);
+int cape_set_log_callback(cape_handle h, cape_log_fn fn, void* user);
+/* The same lines for records the caller holds (HOST memory, e.g. out of cape_copy_results): no handle, no device.  Returns the
+ * number of lines (>= 0) or a negative cape_status. */
+int cape_log_records(const cape_frame_record* records, int32_t n_frames, cape_log_fn fn, void* user);
 
 const char* cape_last_error(void);
 const char* cape_version(void);

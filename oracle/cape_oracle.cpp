@@ -1372,7 +1372,10 @@ void Oracle::find_primitives(const float* cloud, const float* depth, FrameResult
                 break;
         }
         if (minMSE >= std::numeric_limits<double>::max())
+        {
+            ++out.logInvalidSeed; // log_warning, :302
             break;
+        }
 
         // ---- grow_plane_segment_at_seed, :312-389
         out.seeds.push_back(static_cast<int32_t>(seedId));
@@ -1419,6 +1422,7 @@ void Oracle::find_primitives(const float* cloud, const float* depth, FrameResult
         if (!newSeg.planar)
         {
             out.seedOutcome.back() = 4;
+            ++out.logNotPlanarAfterMerge; // log, :374
             continue;
         }
 
@@ -1463,6 +1467,8 @@ void Oracle::find_primitives(const float* cloud, const float* depth, FrameResult
                 if (!fitable)
                     continue;
                 fit_plane(merged);
+                if (!merged.planar)
+                    ++out.logNotPlanarAfterMerge; // log, :497 (the sub-segment still goes through the model selection)
                 // add_cylinder_to_features, :437-476
                 if (merged.mse < cyl.mse[segId])
                 {
@@ -1761,6 +1767,13 @@ void cape_oracle_get_labels(void* h, int32_t* plane, int32_t* cyl)
     Handle* H = static_cast<Handle*>(h);
     std::memcpy(plane, H->res.planeLabels.data(), H->res.planeLabels.size() * sizeof(int32_t));
     std::memcpy(cyl, H->res.cylLabels.data(), H->res.cylLabels.size() * sizeof(int32_t));
+}
+
+void cape_oracle_log_counts(void* h, int* invalid_seed, int* not_planar_after_merge)
+{
+    Handle* H = static_cast<Handle*>(h);
+    *invalid_seed = H->res.logInvalidSeed;
+    *not_planar_after_merge = H->res.logNotPlanarAfterMerge;
 }
 
 int cape_oracle_num_seeds(void* h) { return static_cast<int>(static_cast<Handle*>(h)->res.seeds.size()); }

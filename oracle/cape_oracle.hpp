@@ -88,6 +88,9 @@ struct FrameResult
     std::vector<int32_t> seeds;          // seed ids in the order they were tried
     std::vector<int32_t> seedOutcome;    // 0 none/too small, 1 plane, 2 cylinder branch, 3 dropped (score<=100), 4 not planar after merge
     std::vector<uint32_t> seedActivated; // activated cell count per seed
+    // the hot path's log lines (outputs::log / log_warning), counted: what a log callback of the drop-in must reproduce
+    int logInvalidSeed = 0;       // "Could not find a single plane segment: invalid seed", primitive_detection.cpp:302
+    int logNotPlanarAfterMerge = 0; // "Plane segment is not planar after merge", :374 (grown region) and :497 (cylinder sub-segment)
 };
 
 class Oracle

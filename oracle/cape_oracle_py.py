@@ -46,6 +46,7 @@ def lib(path=None):
         L.cape_oracle_get_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cape_oracle_num_seeds.argtypes = [C.c_void_p]
         L.cape_oracle_get_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cape_oracle_log_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.cape_oracle_num_plane_segments.argtypes = [C.c_void_p]
         L.cape_oracle_get_plane_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cape_oracle_num_planes.argtypes = [C.c_void_p]
@@ -126,6 +127,9 @@ class Oracle:
         r.seed_activated = np.zeros(ns, np.uint32)
         if ns:
             self.L.cape_oracle_get_seeds(self.h, _p(r.seeds), _p(r.seed_outcome), _p(r.seed_activated))
+        a, b = C.c_int(0), C.c_int(0)
+        self.L.cape_oracle_log_counts(self.h, C.byref(a), C.byref(b))
+        r.log_invalid_seed, r.log_not_planar_after_merge = a.value, b.value  # the reference's log lines, counted
         P = self.L.cape_oracle_num_plane_segments(self.h)
         r.segments = np.zeros((P, 20), np.float64)
         r.merge_labels = np.zeros(P, np.uint32)

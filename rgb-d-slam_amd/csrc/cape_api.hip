@@ -184,6 +184,11 @@ struct cape_handle_s
     size_t evPending = 0;           // triples [0, evPending) hold unread measurements
     bool timing = false;
     cape_timings tm{};
+    unsigned long long* phaseTicks = nullptr; // device, 4 u64: ticks in grow / merge / refine of the timed calls (StageBParams::phaseTicks)
+    // cape_set_log_callback
+    cape_log_fn logFn = nullptr;
+    void* logUser = nullptr;
+    bool logPending = false; // a batch has been extracted whose records have not been through the callback yet
     // sub-batch pipelining (cfg.sub_batches > 1)
     hipStream_t pipeStream[2] = {nullptr, nullptr};
     hipEvent_t pipeFork = nullptr;
@@ -276,6 +281,7 @@ void free_all(cape_handle_s* h)
     if (h->handedOverReady)
         (void)hipEventDestroy(h->handedOverReady);
     (void)hipFree(h->debugCycles);
+    (void)hipFree(h->phaseTicks);
     (void)hipFree(h->countScratch);
     (void)hipFree(h->polyLadder);
     (void)hipFree(h->matchesExact);
@@ -541,6 +547,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
             CAPE_HIP_TRY(hipEventRecord(t->e[2], st));
     }
     cape::StageBParams bb = b;
+    bb.phaseTicks = t ? h->phaseTicks : nullptr; // the reference's grow / merge / refine buckets, only while timing is on
     bb.a2RowsPerTile = strips ? a.vCells : cape::cell_plane_rows_per_tile(a, frames);
     bb.countersCleared = 1;
     // The one-frame chain: stage A, then ONE grow kernel -- the 64-segment instance on every frame of the call, no
@@ -668,7 +675,55 @@ int fold_timings(cape_handle_s* h)
         h->tm.calls += 1;
     }
     h->evPending = 0;
+    // the reference's buckets: stage B's event time split by the ticks its waves booked (all timed calls since the last reset)
+    h->tm.reset_s = 0.0;
+    h->tm.init_s = h->tm.cell_fit_s;
+    h->tm.grow_phase_s = h->tm.grow_s;
+    h->tm.merge_s = h->tm.refine_s = 0.0;
+    if (h->phaseTicks && h->tm.calls > 0)
+    {
+        unsigned long long ticks[4] = {0, 0, 0, 0};
+        CAPE_HIP_TRY(hipMemcpy(ticks, h->phaseTicks, sizeof ticks, hipMemcpyDeviceToHost));
+        const double all = (double)ticks[0] + (double)ticks[1] + (double)ticks[2];
+        if (all > 0)
+        {
+            h->tm.merge_s = h->tm.grow_s * ((double)ticks[1] / all);
+            h->tm.refine_s = h->tm.grow_s * ((double)ticks[2] / all);
+            h->tm.grow_phase_s = h->tm.grow_s - h->tm.merge_s - h->tm.refine_s;
+        }
+    }
     return CAPE_OK;
+}
+
+// the reference's hot-path log lines of one frame, from its record (cape_set_log_callback)
+int log_frame(cape_log_fn fn, void* user, const cape_frame_record& r, int frame)
+{
+    int lines = 0;
+    const uint32_t st = r.header.status;
+    // grow_planes_and_cylinders comes first in the reference (the seed loop's lines, in the order they fall; only their NUMBER
+    // travels in the record), add_planes_to_primitives behind it
+    for (uint32_t k = 0; k < CAPE_FRAME_NOT_PLANAR_COUNT(st); ++k, ++lines)
+        fn(0, "Plane segment is not planar after merge", frame, user);
+    if (st & CAPE_FRAME_INVALID_SEED) // ends the seed loop: the last line of the grow step
+        fn(1, "Could not find a single plane segment: invalid seed", frame, user), ++lines;
+    const int n = r.header.n_plane_segments < CAPE_MAX_PLANES ? r.header.n_plane_segments : CAPE_MAX_PLANES;
+    for (int i = 0; i < n; ++i)
+    {
+        const cape_plane_segment& s = r.segments[i];
+        if (s.merge_label == (uint32_t)i && s.planar && s.boundary_count < 3)
+            fn(1, "Could not find a correct boundary polygon, rejecting plane segment", frame, user), ++lines;
+    }
+    if (st & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
+        fn(1, "find_primitives: per-frame capacity exceeded, primitive list truncated", frame, user), ++lines;
+    return lines;
+}
+void log_batch(cape_handle_s* h, const cape_frame_record* records, int n)
+{
+    if (!h->logFn || !h->logPending || !records)
+        return;
+    h->logPending = false;
+    for (int f = 0; f < n && f < h->lastFrames; ++f)
+        (void)log_frame(h->logFn, h->logUser, records[f], f);
 }
 
 } // namespace
@@ -800,6 +855,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     }
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
+    CAPE_ALLOC(dalloc(h->phaseTicks, 4));
+    CAPE_ALLOC(hipMemset(h->phaseTicks, 0, 4 * 8));
     h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
     if (h->resultsOnHost)
     {
@@ -967,6 +1024,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     if (const char* sched = std::getenv("CAPE_SCHEDULE"))
         h->forcedSchedule = std::string(sched) == "two" ? 1 : (std::string(sched) == "single" ? 2 : 0);
     b.debugCycles = h->debugCycles;
+    b.phaseTicks = nullptr; // set per launch (launch_chain) while timing is on
     b.seed_sequence = h->seedSeq;
     b.rngTable = h->rng;
     b.rngCount = kRngTable;
@@ -1043,6 +1101,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     if ((depth_dev && reinterpret_cast<uintptr_t>(depth_dev) % 16 != 0) || (depth_u16 && reinterpret_cast<uintptr_t>(depth_u16) % 8 != 0))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "depth must be aligned to four pixels (16 bytes of float32, 8 bytes of uint16)");
     h->lastFrames = n_frames;
+    h->logPending = n_frames > 0; // cape_set_log_callback: this batch's records have not reached the host yet
     h->polygonFrames = 0; // the polygons on the device belong to the previous batch
     h->matchExactFrames = 0; // and so do the polygon matches
     if (n_frames == 0)
@@ -1100,6 +1159,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
             b.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, f1 - f0);
             b.countersCleared = 1;
+            b.phaseTicks = t ? h->phaseTicks : nullptr;
             CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));
@@ -1241,6 +1301,7 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
             return rc;
         if (records)
             std::memcpy(records, h->records, n * sizeof(cape_frame_record));
+        log_batch(h, records ? h->records : nullptr, n_frames);
         if (plane_labels)
             std::memcpy(plane_labels, h->planeLabels, n * C * sizeof(int32_t));
         if (cyl_labels)
@@ -1252,6 +1313,7 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
     CAPE_HIP_TRY(hipDeviceSynchronize());
     if (records)
         CAPE_HIP_TRY(hipMemcpy(records, h->records, n * sizeof(cape_frame_record), hipMemcpyDeviceToHost));
+    log_batch(h, records, n_frames);
     if (plane_labels)
         CAPE_HIP_TRY(hipMemcpy(plane_labels, h->planeLabels, n * C * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (cyl_labels)
@@ -1271,6 +1333,7 @@ int cape_host_results(cape_handle h, const cape_frame_record** records, const in
     CAPE_ON_DEVICE(h);
     if (const int rc = wait_results(h); rc != CAPE_OK)
         return rc;
+    log_batch(h, h->records, h->lastFrames);
     if (records)
         *records = h->records;
     if (plane_labels)
@@ -2132,6 +2195,25 @@ int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* ticket
     return CAPE_OK;
 }
 
+int cape_log_records(const cape_frame_record* records, int32_t n_frames, cape_log_fn fn, void* user)
+{
+    if (!records || !fn || n_frames < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null records / callback or negative frame count");
+    int lines = 0;
+    for (int f = 0; f < n_frames; ++f)
+        lines += log_frame(fn, user, records[f], f);
+    return lines;
+}
+
+int cape_set_log_callback(cape_handle h, cape_log_fn fn, void* user)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    h->logFn = fn;
+    h->logUser = user;
+    return CAPE_OK;
+}
+
 int cape_enable_timing(cape_handle h, int32_t enable)
 {
     if (!h)
@@ -2159,6 +2241,8 @@ int cape_reset_timings(cape_handle h)
     CAPE_ON_DEVICE(h);
     const int rc = fold_timings(h);
     h->tm = cape_timings{};
+    if (h->phaseTicks)
+        CAPE_HIP_TRY(hipMemset(h->phaseTicks, 0, 4 * 8));
     return rc;
 }
 

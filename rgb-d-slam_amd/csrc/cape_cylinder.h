@@ -598,6 +598,8 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
         const double cnt = readlane_f64(chain, 25);
         PlaneFit f;
         fit_plane(S, (uint32_t)cnt, f);
+        if (!f.planar)
+            status_count_not_planar(status); // "Plane segment is not planar after merge" (:497); the model selection still runs
         CAPE_CYL_TICK(21); // merged plane fit
         CAPE_CYL_COUNT(24, 1);          // RANSAC rounds (outer while)
         CAPE_CYL_COUNT(25, N);          // cells of the region

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/cape_hip.h"
+
 namespace cape {
 
 constexpr int kCell = 20;
@@ -411,6 +413,20 @@ __device__ __forceinline__ bool can_be_merged(double pnx, double pny, double pnz
     const double cosAngle = dot3(pnx, pny, pnz, cnx, cny, cnz);
     const double dist = dot3(pnx, pny, pnz, ccx, ccy, ccz) + pd;
     return (cosAngle > cosMerge) & (fabs(dist) < maxDist); // no short-circuit: keeps the callers branch-free
+}
+
+// "Plane segment is not planar after merge" (primitive_detection.cpp:374, :497): counted in bits 8..15 of the frame's status.  Every
+// lane of the frame holds the SAME count (the callers bump it in uniform control flow), so the OR-fold of the status keeps it.
+__device__ __forceinline__ void status_count_not_planar(uint32_t& status)
+{
+    if (CAPE_FRAME_NOT_PLANAR_COUNT(status) < 255u)
+        status += 1u << CAPE_FRAME_NOT_PLANAR_SHIFT;
+}
+// a parked frame's status: the flag bits live in lane 0 (the fold ORs them back), the count in every lane
+__device__ __forceinline__ uint32_t status_resume(uint32_t parked, bool first)
+{
+    const uint32_t count = parked & (0xFFu << CAPE_FRAME_NOT_PLANAR_SHIFT);
+    return (first ? (parked & ~count) : 0u) | count;
 }
 
 } // namespace cape

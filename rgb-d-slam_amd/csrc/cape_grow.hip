@@ -70,6 +70,13 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
     }
     unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
     const int C = p.cells, HC = p.hCells, VC = p.vCells;
+    // timing on: the wave's ticks from here to grow_tail -- or to the point where it hands its frame on -- are the reference's
+    // _growTime (grow_planes_and_cylinders); grow_tail books merge and refine
+    const unsigned long long tPhase = p.phaseTicks ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
+    auto book_grow_ticks = [&]() {
+        if (p.phaseTicks && lane == 0)
+            atomicAdd(&p.phaseTicks[0], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
+    };
     const size_t cellBase = (size_t)frame * C;
 
     // ---- LDS carve (every offset a multiple of 8; grow_lds_bytes() mirrors it).  The RESUME instance has no histogram, bins
@@ -329,7 +336,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
         nSeeds = hd.nSeeds;
         nPlanar = hd.nPlanar;
         untried = 0;
-        status = lane == 0 ? hd.status : 0u;
+        status = status_resume(hd.status, lane == 0);
         const int nRec = hd.pendCount - hd.pendFrom;
         for (int i = lane; i < nSeg * kSegDoubles; i += 64)
             s_seg[i] = gseg[i];
@@ -437,6 +444,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                 if (__longlong_as_double((long long)bestAll) >= kDblMax)
                 {
                     moreSeeds = false; // "invalid seed" (:299-304)
+                    status |= CAPE_FRAME_INVALID_SEED;
                     break;
                 }
                 if (lane == 0 && p.seed_sequence && nSeeds < C)
@@ -598,7 +606,10 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                 const unsigned long long meta = s_adj[j];
                 const int roff = (int)(unsigned)meta, total = (int)(meta >> 32);
                 if (ns.planar == 0.0)
-                    continue; // "Plane segment is not planar after merge"
+                {
+                    status_count_not_planar(status); // "Plane segment is not planar after merge" (:374)
+                    continue;
+                }
                 if (ns.score > 100)
                 {
                     if (nSeg >= MAXP)
@@ -608,6 +619,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                             // out of LDS segment slots: the 64-segment instance redoes this frame from the start
                             if (lane == 0)
                                 p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                            book_grow_ticks();
                             return;
                         }
                         status |= CAPE_FRAME_PLANE_OVERFLOW;
@@ -681,6 +693,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                     }
                     else if (lane == 0)
                         p.needCylinder[1 + atomicAdd(&p.needCylinder[0], 1u)] = (uint32_t)frame;
+                    book_grow_ticks();
                     return;
                 }
                 else if (CYL && total > 5)
@@ -720,6 +733,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                         {
                             if (lane == 0)
                                 p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                            book_grow_ticks();
                             return;
                         }
                         status |= CAPE_FRAME_PLANE_OVERFLOW;
@@ -766,7 +780,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
 #else
         L.s_prof = nullptr;
 #endif
-        grow_tail<MaskT, CYL, MAXP>(p, frame, lane, L, nSeg, nCylLabels, nSeeds, nPlanar, status);
+        grow_tail<MaskT, CYL, MAXP>(p, frame, lane, L, nSeg, nCylLabels, nSeeds, nPlanar, status, tPhase);
     }
 #ifdef CAPE_B_PROFILE
     CAPE_WAVE_SYNC();

@@ -224,8 +224,17 @@ struct GrowTailLds
 
 template <typename MaskT, bool CYL, int MAXP>
 __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame, const int lane, const GrowTailLds& L, const int nSeg,
-                                          const int nCylLabels, const int nSeeds, const int nPlanar, uint32_t status)
+                                          const int nCylLabels, const int nSeeds, const int nPlanar, uint32_t status,
+                                          const unsigned long long tPhase = 0ull)
 {
+    // stage buckets of the reference (timing on): everything up to here was grow_planes_and_cylinders
+    unsigned long long tMerge = 0ull;
+    if (p.phaseTicks)
+    {
+        tMerge = __builtin_amdgcn_s_memtime();
+        if (lane == 0)
+            atomicAdd(&p.phaseTicks[0], tMerge - tPhase);
+    }
     double* const s_seg = L.s_seg;
     unsigned long long* const s_adj = L.s_adj;
     unsigned char* const s_mlab = L.s_mlab;
@@ -313,6 +322,13 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
     }
 
     CAPE_TICK(10);
+    unsigned long long tRefine = 0ull;
+    if (p.phaseTicks)
+    {
+        tRefine = __builtin_amdgcn_s_memtime();
+        if (lane == 0)
+            atomicAdd(&p.phaseTicks[1], tRefine - tMerge);
+    }
     // =========================================================================================
     // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
     // =========================================================================================
@@ -543,6 +559,8 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
         rec->header.n_seeds = nSeeds;
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
+        if (p.phaseTicks)
+            atomicAdd(&p.phaseTicks[2], (unsigned long long)__builtin_amdgcn_s_memtime() - tRefine);
     }
 }
 

@@ -119,6 +119,11 @@ struct StageBParams
                              // per frame (the RESUME instance of the grow kernel; kept for A/B runs: CAPE_RESUME=wave)
     int twoPass;             // 0: the cylinder kernel grows every frame itself (chosen when most frames were handed over)
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
+    // The reference's stage buckets inside stage B (primitive_detection.cpp:140-160): shader-clock ticks every frame's wave spent
+    // in [0] grow_planes_and_cylinders, [1] merge_planes, [2] add_planes / add_cylinders_to_primitives, summed over the timed calls
+    // (three fire-and-forget atomics per frame); nullptr unless the handle's timing is on.  cape_get_timings splits the grow
+    // kernels' event time in these proportions.
+    unsigned long long* phaseTicks;
     int countersCleared;     // 1: stage A2 zeroed redoList[0] / needCylinder[0] (StageAParams::clear0/1); 0: launch_grow does
     int a2RowsPerTile;       // cell rows per workgroup of stage A2: the vertical edges into rows k * a2RowsPerTile are evaluated here
     uint16_t* seed_sequence; // [frames][cells] seed cells in the order the seed loop tried them (first n_seeds entries valid)

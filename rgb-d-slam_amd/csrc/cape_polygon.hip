@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
 #define CAPE_POLY_QUEUE_PER_FRAME (6 * CAPE_MAX_PLANES)
 #endif
 constexpr size_t kPolyQuitSlots = CAPE_POLY_QUIT_SLOTS;          // one kTaskQuit per wave of the task kernel's grid behind the last task
-constexpr size_t kPolyQueuePerFrame = CAPE_POLY_QUEUE_PER_FRAME; // rungs 2 .. 7 of every plane of a frame: each is spawned at most once
+[[maybe_unused]] constexpr size_t kPolyQueuePerFrame = CAPE_POLY_QUEUE_PER_FRAME; // rungs 2 .. 7 of every plane of a frame: each is spawned at most once
 #ifdef CAPE_POLY_QUEUE_LEN
 // test build: a queue of CAPE_POLY_QUEUE_LEN slots whatever the batch, so that spawned rungs overflow it (the grid keeps its size)
 size_t polygon_queue_slots(size_t) { return CAPE_POLY_QUEUE_LEN; }

@@ -647,6 +647,8 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
         // ===== cylinder_fitting's per-segment work (primitive_detection.cpp:488-500): merged plane of the inlier cells
         PlaneFit f;
         fit_plane(S, (uint32_t)cnt, f);
+        if (!f.planar)
+            status_count_not_planar(status); // "Plane segment is not planar after merge" (:497); the model selection still runs
         CAPE_GTICK(21); // merged plane fit
         CAPE_GCOUNT(24, 1);          // RANSAC rounds (outer while)
         CAPE_GCOUNT(25, N);          // cells of the region
@@ -750,6 +752,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
     const int frame = resume_pick(p, (int)blockIdx.x); // the grid is sized for the worst case; the k-th workgroup takes the k-th parked frame
     if (frame < 0)
         return;
+    const unsigned long long tPhase = p.phaseTicks ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; // (see grow_frame_wave)
     constexpr int MAXP = kFastPlanes;
     const int C = p.cells;
     const size_t cellBase = (size_t)frame * C;
@@ -786,7 +789,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
     const unsigned char* glab = st + grow_state_lab_off(C);
     int nSeg = hd.nSeg;
     const int nSeeds = hd.nSeeds, nPlanar = hd.nPlanar;
-    uint32_t status = tid == 0 ? hd.status : 0u;
+    uint32_t status = status_resume(hd.status, tid == 0);
     const int nRec = hd.pendCount - hd.pendFrom;
     for (int i = tid; i < nSeg * kSegDoubles; i += kGroupThreads)
         s_seg[i] = gseg[i];
@@ -816,7 +819,10 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
         const unsigned long long meta = s_adj[j];
         const int roff = (int)(unsigned)meta, total = (int)(meta >> 32);
         if (ns.planar == 0.0)
-            continue; // "Plane segment is not planar after merge"
+        {
+            status_count_not_planar(status); // "Plane segment is not planar after merge" (:374)
+            continue;
+        }
         bool overflow = false;
         if (ns.score > 100)
         {
@@ -866,7 +872,11 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
             if (p.redoList)
             {
                 if (tid == 0)
+                {
                     p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                    if (p.phaseTicks)
+                        atomicAdd(&p.phaseTicks[0], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
+                }
                 handedOn = true;
             }
             else
@@ -893,7 +903,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
     L.s_zc = s_zc;
     L.s_ring = reinterpret_cast<unsigned short*>(s_stage);
     L.s_prof = s_prof;
-    grow_tail<MaskT, true, MAXP>(p, frame, lane, L, nSeg, nCylLabels, nSeeds, nPlanar, status);
+    grow_tail<MaskT, true, MAXP>(p, frame, lane, L, nSeg, nCylLabels, nSeeds, nPlanar, status, tPhase);
 #ifdef CAPE_B_PROFILE
     CAPE_WAVE_SYNC();
     if (lane < kProfileSlots)

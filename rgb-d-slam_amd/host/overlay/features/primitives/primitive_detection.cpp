@@ -129,8 +129,33 @@ struct PolygonPool
     bool stop = false;
 };
 
+namespace {
+// cape_set_log_callback: the lines the reference's find_primitives logs on the hot path (decided on the device, carried by the
+// frame record) and the library's capacity warnings, through the reference's logger
+void forward_log(int32_t level, const char* message, int32_t /*frame*/, void* /*user*/)
+{
+    if (level >= 2)
+        outputs::log_error(message);
+    else if (level == 1)
+        outputs::log_warning(message);
+    else
+        outputs::log(message);
+}
+} // namespace
+
+void Primitive_Detection::set_detailed_statistics(bool on) noexcept
+{
+    _detailedStatistics = on;
+    if (_single.handle)
+        cape_enable_timing(_single.handle, on ? 1 : 0);
+    for (Shard& s : _shards)
+        cape_enable_timing(s.handle, on ? 1 : 0);
+}
+
 Primitive_Detection::Primitive_Detection(const uint width, const uint height) : _width(width), _height(height)
 {
+    if (const char* env = std::getenv("CAPE_DETAILED_STATISTICS"))
+        _detailedStatistics = env[0] == '1';
     Plane_Segment::set_static_members(parameters::detection::depthMapPatchSize_px,
                                       parameters::detection::depthMapPatchSize_px * parameters::detection::depthMapPatchSize_px);
     int devices = 0;
@@ -174,6 +199,9 @@ bool Primitive_Detection::make_shard(Shard& s, int device, int maxBatch) noexcep
             s.handle = nullptr;
             return false;
         }
+        cape_set_log_callback(s.handle, &forward_log, nullptr);
+        if (_detailedStatistics)
+            cape_enable_timing(s.handle, 1);
         cape_layout lay {};
         cape_get_layout(s.handle, &lay);
         _cells = lay.cells;
@@ -222,8 +250,8 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
     planes.clear();
     cylinders.clear();
     const cape_frame_record& r = shard.records[f];
-    if (r.header.status & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
-        outputs::log_warning("find_primitives: per-frame capacity exceeded, primitive list truncated");
+    // (the frame's log lines -- invalid seed, not planar after merge, rejected boundary, capacity -- came through forward_log when
+    //  the record reached the host)
     planes.reserve(r.header.n_planes);
     const double* bnd = shard.boundary ? shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3 : nullptr;
     // the output planes whose polygon the host class builds (one-frame calls, CAPE_POLY_OVERFLOW planes of a batch): built side
@@ -523,8 +551,10 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
 {
     try
     {
+        const auto tr = std::chrono::steady_clock::now();
         planeContainer.clear();
         primitiveContainer.clear();
+        _hostResetTime += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr).count(); // all reset_data() leaves to do
         if (depthImage.rows != static_cast<int>(_height) || depthImage.cols != static_cast<int>(_width))
         {
             outputs::log_error("find_primitives: depth image size differs from the configured size");
@@ -544,8 +574,11 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
             outputs::log_error("find_primitives: " + _single.error);
             return;
         }
+        const auto t1 = std::chrono::steady_clock::now();
         collect(_single, 0, planeContainer, primitiveContainer); // in place, like emplace_back at primitive_detection.cpp:627
-        _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const auto t2 = std::chrono::steady_clock::now();
+        _hostRefineTime += std::chrono::duration<double>(t2 - t1).count();
+        _meanPrimitiveTreatmentDuration += std::chrono::duration<double>(t2 - t0).count();
     }
     catch (const std::exception& e)
     {
@@ -686,15 +719,35 @@ void Primitive_Detection::show_statistics(const double meanFrameTreatmentDuratio
     std::snprintf(buf, sizeof buf, "\tMean primitive extraction time is %.4f seconds (%.2f%%)", mean,
                   percent(mean, meanFrameTreatmentDuration));
     outputs::log(buf);
-    if (shouldDisplayDetails && _single.handle)
-    {
+    if (!shouldDisplayDetails)
+        return;
+    // the reference's five buckets (:87-115), per frame: device seconds of every handle (HIP events; stage B's kernels split into
+    // grow / merge / refine by the ticks their waves booked, cape_timings) + the host's own share of reset and refine
+    double reset = _hostResetTime, init = 0.0, grow = 0.0, merge = 0.0, refine = _hostRefineTime;
+    uint64_t timedCalls = 0;
+    auto add = [&](cape_handle handle) {
         cape_timings t {};
-        if (cape_get_timings(_single.handle, &t) == CAPE_OK && t.calls > 0)
+        if (handle && cape_get_timings(handle, &t) == CAPE_OK)
         {
-            std::snprintf(buf, sizeof buf, "\t\tMean primitive init time is %.6f seconds, grow+merge+refine %.6f seconds (device, per call)",
-                          t.cell_fit_s / t.calls, t.grow_s / t.calls);
-            outputs::log(buf);
+            reset += t.reset_s, init += t.init_s, grow += t.grow_phase_s, merge += t.merge_s, refine += t.refine_s;
+            timedCalls += t.calls;
         }
+    };
+    add(_single.handle);
+    for (const Shard& s : _shards)
+        add(s.handle);
+    if (timedCalls == 0)
+    {
+        outputs::log("\t\t(stage details need set_detailed_statistics(true) or CAPE_DETAILED_STATISTICS=1 before the frames are treated)");
+        return;
+    }
+    const double n = static_cast<double>(frameCount);
+    const std::pair<const char*, double> buckets[5] = {{"reset", reset / n}, {"init", init / n}, {"grow", grow / n}, {"merge", merge / n},
+                                                       {"refine", refine / n}};
+    for (const auto& b : buckets)
+    {
+        std::snprintf(buf, sizeof buf, "\t\tMean primitive %s time is %.4f seconds (%.2f%%)", b.first, b.second, percent(b.second, mean));
+        outputs::log(buf);
     }
 }
 

@@ -67,6 +67,10 @@ class Primitive_Detection
     void set_chunk_frames(int frames) noexcept { _maxBatch = frames > 8 ? frames : 9; }
     // batches: boundary polygons on the device (default) or with the host class, plane by plane (A/B runs, tests)
     void set_device_polygons(bool on) noexcept { _devicePolygons = on; }
+    // The five buckets show_statistics(.., shouldDisplayDetails = true) prints -- reset / init / grow / merge / refine,
+    // primitive_detection.cpp:69-117 -- need HIP events around the kernels and three atomics per frame inside the grow kernel
+    // (cape_enable_timing): a few microseconds on the one-frame call, hence opt-in (also: environment CAPE_DETAILED_STATISTICS=1).
+    void set_detailed_statistics(bool on) noexcept;
     [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
 
     // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
@@ -161,6 +165,9 @@ class Primitive_Detection
     mutable std::unique_ptr<PolygonPool> _polygonPool; // created at the first frame that shows three or more planes
     mutable std::vector<Shard> _shards;    // batch shards (max_batch = set_chunk_frames each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
+    mutable double _hostRefineTime = 0.0;  // seconds the host spent in collect(): containers + the polygons it builds itself (part of _refineTime)
+    mutable double _hostResetTime = 0.0;   // seconds spent clearing the output containers (the host's share of reset_data)
+    bool _detailedStatistics = false;
 
     // remove copy functions, like the reference (primitive_detection.hpp:228-230)
     Primitive_Detection(const Primitive_Detection&) = delete;

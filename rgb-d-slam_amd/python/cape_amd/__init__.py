@@ -47,7 +47,19 @@ class cape_layout(C.Structure):
 class cape_timings(C.Structure):
     _fields_ = [("cell_fit_s", C.c_double), ("cell_moments_s", C.c_double), ("cell_plane_s", C.c_double),
                 ("grow_s", C.c_double), ("total_s", C.c_double),
-                ("frames", C.c_uint64), ("calls", C.c_uint64)]
+                ("frames", C.c_uint64), ("calls", C.c_uint64),
+                # the reference's five buckets (primitive_detection.cpp:126-160)
+                ("reset_s", C.c_double), ("init_s", C.c_double), ("grow_phase_s", C.c_double), ("merge_s", C.c_double),
+                ("refine_s", C.c_double)]
+
+
+LOG_FN = C.CFUNCTYPE(None, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p)  # cape_log_fn
+FRAME_INVALID_SEED = 1 << 7
+
+
+def frame_not_planar_count(status):
+    """CAPE_FRAME_NOT_PLANAR_COUNT: how often the frame logged "Plane segment is not planar after merge"."""
+    return (int(status) >> 8) & 0xFF
 
 
 # numpy mirrors of the record structs (natural C alignment; checked against frame_record_bytes at create)
@@ -130,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "cape_match_polygons", "cape_match_polygons_pose", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
-    "cape_debug_polygon_queue",
+    "cape_debug_polygon_queue", "cape_set_log_callback", "cape_log_records",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -176,6 +188,8 @@ def load_library():
     L.cape_enable_timing.argtypes = [vp, C.c_int32]
     L.cape_get_timings.argtypes = [vp, C.POINTER(cape_timings)]
     L.cape_reset_timings.argtypes = [vp]
+    L.cape_set_log_callback.argtypes = [vp, LOG_FN, vp]
+    L.cape_log_records.argtypes = [vp, C.c_int32, LOG_FN, vp]
     L.cape_gather_configure.argtypes = [vp, C.POINTER(cape_gather_config), C.POINTER(cape_gather_layout)]
     L.cape_pack_primitives.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), vp]
     L.cape_copy_packed.argtypes = [vp, vp]
@@ -489,7 +503,17 @@ class Extractor:
         t = cape_timings()
         _check(self.L, self.L.cape_get_timings(self.h, C.byref(t)), "cape_get_timings")
         return dict(cell_fit_s=t.cell_fit_s, cell_moments_s=t.cell_moments_s, cell_plane_s=t.cell_plane_s,
-                    grow_s=t.grow_s, total_s=t.total_s, frames=t.frames, calls=t.calls)
+                    grow_s=t.grow_s, total_s=t.total_s, frames=t.frames, calls=t.calls,
+                    reset_s=t.reset_s, init_s=t.init_s, grow_phase_s=t.grow_phase_s, merge_s=t.merge_s, refine_s=t.refine_s)
+
+    def set_log_callback(self, fn):
+        """fn(level, message, frame) gets the reference's hot-path log lines when a batch's records first reach the host
+        (cape_set_log_callback); None removes it."""
+        if fn is None:
+            self._log_cb = LOG_FN(0)
+        else:
+            self._log_cb = LOG_FN(lambda level, msg, frame, _user: fn(int(level), msg.decode(), int(frame)))
+        _check(self.L, self.L.cape_set_log_callback(self.h, self._log_cb, None), "cape_set_log_callback")
 
 
 def debug_eval(op, a, b=None):
@@ -503,4 +527,17 @@ def debug_eval(op, a, b=None):
     _check(L, L.cape_debug_eval(DEBUG_OPS[op], a.ctypes.data_as(C.c_void_p),
                                 bb.ctypes.data_as(C.c_void_p) if bb is not None else None,
                                 out.ctypes.data_as(C.c_void_p), n), "cape_debug_eval")
+    return out
+
+
+def log_records(records):
+    """cape_log_records: the reference's hot-path log lines [(level, message, frame)] of host frame records (no device needed)."""
+    L = load_library()
+    rec = np.ascontiguousarray(records)
+    out = []
+    cb = LOG_FN(lambda level, msg, frame, _user: out.append((int(level), msg.decode(), int(frame))))
+    n = L.cape_log_records(rec.ctypes.data_as(C.c_void_p), len(rec), cb, None)
+    if n < 0:
+        raise CapeError(f"cape_log_records: {L.cape_last_error().decode()}")
+    assert n == len(out)
     return out

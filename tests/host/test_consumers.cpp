@@ -12,9 +12,12 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <future>
 #include <memory>
+#include <string>
 #include <unordered_set>
+#include <utility>
 #include <vector>
 
 #include "outputs/logger.hpp"
@@ -202,6 +205,9 @@ int main()
     // rgbd_slam.cpp:291-297, 315: the extraction runs on a std::async thread and returns the container by value.
     // Without a GPU the detector is "not ready" and yields no primitives -- it must not throw, exit or compute on the CPU.
     auto detector = std::make_unique<prim::Primitive_Detection>(640, 480);
+    detector->set_detailed_statistics(true); // the five stage buckets of show_statistics(.., true)
+    static std::vector<std::pair<int, std::string>> logged; // what reaches the reference's logger from here on
+    outputs::set_log_callback([](int level, const std::string& message) { logged.emplace_back(level, message); });
     auto depthOps = std::make_unique<prim::Depth_Map_Transformation>(640, 480, parameters::detection::depthMapPatchSize_px);
     std::vector<float> pixels(640 * 480, 1500.0f);
     const prim::depth_image depthImage(480, 640, pixels.data());
@@ -216,6 +222,66 @@ int main()
     });
     const prim::plane_container got = planeHandler.get();
     detector->show_statistics(0.01, 1, false);
+    if (detector->is_ready())
+    {
+        // a real frame (a room corner: three planes), so that every stage has something to do
+        std::vector<float> room(640 * 480);
+        for (int v = 0; v < 480; ++v)
+            for (int u = 0; u < 640; ++u)
+            {
+                const double x = (u - 320.0) / 550.0, y = (v - 240.0) / 550.0;
+                double z = 3000.0;                              // back wall
+                if (x > 0.05)
+                    z = std::min(z, 1500.0 / x * 0.4);          // right wall at X = 600 mm
+                if (y > 0.05)
+                    z = std::min(z, 1200.0 / y * 0.4);          // floor at Y = 480 mm
+                room[v * 640 + u] = static_cast<float>(std::floor(z + 0.5 * std::sin(0.37 * u + 0.91 * v)));
+            }
+        const prim::depth_image roomImage(480, 640, room.data());
+        prim::plane_container planes;
+        prim::cylinder_container cylinders;
+        logged.clear();
+        for (int k = 0; k < 3; ++k)
+            detector->find_primitives(cloudArrayOrganized, roomImage, planes, cylinders);
+        if (planes.size() < 2)
+            return 13;
+        for (const auto& ln : logged) // a clean frame logs nothing: no capacity warning, no rejected boundary
+            if (ln.first >= 1)
+                return 14;
+        logged.clear();
+        detector->show_statistics(0.01, 4, true);
+        // primitive_detection.cpp:80-115: the summary line, then reset / init / grow / merge / refine in this order
+        const char* wanted[6] = {"\tMean primitive extraction time is ", "\t\tMean primitive reset time is ", "\t\tMean primitive init time is ",
+                                 "\t\tMean primitive grow time is ", "\t\tMean primitive merge time is ", "\t\tMean primitive refine time is "};
+        if (logged.size() != 6)
+            return 15;
+        for (int k = 0; k < 6; ++k)
+            if (logged[k].first != 0 || logged[k].second.rfind(wanted[k], 0) != 0 || logged[k].second.find(" seconds (") == std::string::npos)
+                return 16;
+    }
+    else
+    {
+        logged.clear();
+        detector->show_statistics(0.01, 1, true); // no device, no timed call: the summary line and one explanatory line
+        if (logged.size() != 2)
+            return 17;
+    }
+    // cape_log_records: the reference's hot-path lines from a frame record, host code only (cape_set_log_callback feeds the same
+    // function when a batch's records reach the host)
+    {
+        static cape_frame_record rec[2];
+        std::memset(rec, 0, sizeof rec);
+        rec[0].header.status = CAPE_FRAME_INVALID_SEED | (1u << CAPE_FRAME_NOT_PLANAR_SHIFT);
+        rec[1].header.n_plane_segments = 1;
+        rec[1].segments[0].planar = 1;
+        rec[1].segments[0].boundary_count = 2;
+        static std::vector<std::string> lines;
+        const int n = cape_log_records(rec, 2, [](int32_t, const char* m, int32_t, void*) { lines.emplace_back(m); }, nullptr);
+        if (n != 3 || lines.size() != 3 || lines[0] != "Plane segment is not planar after merge" ||
+            lines[1] != "Could not find a single plane segment: invalid seed" ||
+            lines[2] != "Could not find a correct boundary polygon, rejecting plane segment")
+            return 18;
+    }
     std::printf("consumer call sites ok (detector %s, %zu planes)\n", detector->is_ready() ? "ready" : "not ready: no GPU", got.size());
     return 0;
 }

@@ -111,3 +111,47 @@ def test_unresolvable_rccl_is_an_error_not_a_crash(hip_library):
     assert out.returncode == 0, out.stderr[-800:]
     rc, msg = out.stdout.strip().split(" ", 1)
     assert int(rc) == -5 and "librccl.so not found" in msg and "/nonexistent/librccl.so" in msg
+
+
+def test_log_lines_from_frame_records(hip_library):
+    """cape_log_records / cape_set_log_callback: the lines the reference's find_primitives logs on the hot path
+    (primitive_detection.cpp:302, :374 / :497, :618) are derived from the frame record -- status bits and segment fields --
+    on the host.  Pure host code: crafted records, no GPU."""
+    import numpy as np
+
+    import cape_amd
+
+    rec = np.zeros(4, cape_amd.FRAME_RECORD_DTYPE)
+    # frame 0: nothing to say
+    rec["header"]["n_plane_segments"][0] = 2
+    rec["segments"][0]["planar"][:2] = 1
+    rec["segments"][0]["merge_label"][:2] = [0, 1]
+    rec["segments"][0]["boundary_count"][:2] = [40, 3]
+    # frame 1: two "not planar after merge", then the seed loop ends on an invalid seed
+    rec["header"]["status"][1] = cape_amd.FRAME_INVALID_SEED | (2 << 8) | (1 << 4)  # (+ an unrelated bit: CAPE_FRAME_INORDER_CELLS)
+    # frame 2: a planar merge root with two boundary points (rejected), a merged-away segment and a non-planar one that say nothing
+    rec["header"]["n_plane_segments"][2] = 3
+    rec["segments"][2]["planar"][:3] = [1, 1, 0]
+    rec["segments"][2]["merge_label"][:3] = [0, 0, 2]
+    rec["segments"][2]["boundary_count"][:3] = [2, 0, 0]
+    # frame 3: a capacity overflow (the library's own warning)
+    rec["header"]["status"][3] = 1
+    lines = cape_amd.log_records(rec)
+    assert lines == [
+        (0, "Plane segment is not planar after merge", 1), (0, "Plane segment is not planar after merge", 1),
+        (1, "Could not find a single plane segment: invalid seed", 1),
+        (1, "Could not find a correct boundary polygon, rejecting plane segment", 2),
+        (1, "find_primitives: per-frame capacity exceeded, primitive list truncated", 3)]
+    assert cape_amd.frame_not_planar_count(rec["header"]["status"][1]) == 2
+    lib = cape_amd.load_library()
+    assert lib.cape_log_records(None, 1, cape_amd.LOG_FN(0), None) == -1
+
+
+def test_timings_struct_carries_the_five_buckets(hip_library):
+    import cape_amd
+
+    names = [f[0] for f in cape_amd.cape_timings._fields_]
+    assert names[-5:] == ["reset_s", "init_s", "grow_phase_s", "merge_s", "refine_s"]  # primitive_detection.cpp:126-160
+    assert C.sizeof(cape_amd.cape_timings) == 12 * 8
+    src = open(os.path.join(ROOT, "include", "cape_hip.h")).read()
+    assert "double reset_s, init_s, grow_phase_s, merge_s, refine_s;" in src

@@ -199,3 +199,74 @@ def test_polygon_reads_refuse_a_stale_batch():
     with pytest.raises(CapeError):
         ex.polygons(3)
     ex.close()
+
+
+@pytest.mark.parametrize("cyl,batch", [(False, 96), (True, 96), (True, 1)])
+def test_timings_carry_the_references_five_buckets(cyl, batch):
+    """cape_get_timings maps the kernels onto the reference's stage buckets (find_primitives,
+    primitive_detection.cpp:126-160): reset (nothing to reset: 0), init = A1 + A2, and the stage-B kernels' event time split into
+    grow / merge / refine by the shader-clock ticks every frame's wave books in each.  Same bits with timing on (the parity suite
+    runs with it off)."""
+    import torch
+    from cape_amd import Extractor, synth, synth_gpu
+
+    dev = synth_gpu.stream("room", 12, batch, start=5, device="cuda", chunk=16)
+    st = torch.cuda.current_stream().cuda_stream
+    ex = Extractor(640, 480, cylinders=cyl, max_batch=batch, **_intr())
+    ex.extract_device(dev.data_ptr(), batch, st)
+    ref = ex.results(batch)
+    assert ex.timings()["calls"] == 0
+    ex.enable_timing(True)
+    for _ in range(3):
+        ex.extract_device(dev.data_ptr(), batch, st)
+    t = ex.timings()
+    assert t["calls"] == 3 and t["frames"] == 3 * batch
+    assert t["reset_s"] == 0.0 and t["init_s"] == t["cell_fit_s"] > 0
+    assert t["grow_phase_s"] > 0 and t["merge_s"] > 0 and t["refine_s"] > 0
+    assert abs(t["grow_phase_s"] + t["merge_s"] + t["refine_s"] - t["grow_s"]) <= 1e-9 * t["grow_s"]
+    assert t["merge_s"] < t["grow_phase_s"], "merge_planes is the short one of the three"
+    got = ex.results(batch)
+    assert got.records.tobytes() == ref.records.tobytes() and np.array_equal(got.plane_labels, ref.plane_labels)
+    ex.reset_timings()
+    z = ex.timings()
+    assert z["calls"] == 0 and z["grow_phase_s"] == 0 and z["refine_s"] == 0
+    ex.enable_timing(False)
+    ex.close()
+
+
+def test_log_callback_gets_the_batch_once(oracle_mod):
+    """cape_set_log_callback: the lines arrive when a batch's records first reach the host, once per extracted batch.  Frames that
+    overflow the boundary capacity (a handle made with a tiny one) produce the library's capacity warning; the reference's own lines
+    (invalid seed / not planar after merge) are compared with the oracle's counts by every parity test (compare_frame) and, as host
+    logic, by tests/test_abi.py::test_log_lines_from_frame_records."""
+    import ctypes as C
+
+    import cape_amd
+    from cape_amd import synth
+
+    frames = np.stack([synth.room(seed=2, frame=i) for i in range(3)])
+    lines = []
+    for max_batch in (1, 16):  # results in pinned host memory / in HBM
+        L = cape_amd.load_library()
+        cfg = cape_amd.cape_config(640, 480, 550.0, 550.0, 320.0, 240.0, 0, 0, max_batch, 8, 0)  # boundary_capacity = 8 points
+        h = C.c_void_p()
+        assert L.cape_create(C.byref(cfg), C.byref(h)) == 0
+        cb = cape_amd.LOG_FN(lambda level, msg, frame, _u: lines.append((max_batch, int(level), msg.decode(), int(frame))))
+        assert L.cape_set_log_callback(h, cb, None) == 0
+        n = min(max_batch, 3)
+        d = np.ascontiguousarray(frames[:n])
+        assert L.cape_extract_host(h, d.ctypes.data_as(C.c_void_p), n, None) == 0
+        rec = np.zeros(n, cape_amd.FRAME_RECORD_DTYPE)
+        for _ in range(2):  # the second copy of the same batch stays silent
+            assert L.cape_copy_results(h, n, rec.ctypes.data_as(C.c_void_p), None, None, None) == 0
+        assert (rec["header"]["status"] & 2).all(), "boundary capacity of 8 points must overflow on a room frame"
+        got = [ln for ln in lines if ln[0] == max_batch]
+        assert got == [(max_batch, 1, "find_primitives: per-frame capacity exceeded, primitive list truncated", f) for f in range(n)]
+        assert L.cape_extract_host(h, d.ctypes.data_as(C.c_void_p), n, None) == 0  # the next batch speaks again
+        assert L.cape_copy_results(h, n, rec.ctypes.data_as(C.c_void_p), None, None, None) == 0
+        assert len([ln for ln in lines if ln[0] == max_batch]) == 2 * n
+        assert L.cape_set_log_callback(h, cape_amd.LOG_FN(0), None) == 0
+        assert L.cape_extract_host(h, d.ctypes.data_as(C.c_void_p), n, None) == 0
+        assert L.cape_copy_results(h, n, rec.ctypes.data_as(C.c_void_p), None, None, None) == 0
+        assert len([ln for ln in lines if ln[0] == max_batch]) == 2 * n
+        L.cape_destroy(h)

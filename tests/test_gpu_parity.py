@@ -41,6 +41,9 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert np.array_equal(cs["bin"], orc_res.bins), "histogram bins"
     hdr = res.records["header"][f]
     assert hdr["n_seeds"] == len(orc_res.seeds), "seed loop length"
+    # the reference's hot-path log lines travel in the status word (cape_set_log_callback): as many as the oracle counted
+    assert bool(hdr["status"] & (1 << 7)) == (orc_res.log_invalid_seed > 0), "log: invalid seed (primitive_detection.cpp:302)"
+    assert ((int(hdr["status"]) >> 8) & 0xFF) == min(255, orc_res.log_not_planar_after_merge), "log: not planar after merge (:374, :497)"
     assert np.array_equal(ex.seed_sequence(f), orc_res.seeds), "seed sequence (cells in the order they were tried)"
     assert np.array_equal(res.plane_labels[f], orc_res.plane_labels), "plane label grid (bit-exact)"
     assert np.array_equal(res.cyl_labels[f], orc_res.cyl_labels), "cylinder label grid (bit-exact)"
