@@ -17,7 +17,13 @@
 //
 //  PARITY STATUS: pinned by the reference's own polygon tests -- tests/test_polygons.cpp:6-89 (SquareTests.SimpleFitting:
 //  boundary length, area, containment, inter / union area with itself and with the flipped polygon, project and transform
-//  results) is replayed on this library by tests/test_polygon_oracle.py.  What stays UNPINNED (the libraries are absent
+//  results) is replayed on this library by tests/test_polygon_oracle.py; so are -- round 5 -- the reference's
+//  CoordinateSystemChangeTests (tests/test_coordinate_systems.cpp:23-160: the transformation matrix Polygon::transform moves its
+//  vertices with) and PlaneCoordinateSystemTests (:700-793: a plane through compute_plane_camera_to_world_matrix and back through
+//  compute_plane_world_to_camera_matrix, i.e. the reference's two 4x4 inversions, which polyref_plane_to_camera now follows
+//  operation by operation; the closed form of round 4 stays as polyref_plane_to_camera_analytic, the variant).  How much the
+//  unpinned choices below can matter is MEASURED by oracle/polygon_variants.py (POLY_VAR_* switches; profiles/r05_polygon_variants.txt:
+//  no validity, fallback or match decision depends on any of them).  What stays UNPINNED (the libraries are absent
 //  from this image and from /root/reference; their published algorithms are restated and each restatement says so):
 //    * FLANN 1.9 `Index<L2<double>>(KDTreeIndexParams(4))::knnSearch(..., SearchParams(128))` -- four RANDOMIZED kd-trees,
 //      an approximate search: the reference's hull is not reproducible run to run.  Restated as the EXACT k nearest
@@ -27,6 +33,19 @@
 //      with the product's (boundary integration over the pieces of each outline that lie inside the other polygon; the
 //      product cuts vertical slabs).
 // =====================================================================================================
+// ---- switches of oracle/polygon_variants.py: each flips ONE of the third-party behaviours this file could only restate from
+//      documentation, so that the sweep can measure how much of the polygons / matches depends on it (default 0 = the restatement
+//      described above)
+#ifndef POLY_VAR_KNN
+#define POLY_VAR_KNN 0      // 1: equal squared distances ordered by DESCENDING id (FLANN's order among ties is arbitrary)
+#endif
+#ifndef POLY_VAR_SIMPLIFY
+#define POLY_VAR_SIMPLIFY 0 // 1: Douglas-Peucker distance to the carrier LINE instead of the segment; 2: `>=` instead of `>` against
+#endif                      //    the threshold; 3: the ring is rotated to the vertex farthest from its first one before it is simplified
+                            //    (what newer Boost releases do with rings)
+#ifndef POLY_VAR_VALID
+#define POLY_VAR_VALID 0    // 1: a ring that merely TOUCHES itself (vertex on another edge) counts as valid; only proper crossings do not
+#endif
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -184,7 +203,11 @@ struct NeighbourIndex
         }
         const size_t kk = std::min(k, all.size());
         std::partial_sort(all.begin(), all.begin() + kk, all.end(), [](const PointValue& a, const PointValue& b) {
+#if POLY_VAR_KNN == 1
+            return a.distance < b.distance || (a.distance == b.distance && a.point.id > b.point.id);
+#else
             return a.distance < b.distance || (a.distance == b.distance && a.point.id < b.point.id);
+#endif
         });
         all.resize(kk);
         return all;
@@ -433,8 +456,17 @@ bool ring_is_simple(const Ring& r)
                     return false;
                 continue;
             }
+#if POLY_VAR_VALID == 1
+            {
+                const double d1 = orient(r[j], r[j + 1], r[i]), d2 = orient(r[j], r[j + 1], r[i + 1]), d3 = orient(r[i], r[i + 1], r[j]),
+                             d4 = orient(r[i], r[i + 1], r[j + 1]);
+                if (((d1 > 0 && d2 < 0) || (d1 < 0 && d2 > 0)) && ((d3 > 0 && d4 < 0) || (d3 < 0 && d4 > 0)))
+                    return false;
+            }
+#else
             if (segments_touch(r[i], r[i + 1], r[j], r[j + 1]))
                 return false;
+#endif
         }
     }
     return true;
@@ -590,6 +622,14 @@ double seg_dist2(const P2& p, const P2& a, const P2& b)
 {
     const double vx = b.x - a.x, vy = b.y - a.y, wx = p.x - a.x, wy = p.y - a.y;
     const double c1 = wx * vx + wy * vy;
+#if POLY_VAR_SIMPLIFY == 1
+    const double c2line = vx * vx + vy * vy;
+    if (c2line > 0)
+    {
+        const double cr = vx * wy - vy * wx;
+        return cr * cr / c2line;
+    }
+#endif
     if (c1 <= 0)
         return wx * wx + wy * wy;
     const double c2 = vx * vx + vy * vy;
@@ -617,17 +657,40 @@ void douglas_peucker(const Ring& in, size_t a, size_t b, double maxDist2, std::v
             idx = i;
         }
     }
+#if POLY_VAR_SIMPLIFY == 2
+    if (best >= maxDist2)
+#else
     if (best > maxDist2)
+#endif
     {
         keep[idx] = 1;
         douglas_peucker(in, a, idx, maxDist2, keep);
         douglas_peucker(in, idx, b, maxDist2, keep);
     }
 }
-Ring simplify_ring(const Ring& ring, double maxDist)
+Ring simplify_ring(const Ring& ringIn, double maxDist)
 {
-    if (ring.size() <= 4) // core_detail::closure::minimum_ring_size<closed> = 4: nothing to drop
-        return ring;
+    if (ringIn.size() <= 4) // core_detail::closure::minimum_ring_size<closed> = 4: nothing to drop
+        return ringIn;
+#if POLY_VAR_SIMPLIFY == 3
+    // open the ring at the vertex farthest from its first one
+    Ring ring;
+    {
+        const size_t n = ringIn.size() - 1;
+        size_t far = 0;
+        double best = -1.0;
+        for (size_t i = 0; i < n; ++i)
+        {
+            const double dx = ringIn[i].x - ringIn[0].x, dy = ringIn[i].y - ringIn[0].y;
+            if (dx * dx + dy * dy > best)
+                best = dx * dx + dy * dy, far = i;
+        }
+        for (size_t i = 0; i <= n; ++i)
+            ring.push_back(ringIn[(far + i) % n]);
+    }
+#else
+    const Ring& ring = ringIn;
+#endif
     std::vector<char> keep(ring.size(), 0);
     keep.front() = keep.back() = 1;
     douglas_peucker(ring, 0, ring.size() - 1, maxDist * maxDist, keep);
@@ -1168,10 +1231,89 @@ int polyref_move(int mode, const double* ring, int n, const double* x, const dou
     return poly_out(out, ring_out, cap, count, area, x_out, y_out, c_out, flags, nullptr);
 }
 
-// PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24) through compute_plane_world_to_camera_matrix
-// (camera_transformation.cpp:53-71): the 4x4 plane matrix is inverse([R^T 0; t^T 1]) for worldToCamera = [R t] = [R 0; -t^T R 1],
-// and the PlaneCameraCoordinates constructor re-normalises the normal (plane_coordinates.hpp:19-40).  plane = (nx, ny, nz, d).
+// ---- plane through a pose: plane_coordinates.cpp:15-24 over camera_transformation.cpp:19-71 --------------------------------
+// The reference builds the 4x4 plane matrix with TWO general matrix inversions (its own TODO says so, :62):
+//     compute_plane_world_to_camera_matrix(W) = inverse( compute_plane_camera_to_world_matrix( inverse(W) ) )
+//     compute_plane_camera_to_world_matrix(C) = [ R_C 0 ; -p_C^T R_C  1 ]                                  (:53-60)
+// and multiplies the (normal, d) 4-vector by it; the PlaneCoordinates constructor normalises the normal (plane_coordinates.hpp:19-22).
+// `matrix44::inverse()` is Eigen 3.4.0's fixed-size 4x4 inverse, restated below from its scalar cofactor form
+// (Eigen/src/LU/InverseImpl.h: cofactor_4x4 over general_det3_helper, then result /= (col(0) . row(0)^T).sum()) -- UNPINNED: Eigen is
+// absent from this image, and a vectorised build of the reference takes Eigen's SSE path for the same inverse (another summation
+// order).  polyref_plane_to_camera_analytic keeps the closed form [R 0; -t^T R 1] for W = [R t] -- what the product computes -- as
+// the variant: tests/test_polygon_oracle.py bounds the difference and shows that no match decision depends on it.
+double det3_helper(const double* m, int i1, int i2, int i3, int j1, int j2, int j3)
+{
+    return m[4 * i1 + j1] * (m[4 * i2 + j2] * m[4 * i3 + j3] - m[4 * i2 + j3] * m[4 * i3 + j2]);
+}
+double cofactor44(const double* m, int i, int j)
+{
+    const int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4, j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+    return (det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3)) + det3_helper(m, i3, i1, i2, j1, j2, j3);
+}
+void inverse44(const double* m, double* r)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+        {
+            const double c = cofactor44(m, j, i); // result(i, j) = +-cofactor(j, i)
+            r[4 * i + j] = ((i + j) & 1) ? -c : c;
+        }
+    // det = matrix.col(0) . result.row(0)
+    const double det = ((m[0] * r[0] + m[4] * r[1]) + m[8] * r[2]) + m[12] * r[3];
+    for (int k = 0; k < 16; ++k)
+        r[k] /= det;
+}
+// compute_plane_camera_to_world_matrix, camera_transformation.cpp:53-60
+void plane_camera_to_world_matrix(const double* c2w, double* out)
+{
+    for (int i = 0; i < 3; ++i)
+    {
+        for (int j = 0; j < 3; ++j)
+            out[4 * i + j] = c2w[4 * i + j];
+        out[4 * i + 3] = 0.0;
+    }
+    for (int j = 0; j < 3; ++j) // -position^T * rotation
+        out[12 + j] = ((-c2w[3]) * c2w[0 + j] + (-c2w[7]) * c2w[4 + j]) + (-c2w[11]) * c2w[8 + j];
+    out[15] = 1.0;
+}
+// compute_plane_world_to_camera_matrix, :62-71
+void plane_world_to_camera_matrix(const double* w2c, double* out)
+{
+    double c2w[16], pc2w[16];
+    inverse44(w2c, c2w);                     // compute_camera_to_world_transform(worldToCamera), :19-24
+    plane_camera_to_world_matrix(c2w, pc2w);
+    inverse44(pc2w, out);
+}
+// PlaneCoordinates(matrix * parametrization): 4x4 times 4-vector, then the normal normalised
+void plane_through(const double* M, const double* plane, double* out)
+{
+    double v[4];
+    for (int i = 0; i < 4; ++i)
+        v[i] = ((M[4 * i] * plane[0] + M[4 * i + 1] * plane[1]) + M[4 * i + 2] * plane[2]) + M[4 * i + 3] * plane[3];
+    const V3 nn = normalized3({{v[0], v[1], v[2]}});
+    out[0] = nn[0];
+    out[1] = nn[1];
+    out[2] = nn[2];
+    out[3] = v[3];
+}
+
+// PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24) through compute_plane_world_to_camera_matrix, the
+// reference's operation sequence.  plane = (nx, ny, nz, d).
 void polyref_plane_to_camera(const double* plane, const double* worldToCamera, double* out)
+{
+    double M[16];
+    plane_world_to_camera_matrix(worldToCamera, M);
+    plane_through(M, plane, out);
+}
+// PlaneCameraCoordinates::to_world_coordinates (plane_coordinates.cpp:15-18) with compute_plane_camera_to_world_matrix(cameraToWorld)
+void polyref_plane_to_world(const double* plane, const double* cameraToWorld, double* out)
+{
+    double M[16];
+    plane_camera_to_world_matrix(cameraToWorld, M);
+    plane_through(M, plane, out);
+}
+// the variant: the closed form of the same matrix, inverse([R^T 0; t^T 1]) = [R 0; -t^T R 1] for worldToCamera = [R t]
+void polyref_plane_to_camera_analytic(const double* plane, const double* worldToCamera, double* out)
 {
     const V3 n {{plane[0], plane[1], plane[2]}};
     const V3 rn = rotate44(worldToCamera, n);
@@ -1186,6 +1328,45 @@ void polyref_plane_to_camera(const double* plane, const double* worldToCamera, d
     out[1] = nn[1];
     out[2] = nn[2];
     out[3] = d;
+}
+// matrix44::inverse() as restated above (compute_world_to_camera_transform / compute_camera_to_world_transform, :19-24, :39-44)
+void polyref_inverse44(const double* m, double* out) { inverse44(m, out); }
+// utils::get_transformation_matrix(quaternion, position) (camera_transformation.hpp:16-19): Eigen's Quaternion::toRotationMatrix
+// (the quaternion is used AS GIVEN -- the reference's tests pass unnormalised ones) beside the position.  q = (w, x, y, z).
+void polyref_transform_from_quaternion(const double* q, const double* position, double* out)
+{
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+    for (int i = 0; i < 3; ++i)
+    {
+        for (int j = 0; j < 3; ++j)
+            out[4 * i + j] = R[3 * i + j];
+        out[4 * i + 3] = position[i];
+        out[12 + i] = 0.0;
+    }
+    out[15] = 1.0;
+}
+// get_transformation_matrix(xFrom, yFrom, centerFrom, xTo, yTo, centerTo) (point_coordinates.cpp:24-70) as polygon_transform above
+// restates it: linear part R_to * R_from^T over the bases [x y x^y], translation centerTo - centerFrom.  0 if the reference throws.
+int polyref_transformation_matrix(const double* xFrom, const double* yFrom, const double* cFrom, const double* xTo, const double* yTo,
+                                  const double* cTo, double* out)
+{
+    const V3 xf {{xFrom[0], xFrom[1], xFrom[2]}}, yf {{yFrom[0], yFrom[1], yFrom[2]}}, xt {{xTo[0], xTo[1], xTo[2]}}, yt {{yTo[0], yTo[1], yTo[2]}};
+    if (!frame_ok(xf, yf) || !frame_ok(xt, yt))
+        return 0;
+    const V3 zF = cross3(xf, yf), zT = cross3(xt, yt);
+    const V3 from[3] = {xf, yf, zF}, to[3] = {xt, yt, zT};
+    std::memset(out, 0, 16 * sizeof(double));
+    for (int i = 0; i < 3; ++i)
+    {
+        for (int j = 0; j < 3; ++j)
+            out[4 * i + j] = (to[0][i] * from[0][j] + to[1][i] * from[1][j]) + to[2][i] * from[2][j];
+        out[4 * i + 3] = cTo[i] - cFrom[i];
+    }
+    out[15] = 1.0;
+    return 1;
 }
 
 } // extern "C"

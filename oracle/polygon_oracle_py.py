@@ -46,8 +46,12 @@ def lib():
         L.polyref_rings_inter_area.argtypes = [vp, C.c_int, vp, C.c_int]
         L.polyref_rings_inter_area.restype = C.c_double
         L.polyref_move.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, ip, dp, vp, vp, vp, ip]
-        L.polyref_plane_to_camera.argtypes = [vp, vp, vp]
-        L.polyref_plane_to_camera.restype = None
+        for name in ("polyref_plane_to_camera", "polyref_plane_to_camera_analytic", "polyref_plane_to_world", "polyref_transform_from_quaternion"):
+            getattr(L, name).argtypes = [vp, vp, vp]
+            getattr(L, name).restype = None
+        L.polyref_inverse44.argtypes = [vp, vp]
+        L.polyref_inverse44.restype = None
+        L.polyref_transformation_matrix.argtypes = [vp] * 7
         _lib = L
     return _lib
 
@@ -158,12 +162,44 @@ def rings_inter_area(a, b):
     return float(lib().polyref_rings_inter_area(_p(a), len(a), _p(b), len(b)))
 
 
-def plane_to_camera(normal, d, world_to_camera):
-    """PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24): (normal, d) seen from the camera."""
+def plane_to_camera(normal, d, world_to_camera, analytic=False):
+    """PlaneWorldCoordinates::to_camera_coordinates (plane_coordinates.cpp:20-24): (normal, d) seen from the camera, through the
+    plane matrix the reference builds with two 4x4 inversions (camera_transformation.cpp:62-71); analytic=True: the closed form of
+    that matrix (the variant the product computes)."""
     plane = _f64(list(normal) + [d])
     out = np.zeros(4)
-    lib().polyref_plane_to_camera(_p(plane), _p(_f64(world_to_camera, (16,))), _p(out))
+    fn = lib().polyref_plane_to_camera_analytic if analytic else lib().polyref_plane_to_camera
+    fn(_p(plane), _p(_f64(world_to_camera, (16,))), _p(out))
     return out[:3].copy(), float(out[3])
+
+
+def plane_to_world(normal, d, camera_to_world):
+    """PlaneCameraCoordinates::to_world_coordinates (plane_coordinates.cpp:15-18) with compute_plane_camera_to_world_matrix."""
+    plane = _f64(list(normal) + [d])
+    out = np.zeros(4)
+    lib().polyref_plane_to_world(_p(plane), _p(_f64(camera_to_world, (16,))), _p(out))
+    return out[:3].copy(), float(out[3])
+
+
+def inverse44(m):
+    """matrix44::inverse() as the oracle restates it (Eigen's fixed-size cofactor form)."""
+    out = np.zeros(16)
+    lib().polyref_inverse44(_p(_f64(m, (16,))), _p(out))
+    return out.reshape(4, 4)
+
+
+def transform_from_quaternion(wxyz, position):
+    """utils::get_transformation_matrix(quaternion, position) (camera_transformation.hpp:16-19); the quaternion as given."""
+    out = np.zeros(16)
+    lib().polyref_transform_from_quaternion(_p(_f64(wxyz, (4,))), _p(_f64(position, (3,))), _p(out))
+    return out.reshape(4, 4)
+
+
+def transformation_matrix(x_from, y_from, c_from, x_to, y_to, c_to):
+    """get_transformation_matrix(xFrom, yFrom, centerFrom, xTo, yTo, centerTo) (point_coordinates.cpp:24-70); None where it throws."""
+    out = np.zeros(16)
+    ok = lib().polyref_transformation_matrix(*[_p(_f64(v, (3,))) for v in (x_from, y_from, c_from, x_to, y_to, c_to)], _p(out))
+    return out.reshape(4, 4) if ok else None
 
 
 # ---- MapPlane::find_matches (src/map_management/map_features/map_primitive.cpp:91-161) --------------------------------------

@@ -11,8 +11,8 @@ default build and every variant, and reports per variant
     frames whose plane / cylinder label grid changes, cells changed, frames whose plane count changes,
     and over the frames whose labels are unchanged: max |delta normal| (per component), max |delta d| (mm).
 
-usage: variants.py [n_frames=2048] [seed=1] [workers=8]    -> prints a markdown table (DESIGN.md section 2 keeps a copy,
-                                                             profiles/r02_oracle_variants.txt the full log)
+usage: variants.py [n_frames=2048] [seed=1] [workers=8] [width=640] [height=480]
+       -> prints a markdown table (DESIGN.md section 2 keeps a copy; profiles/r02_oracle_variants.txt, r05_oracle_variants.txt the logs)
 """
 import os
 import subprocess
@@ -97,7 +97,7 @@ def compare(base, var):
 
 
 def _work(args):
-    seed, n, paths = args
+    seed, n, paths, W, H = args
     import cape_oracle_py as O
 
     rng = np.random.default_rng(seed)
@@ -106,11 +106,11 @@ def _work(args):
     oracles = {}
     n_planes = 0
     for _ in range(n):
-        d, intr = fuzz_frame(rng)
+        d, intr = fuzz_frame(rng, W, H)
         key = tuple(sorted(intr.items()))
         if key not in oracles:
-            oracles[key] = (O.Oracle(640, 480, cylinders=True, **intr),
-                            {nm: O.Oracle(640, 480, cylinders=True, lib_path=p, **intr) for nm, p in paths.items()})
+            oracles[key] = (O.Oracle(W, H, cylinders=True, **intr),
+                            {nm: O.Oracle(W, H, cylinders=True, lib_path=p, **intr) for nm, p in paths.items()})
         base_o, var_o = oracles[key]
         base = base_o.run(d)
         n_planes += len(base.planes)
@@ -129,12 +129,12 @@ def _work(args):
     return acc, n_planes
 
 
-def run(n_frames, seed=1, workers=8, names=None):
+def run(n_frames, seed=1, workers=8, names=None, width=640, height=480):
     import multiprocessing as mp
 
     paths = build_variants(names)
     per = -(-n_frames // workers)
-    jobs = [(seed * 1000 + w, per, paths) for w in range(workers)]
+    jobs = [(seed * 1000 + w, per, paths, width, height) for w in range(workers)]
     with mp.get_context("spawn").Pool(workers) as pool:
         parts = pool.map(_work, jobs)
     total = {nm: dict(frames=0, label_frames=0, label_cells=0, cyl_frames=0, count_frames=0, bins_cells=0, dn=0.0, dd=0.0, daxis=0.0) for nm in paths}
@@ -154,9 +154,11 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     workers = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    total, planes = run(n, seed, workers)
+    W = int(sys.argv[4]) if len(sys.argv) > 4 else 640
+    H = int(sys.argv[5]) if len(sys.argv) > 5 else 480
+    total, planes = run(n, seed, workers, width=W, height=H)
     frames = next(iter(total.values()))["frames"]
-    print(f"# {frames} randomised 640x480 frames (cylinders on), {planes} output planes in the default build, seed {seed}")
+    print(f"# {frames} randomised {W}x{H} frames (cylinders on), {planes} output planes in the default build, seed {seed}")
     print("| variant | what changes | frames with a plane-label change | cells changed | frames with a cylinder-label change | "
           "frames with another primitive count | histogram bins changed (cells) | max abs delta normal | max abs delta d (mm) | max abs delta cylinder axis |")
     print("|---|---|---|---|---|---|---|---|---|---|")

@@ -231,6 +231,8 @@ struct cape_handle_s
     int polygonFrames = 0;          // frames of the last cape_build_polygons (0: none for the current batch)
     int matchExactFrames = 0;       // frames of the last cape_match_polygons (0: none for the current batch)
     double* matchPoses = nullptr;   // cape_match_polygons_pose: max_batch x 16 doubles, allocated on first use
+    double* matchPosesStage = nullptr; // pinned twin the caller's poses are copied into before the call returns
+    hipEvent_t matchPosesFree = nullptr; // recorded behind the H2D copy out of the twin: its next writer waits for it
     cape_frame_match_exact* matchesExact = nullptr;
     unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 4 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
@@ -287,6 +289,10 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->matchesExact);
     (void)hipFree(h->matchLists);
     (void)hipFree(h->matchPoses);
+    if (h->matchPosesStage)
+        (void)hipHostFree(h->matchPosesStage);
+    if (h->matchPosesFree)
+        (void)hipEventDestroy(h->matchPosesFree);
     if (h->resultsOnHost)
     {
         if (h->polygons)
@@ -2009,9 +2015,23 @@ static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* pr
     if (prev_to_cur)
     {
         // the poses travel to the device in the caller's memory order: n_frames x 16 doubles (entry 0 is never read)
+        // The header promises that prev_to_cur is read before the call returns.  A hipMemcpyAsync straight from the caller's
+        // memory keeps that promise only for pageable memory (the runtime then blocks -- behind everything queued on the stream);
+        // from pinned memory it is truly asynchronous.  So: memcpy into a pinned twin of the handle (waiting for the H2D copy of
+        // the previous call to have left it), then the asynchronous copy from there -- any host pointer, no implicit stream sync.
+        const size_t poseBytes = (size_t)n_frames * 16 * sizeof(double);
         if (!h->matchPoses)
             CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchPoses), (size_t)h->cfg.max_batch * 16 * sizeof(double)));
-        CAPE_HIP_TRY(hipMemcpyAsync(h->matchPoses, prev_to_cur, (size_t)n_frames * 16 * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (!h->matchPosesStage)
+        {
+            CAPE_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->matchPosesStage), (size_t)h->cfg.max_batch * 16 * sizeof(double), hipHostMallocDefault));
+            CAPE_HIP_TRY(hipEventCreateWithFlags(&h->matchPosesFree, hipEventDisableTiming));
+        }
+        else
+            CAPE_HIP_TRY(hipEventSynchronize(h->matchPosesFree));
+        std::memcpy(h->matchPosesStage, prev_to_cur, poseBytes);
+        CAPE_HIP_TRY(hipMemcpyAsync(h->matchPoses, h->matchPosesStage, poseBytes, hipMemcpyHostToDevice, stream));
+        CAPE_HIP_TRY(hipEventRecord(h->matchPosesFree, stream));
         p.poses = h->matchPoses;
     }
     p.records = h->records;

@@ -27,8 +27,10 @@ void block_of(int total, int k, int shards, int& first, int& count)
 
 // The reference's own find_primitives is multi-threaded (OpenCV's forEach over the cells, parameters.hpp: coreNumber = 8); what is
 // left on the host here is the boundary polygon of every plane of a ONE-frame call -- ~7 us each, ~10 per frame, 70 of the call's
-// 207 us on one core.  A few sleeping workers take them side by side with the calling thread (which never waits for them to wake:
-// it works through the same list); batches build their polygons on the device and never come here.
+// 207 us on one core.  A few sleeping workers take them side by side with the calling thread, which works through the same list and
+// waits only for workers that actually JOINED the job: a worker that wakes up after the list is drained finds the epoch closed and
+// goes back to sleep (through round 4 the caller waited for every worker to wake, take the mutex and count itself out: ~15 us on a
+// call whose polygons it had already built itself).  Batches build their polygons on the device and never come here.
 struct PolygonPool
 {
     explicit PolygonPool(unsigned workers)
@@ -65,7 +67,7 @@ struct PolygonPool
             job = &f;
             count = n;
             next.store(0, std::memory_order_relaxed);
-            busy = static_cast<int>(threads.size());
+            busy = 0; // workers count themselves IN when they pick the job up
             ++epoch;
             published.store(epoch, std::memory_order_release);
         }
@@ -73,6 +75,7 @@ struct PolygonPool
         for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;)
             f(i);
         std::unique_lock<std::mutex> lk(m);
+        closed = epoch; // the list is drained: whoever wakes up from now on has nothing to join
         idle.wait(lk, [this]() { return busy == 0; });
         job = nullptr;
     }
@@ -107,6 +110,9 @@ struct PolygonPool
                         break;
                 }
                 seen = epoch;
+                if (closed == epoch)
+                    continue; // too late: the caller has drained the list (and may be gone with `job`)
+                ++busy;
                 f = job;
                 n = count;
             }
@@ -122,7 +128,7 @@ struct PolygonPool
     std::condition_variable wake, idle;
     const std::function<void(int)>* job = nullptr;
     int count = 0, busy = 0;
-    unsigned long epoch = 0, hint = 0;
+    unsigned long epoch = 0, hint = 0, closed = 0;
     std::atomic<unsigned long> published {0};
     std::chrono::steady_clock::time_point expectUntil {};
     std::atomic<int> next {0};
@@ -300,6 +306,8 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         }
     };
     // (only the one-frame call: the shards of a batch run collect() on threads of their own, and the pool serves one caller)
+    if (&shard == &_single)
+        _expectHostPolygons = hostPolygons.size() >= 3;
     if (&shard == &_single && hostPolygons.size() >= 3 && std::thread::hardware_concurrency() > 1)
     {
         if (!_polygonPool)
@@ -495,6 +503,10 @@ void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, fl
         {
             _batchMatches.assign(static_cast<size_t>(n_frames), cape_frame_match_exact {});
             _matchOnHost.assign(static_cast<size_t>(n_frames), 1);
+            // what these entries are computed with: match_consecutive_polygons hands them out only for the same question
+            _batchMatchAdvanced = _matchAdvanced;
+            _batchMatchIndexZero = _matchIndexZero;
+            _batchMatchPoses = _matchPoses;
         }
         else
             _batchMatches.clear();
@@ -567,8 +579,9 @@ void Primitive_Detection::find_primitives(const matrixf&, const depth_image& dep
         }
         const depth_image d = depthImage.isContinuous() ? depthImage : depthImage.clone();
         const auto t0 = std::chrono::steady_clock::now();
-        if (_polygonPool)
-            _polygonPool->prepare(); // the polygon workers wake up while the device works on the frame
+        if (_polygonPool && _expectHostPolygons)
+            _polygonPool->prepare(); // the polygon workers wake up while the device works on the frame (only when the previous
+                                     // frame gave them something to do: three cores spinning for a frame with two planes is waste)
         if (!extract_chunk(_single, d.ptr<float>(0), nullptr, 1.0f, 1))
         {
             outputs::log_error("find_primitives: " + _single.error);
@@ -634,9 +647,20 @@ bool Primitive_Detection::match_consecutive_polygons(int n_frames, std::vector<c
         matches.clear();
         if (_matchInBatch && n_frames >= 0 && static_cast<size_t>(n_frames) <= _batchMatches.size())
         {
-            // set_batch_matching: the last batch was matched while it ran, stitched over its chunks and shards
-            matches.assign(_batchMatches.begin(), _batchMatches.begin() + n_frames);
-            return true;
+            // set_batch_matching: the last batch was matched while it ran, stitched over its chunks and shards -- with the flags
+            // and poses set_batch_matching held at that time.  Another question is not answered from that table (the
+            // arguments used to be ignored): it goes to the device below if the batch is still resident, else it is refused.
+            if (useAdvancedSearch == _batchMatchAdvanced && allowIndexZero == _batchMatchIndexZero && prevToCur == _batchMatchPoses)
+            {
+                matches.assign(_batchMatches.begin(), _batchMatches.begin() + n_frames);
+                return true;
+            }
+            if (_lastBatchShards != 1 || n_frames > _lastBatchResident)
+            {
+                outputs::log_error("match_consecutive_polygons: the batch was matched with other flags / poses (set_batch_matching) and "
+                                   "is no longer resident on one device: run the batch again with the settings wanted");
+                return false;
+            }
         }
         if (_shards.empty() || n_frames < 0 || _lastBatchShards != 1 || n_frames > _lastBatchResident || !_devicePolygons)
         {

@@ -108,6 +108,8 @@ class Primitive_Detection
         _matchIndexZero = allowIndexZero;
         _matchPoses = prevToCur;
     }
+    // An entry flagged CAPE_MATCH_EXACT_HOST | CAPE_MATCH_EXACT_OVERFLOW was filled by the host class from a table of 16 previous
+    // planes: match[] is then PARTIAL (previous planes beyond the table keep -1).
     [[nodiscard]] const std::vector<cape_frame_match_exact>& batch_matches() const noexcept { return _batchMatches; }
 
     [[nodiscard]] bool is_ready() const noexcept { return _single.handle != nullptr; }
@@ -157,12 +159,15 @@ class Primitive_Detection
     bool _devicePolygons = true;
     bool _matchInBatch = false, _matchAdvanced = false, _matchIndexZero = false;
     const double* _matchPoses = nullptr;
+    bool _batchMatchAdvanced = false, _batchMatchIndexZero = false; // the settings _batchMatches was computed with
+    const double* _batchMatchPoses = nullptr;
     mutable std::vector<cape_frame_match_exact> _batchMatches; // set_batch_matching: one entry per frame of the last batch
     mutable std::vector<char> _matchOnHost;                    // frames whose entry the host class owes (chunk / shard starts, flagged frames)
     int _lastBatchShards = 0;              // how the last find_primitives_batch was cut: match_consecutive needs 1 shard,
     int _lastBatchResident = 0;            // and the frames of its LAST chunk are the ones still on the device
     mutable Shard _single;                 // max_batch = 1: the reference's call pattern, results read in place
     mutable std::unique_ptr<PolygonPool> _polygonPool; // created at the first frame that shows three or more planes
+    mutable bool _expectHostPolygons = false;          // the last one-frame call had three or more polygons for the host class
     mutable std::vector<Shard> _shards;    // batch shards (max_batch = set_chunk_frames each), created at the first find_primitives_batch
     mutable double _meanPrimitiveTreatmentDuration = 0.0; // seconds, accumulated like primitive_detection.cpp:164
     mutable double _hostRefineTime = 0.0;  // seconds the host spent in collect(): containers + the polygons it builds itself (part of _refineTime)

@@ -227,10 +227,16 @@ int main(int argc, char** argv)
         const std::vector<cape_frame_match_exact>& three = detector->batch_matches();
         std::vector<cape_frame_match_exact> viaCall;
         const bool served = detector->match_consecutive_polygons(n, viaCall, false, true, poses.data()) && viaCall.size() == static_cast<size_t>(n);
+        // the table answers only the question it was computed for -- other flags on a batch that is spread over three
+        // shards are refused, not served with the wrong parameters
+        std::vector<cape_frame_match_exact> other;
+        const bool refused = !detector->match_consecutive_polygons(n, other, true, true, poses.data()) && other.empty();
         detector->set_batch_matching(false);
         int hostEntries = 0, hostEntriesOne = 0, mismatches = 0, matched = 0;
         if (one.size() != static_cast<size_t>(n) || three.size() != static_cast<size_t>(n) || !served)
             return 9;
+        if (!refused)
+            return 10;
         for (int f = 0; f < n; ++f)
         {
             hostEntries += (three[f].flags & CAPE_MATCH_EXACT_HOST) != 0;

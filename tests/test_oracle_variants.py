@@ -17,7 +17,7 @@ def test_contract_holds_across_oracle_variants(oracle_mod):
 
     names = ["all_at_once", "eigen_direct", "libm_minus_ulp"]
     paths = variants.build_variants(names)
-    acc, n_planes = variants._work((4242, 12, paths))
+    acc, n_planes = variants._work((4242, 12, paths, 640, 480))
     assert n_planes > 20
     for nm in names:
         a = acc[nm]

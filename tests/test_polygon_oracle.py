@@ -209,3 +209,104 @@ def test_find_matches_selection_loop(P):
     assert inter[0, 0] > 0 and inter[0, 2] == -1.0   # 1 500 mm apart: the distance gate
     m2, _ = P.find_matches(prev, cur, allow_index0=True)
     assert m2 == [0, 1, 2]
+
+
+def _is_approx(a, b, prec=1e-12):
+    """Eigen's DenseBase::isApprox: ||a - b||^2 <= prec^2 * min(||a||^2, ||b||^2)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return ((a - b) ** 2).sum() <= prec * prec * min((a ** 2).sum(), (b ** 2).sum())
+
+
+# (quaternion w x y z, camera position, xTo, yTo, centerFrom, centerTo) of the reference's CoordinateSystemChangeTests,
+# tests/test_coordinate_systems.cpp:23-160, in file order
+_COORDINATE_SYSTEM_CHANGE_TESTS = [
+    ((1, 0, 0, 0), (0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 0), (0, 0, 0)),                    # CameraToWorldAtOrigin
+    ((1, 0, 0, 0), (-100, 100, 200), (1, 0, 0), (0, 1, 0), (0, 0, 0), (-100, 100, 200)),      # CameraToWorldFarFromOrigin
+    ((0, 1, 0, 0), (0, 0, 0), (1, 0, 0), (0, -1, 0), (0, 0, 0), (0, 0, 0)),                   # ...AtOriginWithRotation
+    ((0, 0, 1, 0), (0, 0, 0), (-1, 0, 0), (0, 1, 0), (0, 0, 0), (0, 0, 0)),                   # ...WithRotation2
+    ((0, 0, 0, 1), (0, 0, 0), (-1, 0, 0), (0, -1, 0), (0, 0, 0), (0, 0, 0)),                  # ...WithRotation3
+    ((0.5, 0.5, 0.5, 0.5), (0, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0), (0, 0, 0)),            # ...WithRotationCombined
+    ((0, 1, 0, 0), (-100, 100, 200), (1, 0, 0), (0, -1, 0), (0, 0, 0), (-100, 100, 200)),     # CameraToWorldFarFromOriginWithRotation
+    ((0, 1, 0, 0), (0, 0, 0), (1, 0, 0), (0, -1, 0), (-100, 100, 200), (-100, 100, 200)),     # ...FarFromOriginSameWithRotation
+]
+
+
+@pytest.mark.parametrize("case", range(len(_COORDINATE_SYSTEM_CHANGE_TESTS)))
+def test_reference_coordinate_system_change_tests_replayed(P, case):
+    """The reference's CoordinateSystemChangeTests (tests/test_coordinate_systems.cpp:23-160), assertion by assertion:
+    compute_camera_to_world_transform_no_correction(quaternion, position) `isApprox` get_transformation_matrix(x, y, 0, xTo, yTo,
+    centerTo).  The second function is the one Polygon::transform moves its vertices with (polygon.cpp:384-428) and the first
+    builds the poses the plane / polygon round trips below go through -- both as the polygon oracle restates them."""
+    q, pos, x_to, y_to, c_from, c_to = _COORDINATE_SYSTEM_CHANGE_TESTS[case]
+    camera_to_world = P.transform_from_quaternion(q, pos)
+    tr = P.transformation_matrix((1, 0, 0), (0, 1, 0), c_from, x_to, y_to, c_to)
+    assert tr is not None
+    assert _is_approx(camera_to_world, tr)
+    # and the oracle's 4x4 inverse (matrix44::inverse(), compute_world_to_camera_transform) is an inverse
+    w2c = P.inverse44(camera_to_world)
+    assert np.allclose(w2c @ camera_to_world, np.eye(4), rtol=0, atol=1e-12)
+    assert np.allclose(w2c, np.linalg.inv(camera_to_world), rtol=0, atol=1e-9)
+
+
+_PLANE_COORDINATE_SYSTEM_TESTS = [  # tests/test_coordinate_systems.cpp:733-793: (quaternion w x y z -- NOT normalised --, position)
+    ((1, 0, 0, 0), (0, 0, 0)), ((1, 0, 0, 0), (-100, 1000, 100)), ((0.3, 0.2, 0.1, 0.4), (0, 0, 0)), ((0.6, 0.1, 0.2, 0.1), (0, 0, 0)),
+    ((0.6, 0.1, 0.2, 0.1), (100, -100, -100))]
+
+
+@pytest.mark.parametrize("case", range(len(_PLANE_COORDINATE_SYSTEM_TESTS)))
+def test_reference_plane_coordinate_system_tests_replayed(P, case):
+    """PlaneCoordinateSystemTests (tests/test_coordinate_systems.cpp:700-793) on the oracle's plane_to_world / plane_to_camera: a
+    camera plane goes to the world through compute_plane_camera_to_world_matrix and comes back through
+    compute_plane_world_to_camera_matrix(compute_world_to_camera_transform(cameraToWorld)) -- three 4x4 inversions in all, restated
+    operation by operation -- and must agree with itself within the reference's own tolerances (normal 1e-3, d 15: its quaternions
+    are not unit, the round trip is only approximately the identity)."""
+    q, pos = _PLANE_COORDINATE_SYSTEM_TESTS[case]
+    c2w = P.transform_from_quaternion(q, pos)
+    w2c = P.inverse44(c2w)
+    worst_n = worst_d = 0.0
+    count = 0
+    x = 1.0  # `for (double x = 1; x <= 1.0; x += 0.3)`: one trip
+    y = -1.0
+    while y < 1.0:
+        z = -1.0
+        while z < 1.0:
+            n = np.array([x, y, z])
+            n = n / np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+            d = 1.0
+            while d < 100:
+                n0 = n / np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])  # the PlaneCameraCoordinates constructor normalises again
+                wn, wd = P.plane_to_world(n0, d, c2w)
+                cn, cd = P.plane_to_camera(wn, wd, w2c)
+                worst_n = max(worst_n, float(np.abs(cn - n0).max()))
+                worst_d = max(worst_d, abs(cd - d))
+                count += 1
+                d += 5.5
+            z += 0.1
+        y += 0.1
+    assert count == 20 * 20 * 18 or count == 21 * 21 * 18 or count >= 7000  # (accumulated 0.1 steps: 20 or 21 trips)
+    assert worst_n < 0.001 and worst_d < 15, (worst_n, worst_d)
+
+
+def test_plane_to_camera_reference_sequence_against_closed_form(P):
+    """The reference inverts twice to build the plane matrix (camera_transformation.cpp:62-71); the product and the round-4 oracle
+    use the closed form [R 0; -t^T R 1].  Over random rigid poses (up to 30 degrees, 0.5 m) and planes at room distances the two
+    agree to a few ulp of d: relative 1e-12 -- six orders of magnitude below anything find_matches compares (100 mm, 20 degrees),
+    which is why tests/test_gpu_match_pose.py finds identical decisions with either."""
+    rng = np.random.default_rng(9)
+    worst_n = worst_d = 0.0
+    for _ in range(400):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(-0.5, 0.5)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, rng.uniform(-500, 500, 3)
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        d = rng.uniform(-6000, 6000)
+        n1, d1 = P.plane_to_camera(n, d, T)
+        n2, d2 = P.plane_to_camera(n, d, T, analytic=True)
+        worst_n = max(worst_n, float(np.abs(n1 - n2).max()))
+        worst_d = max(worst_d, abs(d1 - d2) / max(1.0, abs(d2)))
+    assert worst_n < 1e-13 and worst_d < 1e-12, (worst_n, worst_d)
