@@ -25,14 +25,10 @@ namespace cape {
 
 constexpr int kGroupThreads = 256;
 constexpr int kProducers = kGroupThreads - 64;      // waves 1-3 stage the chunks of the ordered passes
-#ifndef CAPE_HYP_BATCH
-#define CAPE_HYP_BATCH 8
-#endif
-constexpr int kHypBatch = CAPE_HYP_BATCH;                       // hypotheses scored between two barriers of the RANSAC loop
-constexpr int kGroupRounds = 3;                      // RANSAC cells a lane keeps in registers (x 256 lanes = 768 cells)
 constexpr int kCovChunk = kProducers;                // cells per chunk of the covariance passes: one cell per producer lane
 constexpr int kLlsChunk = 64;                        // cells per chunk of the combined LLS / merged-plane pass (18 f64 each)
-constexpr int kXchDoubles = 64 + 2 * kHypBatch * 8;  // exchange area: broadcasts + reductions (64), two halves of RANSAC batch partials
+constexpr int kHypPerWave = 4;                       // RANSAC, regions beyond the register cache: hypotheses a wave scores per pass over the cells
+constexpr int kXchDoubles = 64 + 2 * 32;             // exchange area: broadcasts + reductions (64), two halves of RANSAC batch partials (16 sums, 16 counts)
 constexpr int kStageDoubles = kLlsChunk * 18;        // doubles per half of the double buffer (>= kCovChunk * 6)
 static_assert(kCovChunk * 6 <= kStageDoubles, "a covariance chunk must fit one half of the staging buffer");
 static_assert(kStageDoubles * 8 >= 1280 * 2, "the boundary phase's ring list borrows one half of the staging buffer");
@@ -69,7 +65,7 @@ struct GroupCtx
     int total;                  // _cellActivatedCount
     unsigned short* s_ids;      // idsLeft
     unsigned char* s_idmask;    // idsLeftMask
-    unsigned char* s_cur;       // inliers of the hypothesis being scored (streamed path only)
+    unsigned long long* s_inl;  // RANSAC: 2 batches x 4 waves x kHypPerWave x ceil(C / 64) ballots, the inliers of the hypotheses being scored
     unsigned char* s_best;      // finalInlierIndexes as flags
     double* scratch;            // [N][kCylStride] projected normals / centroids / n.c / parked exact-path cost
     double* s_stage;            // 2 x kStageDoubles
@@ -205,10 +201,22 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
     const double ax = eg.q[0][0], ay = eg.q[1][0], az = eg.q[2][0];
 
     // ---- projection on the plane orthogonal to the axis (:107-125), one cell per lane and round
+    // (the next cell's plane is requested before this one's arithmetic -- two divisions and a square root -- so that a region of
+    //  nine rounds per lane pays one exposed memory round trip, not nine)
+    double2 nq0 = make_double2(0, 0), nq1 = nq0, nq2 = nq0, nq3 = nq0;
+    if (tid < N)
+    {
+        const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)g.list[tid] * kPlaneStride);
+        nq0 = pl[0], nq1 = pl[1], nq2 = pl[2], nq3 = pl[3];
+    }
     for (int j = tid; j < N; j += kGroupThreads)
     {
-        const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)g.list[j] * kPlaneStride);
-        const double2 q0 = pl[0], q1 = pl[1], q2 = pl[2], q3 = pl[3];
+        const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3;
+        if (j + kGroupThreads < N)
+        {
+            const double2* pl = reinterpret_cast<const double2*>(planeBase + (size_t)g.list[j + kGroupThreads] * kPlaneStride);
+            nq0 = pl[0], nq1 = pl[1], nq2 = pl[2], nq3 = pl[3];
+        }
         const double nx = q0.x, ny = q0.y, nz = q1.x, cx = q2.x, cy = q2.y, cz = q3.x;
         const double cdt = dot3(ax, ay, az, cx, cy, cz);
         const double ndt = dot3(ax, ay, az, nx, ny, nz);
@@ -264,20 +272,40 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             // [minLo, minHi] brackets the ORDERED sum of the best hypothesis' MSAC costs (see cape_cylinder.h: the reference
             // only ever compares against it, and the tree-order sum of the same addends is within CAPE_CYL_EPS of it)
             double minLo = (double)(maxSqrtDistF * (float)m), minHi = minLo;
-            double bR = 0.0, bInvR2 = 0.0, bCx = 0.0, bCy = 0.0, bCz = 0.0;
             int prevBestCount = 0;
             for (int j = tid; j < N; j += kGroupThreads)
                 g.s_best[j] = 0;
-            const bool cached = m <= kGroupThreads * kGroupRounds;
-            double2 cqa[kGroupRounds], cqb[kGroupRounds], cqc[kGroupRounds];
-            int cqi[kGroupRounds];
+            // How the four waves share a RANSAC loop (round 5).  Scoring a hypothesis does not depend on which hypotheses won before
+            // it -- only the bookkeeping does (best so far, early stop) -- so hypotheses are scored in BATCHES between two barriers
+            // and the reference's sequential bookkeeping is replayed over the batch by every lane on identical numbers; what is
+            // scored past an early stop is wasted work, never observable.  Through round 4 every wave scored EIGHT hypotheses on
+            // its quarter of the cells: eight wave-wide reductions per wave and batch, a 4-way combine per hypothesis, ~100
+            // instructions of replay per hypothesis -- 1.9 k ticks per hypothesis, no faster than the lone wave.  Now a hypothesis
+            // belongs to ONE wave (regions of up to 384 cells: four hypotheses per batch) or to a PAIR of waves (larger regions:
+            // two per batch, each wave every other round of 64 cells): one reduction per wave and batch, the inlier sets travel as
+            // wave ballots in LDS (no per-lane bit bookkeeping, no byte array of the streamed path), the replay carries the index
+            // of the best hypothesis instead of its five parameters, and the winner's flags are written once per batch.
+#ifndef CAPE_G_ROUNDS
+#define CAPE_G_ROUNDS 6
+#endif
+            constexpr int kCellRounds = CAPE_G_ROUNDS;           // cells a lane keeps in registers (12 VGPRs each)
+            const int wph = m > 64 * kCellRounds ? 2 : 1;        // waves per hypothesis
+            const int sub = wave & (wph - 1), hloc = wave >> (wph - 1);
+            const int chunkCells = 64 * wph * kCellRounds;       // cells of one pass over the register cache
+            const bool cached = m <= chunkCells;
+            // a region beyond the register cache (the 64 x 48 grid) is STREAMED: every pass over its cells serves kHypPerWave
+            // hypotheses per wave, so that the loads are paid once per eight hypotheses (two pairs of waves), not once per two
+            const int hpw = cached ? 1 : kHypPerWave;
+            const int hpb = (4 / wph) * hpw;                     // hypotheses per batch: hypothesis h of a batch belongs to wave (pair) h / hpw
+            const int nInlWords = (g.C + 63) >> 6;               // ballots a wave may park per batch
+            double2 cqa[kCellRounds], cqb[kCellRounds], cqc[kCellRounds];
             auto fetch_cells = [&](int j0) {
 #pragma unroll
-                for (int k = 0; k < kGroupRounds; ++k)
+                for (int k = 0; k < kCellRounds; ++k)
                 {
-                    const int jj = j0 + tid + kGroupThreads * k;
-                    cqi[k] = g.s_ids[jj < m ? jj : 0];
-                    const double2* t_ = reinterpret_cast<const double2*>(g.scratch + (size_t)cqi[k] * kCylStride);
+                    const int jj = j0 + sub * 64 + lane + 64 * wph * k;
+                    const int id = g.s_ids[jj < m ? jj : 0];
+                    const double2* t_ = reinterpret_cast<const double2*>(g.scratch + (size_t)id * kCylStride);
                     cqa[k] = t_[0];
                     cqb[k] = t_[1];
                     cqc[k] = t_[2];
@@ -323,8 +351,13 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             }
             __syncthreads(); // s_best is clear before the first winner flags its inliers
 
-            // the hypothesis the distance code evaluates (uniform)
+            // the hypothesis the distance code evaluates (uniform within a wave)
             double radius = 0.0, invR2 = 0.0, ctx = 0.0, cty = 0.0, ctz = 0.0;
+            auto take_hypothesis = [&](int it) {
+                const int itLane = (it < p.ransacMaxIterations ? it : p.ransacMaxIterations - 1) & 63;
+                radius = readlane_f64(hypR, itLane), invR2 = readlane_f64(hypInvR2, itLane);
+                ctx = readlane_f64(hypCx, itLane), cty = readlane_f64(hypCy, itLane), ctz = readlane_f64(hypCz, itLane);
+            };
             auto msac = [&](const double2& qa, const double2& qb, const double2& qc, bool& inl) {
                 const double vx = (qb.y - radius * qa.x) - ctx;
                 const double vy = (qc.x - radius * qa.y) - cty;
@@ -333,116 +366,117 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
                 inl = distance < maxSqrtDist;
                 return inl ? distance : maxSqrtDist;
             };
-            // ordered sum of the MSAC costs of the hypothesis in (radius, ...): the costs are parked in the free eighth double
-            // of the scratch records, position by position, and every wave walks them itself (same bits in all four)
-            auto ordered_cost = [&](double limit) {
-                for (int j0 = 0; j0 < m; j0 += kGroupThreads * kGroupRounds)
+            // ordered sum of the MSAC costs of hypothesis `it` (the never-taken exact path; a -DCAPE_CYL_EPS twin build takes it): the
+            // costs are parked in the free eighth double of the scratch records, position by position, and every wave walks them
+            // itself (same bits in all four)
+            auto ordered_cost = [&](int it, double limit) {
+                take_hypothesis(it);
+                for (int jj = tid; jj < m; jj += kGroupThreads)
                 {
-                    if (!cached)
-                        fetch_cells(j0);
-#pragma unroll
-                    for (int k = 0; k < kGroupRounds; ++k)
-                    {
-                        const int jj = j0 + tid + kGroupThreads * k;
-                        bool inl_;
-                        const double d_ = msac(cqa[k], cqb[k], cqc[k], inl_);
-                        if (jj < m)
-                            g.scratch[(size_t)jj * kCylStride + 7] = d_;
-                    }
+                    const double2* t_ = reinterpret_cast<const double2*>(g.scratch + (size_t)g.s_ids[jj] * kCylStride);
+                    bool inl_;
+                    g.scratch[(size_t)jj * kCylStride + 7] = msac(t_[0], t_[1], t_[2], inl_);
                 }
                 __syncthreads();
                 const double d = ordered_sum_lds<kCylStride>(g.scratch + 7, m, limit, lane);
                 __syncthreads(); // the parked costs are rewritten by the next call
                 return d;
             };
-            // Scoring a hypothesis does not depend on which hypotheses won before it -- only the bookkeeping does (best so far,
-            // early stop).  So the lanes score kHypBatch hypotheses back to back (independent work: the f64 latencies of one hide
-            // behind the others), reduce them together, meet at ONE barrier, and then every lane replays the reference's
-            // sequential bookkeeping over the batch on identical numbers.  Hypotheses scored past an early stop are wasted work
-            // (at most kHypBatch - 1 of them); nothing of them is observable.
             bool stop = false;
-            for (int it0 = 0; it0 < p.ransacMaxIterations && !stop; it0 += kHypBatch)
+            int bestIt = -1; // the hypothesis [minLo, minHi] belongs to
+            for (int it0 = 0; it0 < p.ransacMaxIterations && !stop; it0 += hpb)
             {
-                double ps[kHypBatch];
-                int cnl[kHypBatch];
-                unsigned bits = 0; // bit 3 h + k: the lane's cell of round k is an inlier of hypothesis it0 + h (cached path)
+                // ---- this wave's hypotheses of the batch over this wave's rounds of cells
+                double ps[kHypPerWave];
+                int cnt[kHypPerWave];
 #pragma unroll
-                for (int h = 0; h < kHypBatch; ++h)
+                for (int q = 0; q < kHypPerWave; ++q)
+                    ps[q] = 0.0, cnt[q] = 0;
+                unsigned long long* inl = g.s_inl + ((size_t)xchParBatch * 4 + wave) * kHypPerWave * nInlWords;
+                for (int j0 = 0, w0 = 0; j0 < m; j0 += chunkCells, w0 += kCellRounds)
                 {
-                    ps[h] = 0.0;
-                    cnl[h] = 0;
-                }
-                for (int j0 = 0; j0 < m; j0 += kGroupThreads * kGroupRounds)
-                {
-                    unsigned curBits[kGroupRounds]; // streamed path: bit h of round k's cell
                     if (!cached)
-                    {
                         fetch_cells(j0);
 #pragma unroll
-                        for (int k = 0; k < kGroupRounds; ++k)
-                            curBits[k] = 0;
-                    }
-#pragma unroll
-                    for (int h = 0; h < kHypBatch; ++h)
+                    for (int q = 0; q < kHypPerWave; ++q)
                     {
-                        const int itLane = (it0 + h < p.ransacMaxIterations ? it0 + h : p.ransacMaxIterations - 1) & 63;
-                        radius = readlane_f64(hypR, itLane), invR2 = readlane_f64(hypInvR2, itLane);
-                        ctx = readlane_f64(hypCx, itLane), cty = readlane_f64(hypCy, itLane), ctz = readlane_f64(hypCz, itLane);
+                        if (q >= hpw)
+                            break;
+                        take_hypothesis(it0 + hloc * hpw + q);
+                        // the rounds are independent chains of ~8 dependent f64 operations each: all of them first (the scheduler
+                        // interleaves them), the ballots parked by ONE masked block behind -- a masked store inside a round ends its
+                        // basic block and the rounds then run one after the other at the latency of a lone wave's dependent issue
+                        double dk[kCellRounds];
+                        unsigned long long bal[kCellRounds];
 #pragma unroll
-                        for (int k = 0; k < kGroupRounds; ++k)
+                        for (int k = 0; k < kCellRounds; ++k)
                         {
                             bool inl_;
                             const double d_ = msac(cqa[k], cqb[k], cqc[k], inl_);
-                            const bool in_ = j0 + tid + kGroupThreads * k < m;
-                            ps[h] += in_ ? d_ : 0.0;
-                            cnl[h] += (in_ && inl_) ? 1 : 0;
-                            if (cached)
-                                bits |= (in_ && inl_) ? (1u << (3 * h + k)) : 0u;
-                            else
-                                curBits[k] |= (in_ && inl_) ? (1u << h) : 0u;
+                            const bool in_ = j0 + sub * 64 + lane + 64 * wph * k < m;
+                            dk[k] = in_ ? d_ : 0.0;
+                            bal[k] = __ballot(in_ && inl_);
                         }
-                    }
-                    if (!cached)
-                    {
+                        double pk = 0.0; // (any order: the comparison is made on a bracket that covers every order of these addends)
 #pragma unroll
-                        for (int k = 0; k < kGroupRounds; ++k)
-                            if (j0 + tid + kGroupThreads * k < m)
-                                g.s_cur[cqi[k]] = (unsigned char)curBits[k]; // bit h: inlier of hypothesis it0 + h
+                        for (int k = 0; k + 1 < kCellRounds; k += 2)
+                            pk += dk[k] + dk[k + 1];
+                        if (kCellRounds & 1)
+                            pk += dk[kCellRounds - 1];
+                        ps[q] += pk;
+#pragma unroll
+                        for (int k = 0; k < kCellRounds; ++k)
+                            cnt[q] += __popcll(bal[k]);
+                        if (lane == 0)
+                        {
+#pragma unroll
+                            for (int k = 0; k < kCellRounds; ++k)
+                                inl[(size_t)q * nInlWords + w0 + k] = bal[k];
+                        }
                     }
                 }
                 CAPE_GTICK(1); // RANSAC: scoring
-                // wave partials of the whole batch -> exchange area -> one barrier
-                double* x = g.s_xch + 64 + xchParBatch * (kHypBatch * 8);
+                double* x = g.s_xch + 64 + xchParBatch * 32; // [0, 16): sums, [16, 32): counts; entry (hypothesis of the batch) * wph + wave of the pair
 #pragma unroll
-                for (int h = 0; h < kHypBatch; ++h)
+                for (int q = 0; q < kHypPerWave; ++q)
                 {
-                    const double pw = wave_sum_f64_tree(ps[h]);
-                    const int cw = wave_sum_i32(cnl[h]);
+                    if (q >= hpw)
+                        break;
+                    const double pw = wave_sum_f64_tree(ps[q]);
                     if (lane == 0)
                     {
-                        x[h * 8 + wave] = pw;
-                        x[h * 8 + 4 + wave] = __longlong_as_double((long long)cw);
+                        x[(hloc * hpw + q) * wph + sub] = pw;
+                        x[16 + (hloc * hpw + q) * wph + sub] = __longlong_as_double((long long)cnt[q]);
                     }
                 }
-                CAPE_GTICK(2); // RANSAC: wave reductions
+                CAPE_GTICK(2); // RANSAC: wave reduction
                 __syncthreads();
                 CAPE_GTICK(3); // RANSAC: barrier
-                xchParBatch ^= 1;
-                // ---- the reference's bookkeeping, hypothesis by hypothesis
-                for (int h = 0; h < kHypBatch; ++h)
+                // ---- the reference's bookkeeping, hypothesis by hypothesis (the batch's words in ONE LDS round trip)
+                double psH[8];
+                int cntH[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                {
+                    // (entries beyond hpb * wph hold what an earlier batch left: read, never used)
+                    const int e0 = (h * wph) & 15, e1 = (h * wph + 1) & 15;
+                    const double s0 = x[e0], s1 = x[e1];
+                    const int c0 = (int)__double_as_longlong(x[16 + e0]), c1 = (int)__double_as_longlong(x[16 + e1]);
+                    psH[h] = wph == 2 ? s0 + s1 : s0;
+                    cntH[h] = wph == 2 ? c0 + c1 : c0;
+                }
+                int winner = -1;
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
                 {
                     const int it = it0 + h;
-                    if (it >= p.ransacMaxIterations)
+                    if (h >= hpb || it >= p.ransacMaxIterations)
                         break;
                     if (rngBase + 3 * it + 2 >= p.rngCount)
                         status |= CAPE_FRAME_RNG_EXHAUSTED;
                     rngPos = rngBase + 3 * (it + 1);
-                    const int itLane = it & 63;
-                    const double hR = readlane_f64(hypR, itLane), hInvR2 = readlane_f64(hypInvR2, itLane);
-                    const double hCx = readlane_f64(hypCx, itLane), hCy = readlane_f64(hypCy, itLane), hCz = readlane_f64(hypCz, itLane);
-                    const double psAll = (x[h * 8] + x[h * 8 + 1]) + (x[h * 8 + 2] + x[h * 8 + 3]);
-                    const int curCount = (int)__double_as_longlong(x[h * 8 + 4]) + (int)__double_as_longlong(x[h * 8 + 5]) +
-                                         (int)__double_as_longlong(x[h * 8 + 6]) + (int)__double_as_longlong(x[h * 8 + 7]);
+                    const double psAll = psH[h];
+                    const int curCount = cntH[h];
                     double lo = psAll * (1.0 - CAPE_CYL_EPS), hi = psAll * (1.0 + CAPE_CYL_EPS);
                     bool wins;
                     if (lo >= minHi)
@@ -451,36 +485,17 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
                         wins = true; // ordered sum <= hi < the best's
                     else
                     {
-                        // cannot be told apart in tree order (never seen with the default bound outside the test build)
+                        // cannot be told apart in any-order sums (never seen with the default bound outside the test build)
                         if (minLo != minHi)
-                        {
-                            radius = bR, invR2 = bInvR2, ctx = bCx, cty = bCy, ctz = bCz;
-                            minLo = minHi = ordered_cost(__builtin_inf());
-                        }
-                        radius = hR, invR2 = hInvR2, ctx = hCx, cty = hCy, ctz = hCz;
-                        lo = hi = ordered_cost(minHi); // stops once it reaches minHi: >= the best's, loses
+                            minLo = minHi = ordered_cost(bestIt, __builtin_inf());
+                        lo = hi = ordered_cost(it, minHi); // stops once it reaches minHi: >= the best's, loses
                         wins = lo < minHi;
                     }
                     if (wins)
                     {
                         minLo = lo, minHi = hi;
-                        bR = hR, bInvR2 = hInvR2, bCx = hCx, bCy = hCy, bCz = hCz;
-                        if (cached)
-                        {
-#pragma unroll
-                            for (int k = 0; k < kGroupRounds; ++k)
-                                if (tid + kGroupThreads * k < m)
-                                    g.s_best[cqi[k]] = (unsigned char)((bits >> (3 * h + k)) & 1u);
-                        }
-                        else
-                        {
-                            // (the batch barrier stands between the s_cur writes above and these reads)
-                            for (int jj = tid; jj < m; jj += kGroupThreads)
-                            {
-                                const int i = g.s_ids[jj];
-                                g.s_best[i] = (unsigned char)((g.s_cur[i] >> h) & 1u);
-                            }
-                        }
+                        bestIt = it;
+                        winner = h;
                         prevBestCount = bestCount; // inlierIndexes now holds the previous best (swap)
                         bestCount = curCount;
                         // early-stop quirk (:308-312): tests the swapped-out vector
@@ -490,8 +505,21 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
                     if (stop)
                         break;
                 }
-                if (!cached)
-                    __syncthreads(); // s_cur is rewritten by the next batch
+                if (winner >= 0)
+                {
+                    // finalInlierIndexes = the inliers of the batch's last winner: its wave(s) parked them as ballots, position by
+                    // position of idsLeft (chunk, wave of the pair, round, lane)
+                    const int wWave = (winner / hpw) * wph, wq = winner % hpw; // the (first) wave that scored it, and as which of its hypotheses
+                    const unsigned long long* wi = g.s_inl + (((size_t)xchParBatch * 4 + wWave) * kHypPerWave + wq) * nInlWords;
+                    for (int jj = tid; jj < m; jj += kGroupThreads)
+                    {
+                        const int c = cached ? 0 : jj / chunkCells;
+                        const int r = jj - c * chunkCells, q = r >> 6;
+                        const unsigned long long word = wi[(size_t)(q & (wph - 1)) * kHypPerWave * nInlWords + c * kCellRounds + (q >> (wph - 1))];
+                        g.s_best[g.s_ids[jj]] = (unsigned char)((word >> (r & 63)) & 1ull);
+                    }
+                }
+                xchParBatch ^= 1; // the next batch parks in the other half: nobody can still be reading this one when it is rewritten
                 CAPE_GTICK(4); // RANSAC: replay
             }
             __syncthreads(); // the winner's flags are visible to every lane
@@ -510,6 +538,9 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             const int K = (N + kLlsChunk - 1) / kLlsChunk;
             constexpr int kPer = (kLlsChunk * 9 + kProducers - 1) / kProducers; // 16-byte pieces a producer lane moves per chunk
             double2 rq[kPer];
+            bool rkeep[kPer]; // the inlier flag of the piece's cell: applied when the piece is PARKED -- a select right behind the load
+                              // makes the producer wait for its data in front of the barrier, i.e. every chunk costs a memory round trip
+                              // (70 k ticks of "wait for the producers" per 1280x960 tunnel frame, profiles/r05_cylinder_group.txt)
             auto request = [&](int k) {
                 if (wave == 0 || k >= K)
                     return;
@@ -522,7 +553,8 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
                     const int e = (c0 + ce) < N ? (c0 + ce) : N - 1; // clamped: unconditional loads
                     const double2 v = sub < 4 ? *reinterpret_cast<const double2*>(g.scratch + (size_t)e * kCylStride + 2 * sub)
                                               : *reinterpret_cast<const double2*>(sumsBase + (size_t)g.list[e] * kSumStride + 2 * (sub - 4));
-                    rq[q] = g.s_best[e] != 0 ? v : make_double2(0.0, 0.0);
+                    rq[q] = v;
+                    rkeep[q] = g.s_best[e] != 0;
                 }
             };
             auto park = [&](int k) {
@@ -535,7 +567,7 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
                     const int piece = (tid - 64) + kProducers * q;
                     const int ce = piece / 9, sub = piece - ce * 9;
                     if (piece < kLlsChunk * 9)
-                        *reinterpret_cast<double2*>(buf + ce * 18 + 2 * sub) = rq[q];
+                        *reinterpret_cast<double2*>(buf + ce * 18 + 2 * sub) = rkeep[q] ? rq[q] : make_double2(0.0, 0.0);
                 }
             };
             const int slot = lane < 7 ? lane : ((lane >= 16 && lane < 26) ? 8 + (lane - 16) : 0); // the lane's double of a record
@@ -737,8 +769,8 @@ size_t resume_group_lds_bytes(int cells)
     b += (size_t)cells + kFastPlanes + (size_t)cells;   // s_lab, s_mlab, s_cyl
     b = (b + 3) & ~(size_t)3;
     b += (size_t)cells * 4;                             // s_ids, s_idmask, s_best (the boundary phase's s_zc afterwards)
-    if (cells > kGroupThreads * kGroupRounds)
-        b += (size_t)cells;                             // s_cur
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)2 * 4 * kHypPerWave * (((size_t)cells + 63) / 64) * 8; // s_inl
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots;
 #endif
@@ -770,7 +802,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
     unsigned short* s_ids = reinterpret_cast<unsigned short*>(smem + (((size_t)(s_cyl + C - smem) + 3) & ~(size_t)3));
     unsigned char* s_idmask = reinterpret_cast<unsigned char*>(s_ids + C);
     unsigned char* s_best = s_idmask + C;
-    unsigned char* s_cur = s_best + C; // present only on grids beyond the register cache
+    unsigned long long* s_inl = reinterpret_cast<unsigned long long*>(smem + (((size_t)(s_best + C - smem) + 7) & ~(size_t)7));
     float* s_zc = reinterpret_cast<float*>(s_ids);
 #ifdef CAPE_B_PROFILE
     unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(smem + ldsBytes - 8 * kProfileSlots);
@@ -852,7 +884,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
             g.total = total;
             g.s_ids = s_ids;
             g.s_idmask = s_idmask;
-            g.s_cur = s_cur;
+            g.s_inl = s_inl;
             g.s_best = s_best;
             g.scratch = p.cylScratch + cellBase * kCylStride;
             g.s_stage = s_stage;
