@@ -122,3 +122,81 @@ def test_configs4_1280x960_tunnel_1024_cylinders_match(oracle_mod):
         assert g["n_prev"] == len(ap) and g["n_cur"] == len(ac)
         assert list(g["match"][: len(ap)]) == m
         assert np.array_equal(g["inter"][: len(ap), : len(ac)], inter)
+
+
+def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
+    """ALL n frames of a batch against the oracle (the full-size batches were checked by sampling): label grids,
+    counts, the seed-loop length, the log-line bits of the status word, every plane segment record and every output plane bit for
+    bit, cylinder axes.  The oracle runs on a pool of threads (one Oracle object each; ctypes releases the GIL in the C call)."""
+    import concurrent.futures as cf
+    import os
+    import threading
+
+    import torch
+    from cape_amd import Extractor, synth_gpu
+
+    intr = _intr(scene)
+    dev = synth_gpu.stream(scene, 100, n, start=0, device="cuda", chunk=64)
+    ex = Extractor(640, 480, cylinders=cyl, max_batch=n, **intr)
+    ex.extract_device(dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    res = ex.results(n, with_boundary=False)
+    local = threading.local()
+
+    def bits(a):
+        return np.ascontiguousarray(a).view(np.uint64)
+
+    def check(args):
+        f, depth = args
+        if not hasattr(local, "orc"):
+            local.orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+        r = local.orc.run(depth)
+        hdr = res.records["header"][f]
+        ok = (np.array_equal(res.plane_labels[f], r.plane_labels) and np.array_equal(res.cyl_labels[f], r.cyl_labels)
+              and hdr["n_seeds"] == len(r.seeds) and hdr["n_plane_segments"] == len(r.segments) and hdr["n_planes"] == len(r.planes)
+              and hdr["n_cylinders"] == len(r.cylinders)
+              and bool(hdr["status"] & (1 << 7)) == (r.log_invalid_seed > 0) and ((int(hdr["status"]) >> 8) & 0xFF) == min(255, r.log_not_planar_after_merge))
+        segs = res.segments(f)
+        if ok and len(segs):
+            o = r.segments
+            ok = (np.array_equal(bits(segs["normal"]), bits(o[:, 0:3])) and np.array_equal(bits(segs["d"]), bits(o[:, 3]))
+                  and np.array_equal(bits(segs["centroid"]), bits(o[:, 4:7])) and np.array_equal(bits(segs["mse"]), bits(o[:, 7]))
+                  and np.array_equal(bits(segs["score"]), bits(o[:, 8])) and np.array_equal(bits(segs["sums"]), bits(o[:, 9:18]))
+                  and np.array_equal(segs["merge_label"], r.merge_labels))
+        planes = res.planes(f)
+        if ok and len(planes):
+            ok = (np.array_equal(bits(planes["out_normal"]), bits(r.planes[:, 0:3])) and np.array_equal(bits(planes["d"]), bits(r.planes[:, 3]))
+                  and np.array_equal(bits(planes["cov"]).reshape(len(planes), 9), bits(r.planes[:, 10:19])))
+        kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+        kept = kept[kept["kept"] == 1]
+        if ok and len(kept):
+            ok = np.array_equal(bits(kept["axis"]), bits(r.cylinders[:, 0:3])) and bool(np.isnan(kept["radius"]).all())
+        return f if not ok else -1, len(r.planes), len(r.cylinders)
+
+    bad, n_planes, n_cyl = [], 0, 0
+    with cf.ThreadPoolExecutor(max(2, min(16, os.cpu_count() or 2))) as pool:
+        for c0 in range(0, n, chunk):
+            host = dev[c0:c0 + chunk].cpu().numpy()
+            for f, npl, ncy in pool.map(check, [(c0 + k, host[k]) for k in range(len(host))]):
+                n_planes += npl
+                n_cyl += ncy
+                if f >= 0:
+                    bad.append(f)
+    ex.close()
+    assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
+    return n_planes, n_cyl
+
+
+def test_configs1_every_frame_of_the_4096_batch(oracle_mod):
+    """BASELINE.json configs[1], the very batch bench.py times: EVERY one of its 4 096 frames against the oracle."""
+    n_planes, _ = _every_frame(oracle_mod, "room", False, 4096)
+    assert n_planes > 8000
+
+
+@pytest.mark.parametrize("scene,n", [("room", 4096), ("tumlike", 2048), ("tunnel", 2048)])
+def test_reference_faithful_mode_every_frame(oracle_mod, scene, n):
+    """The streams of BASELINE.json configs[1] - [3] with the reference's unconditional cylinder branch on (two-pass schedule, parked
+    frames, finisher; the tunnel: the cylinder kernel alone): every frame of the batch against the oracle."""
+    n_planes, n_cyl = _every_frame(oracle_mod, scene, True, n)
+    assert n_planes + n_cyl > n // 2
+    if scene != "tumlike":
+        assert n_cyl > 50
