@@ -124,50 +124,68 @@ def self_spawn(n_gpus):
 def parity_check(ex, frames_host, intr, cylinders, n):
     """The work proves itself: the first `n` frames of the LAST timed step (their results are still on the device) against
     the CPU oracle run on the very same frames -- label grids, counts, and every plane-segment record bit for bit.  The
-    oracle is the checker here, never the thing measured."""
+    oracle is the checker here, never the thing measured.  frames_host: an array of frames, or a callable (first, count) -> frames
+    (the whole batch does not have to sit in host memory at once); the oracle runs on a pool of threads, one Oracle object each."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
+    import threading
+
     import numpy as np
 
     import cape_oracle_py as O
 
-    n = min(n, len(frames_host))
-    H, W = frames_host.shape[1:]
+    fetch = frames_host if callable(frames_host) else (lambda a, c: frames_host[a:a + c])
+    if not callable(frames_host):
+        n = min(n, len(frames_host))
+    first = fetch(0, 1)
+    H, W = first.shape[1:]
     res = ex.results(n, with_boundary=False)
-    orc = O.Oracle(W, H, cylinders=cylinders, **intr)
-    labels_equal = counts_equal = segments_bitwise = cylinders_bitwise = True
-    n_planes = n_segments = n_cyl = 0
+    local = threading.local()
 
     def bits(a):
         return np.ascontiguousarray(a).view(np.uint64)
 
-    for f in range(n):
-        r = orc.run(frames_host[f])
+    def one(args):
+        f, depth = args
+        if not hasattr(local, "orc"):
+            local.orc = O.Oracle(W, H, cylinders=cylinders, **intr)
+        r = local.orc.run(depth)
         hdr = res.records["header"][f]
-        labels_equal &= bool(np.array_equal(res.plane_labels[f], r.plane_labels) and np.array_equal(res.cyl_labels[f], r.cyl_labels))
-        counts_equal &= bool(hdr["n_plane_segments"] == len(r.segments) and hdr["n_planes"] == len(r.planes)
-                             and hdr["n_cylinders"] == len(r.cylinders) and hdr["n_seeds"] == len(r.seeds))
+        labels = bool(np.array_equal(res.plane_labels[f], r.plane_labels) and np.array_equal(res.cyl_labels[f], r.cyl_labels))
+        counts = bool(hdr["n_plane_segments"] == len(r.segments) and hdr["n_planes"] == len(r.planes)
+                      and hdr["n_cylinders"] == len(r.cylinders) and hdr["n_seeds"] == len(r.seeds))
         segs = res.segments(f)
-        if len(segs) == len(r.segments) and len(segs):
+        seg_ok = len(segs) == len(r.segments)
+        if seg_ok and len(segs):
             o = r.segments
-            segments_bitwise &= bool(
+            seg_ok = bool(
                 np.array_equal(bits(segs["normal"]), bits(o[:, 0:3])) and np.array_equal(bits(segs["d"]), bits(o[:, 3]))
                 and np.array_equal(bits(segs["centroid"]), bits(o[:, 4:7])) and np.array_equal(bits(segs["mse"]), bits(o[:, 7]))
                 and np.array_equal(bits(segs["score"]), bits(o[:, 8])) and np.array_equal(bits(segs["sums"]), bits(o[:, 9:18]))
                 and np.array_equal(segs["merge_label"], r.merge_labels))
-        elif len(segs) != len(r.segments):
-            segments_bitwise = False
         kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
         kept = kept[kept["kept"] == 1]
-        if len(kept) == len(r.cylinders) and len(kept):
-            cylinders_bitwise &= bool(np.array_equal(bits(kept["axis"]), bits(r.cylinders[:, 0:3])))
-        elif len(kept) != len(r.cylinders):
-            cylinders_bitwise = False
-        n_planes += int(hdr["n_planes"])
-        n_segments += int(hdr["n_plane_segments"])
-        n_cyl += int(hdr["n_cylinders"])
+        cyl_ok = len(kept) == len(r.cylinders)
+        if cyl_ok and len(kept):
+            cyl_ok = bool(np.array_equal(bits(kept["axis"]), bits(r.cylinders[:, 0:3])))
+        return labels, counts, seg_ok, cyl_ok, int(hdr["n_planes"]), int(hdr["n_plane_segments"]), int(hdr["n_cylinders"])
+
+    labels_equal = counts_equal = segments_bitwise = cylinders_bitwise = True
+    n_planes = n_segments = n_cyl = 0
+    with cf.ThreadPoolExecutor(max(1, min(32, available_cores()))) as pool:
+        for c0 in range(0, n, 256):
+            host = fetch(c0, min(256, n - c0))
+            for lab, cnt, sg, cy, a, b, c in pool.map(one, [(c0 + k, host[k]) for k in range(len(host))]):
+                labels_equal &= lab
+                counts_equal &= cnt
+                segments_bitwise &= sg
+                cylinders_bitwise &= cy
+                n_planes += a
+                n_segments += b
+                n_cyl += c
     return {"frames": n, "labels_equal": labels_equal, "counts_equal": counts_equal, "segments_bitwise": segments_bitwise,
             "cylinders_bitwise": cylinders_bitwise, "planes": n_planes, "plane_segments": n_segments, "cylinders": n_cyl,
-            "checker": "oracle/libcape_oracle.so on the first frames of the last timed step"}
+            "checker": "oracle/libcape_oracle.so on these frames of the last timed step (threaded, one Oracle per thread)"}
 
 
 def polygon_check(ex, n):
@@ -271,6 +289,7 @@ def main():
     ap.add_argument("--gather-root", action="store_true",
                     help="N>1: gather the packed lists to rank 0 only (cape_gather_primitives_root) instead of all-gathering them")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the in-run comparison of the last step's results with the CPU oracle")
+    ap.add_argument("--parity-frames", type=int, default=0, help="frames of the last step the in-run check compares with the oracle (0 = every distinct frame)")
     ap.add_argument("--no-polygons", action="store_true", help="skip the extra boundary-polygon leg (cape_build_polygons)")
     ap.add_argument("--no-cylinders-on", action="store_true",
                     help="N=1 default workload: skip the extra 'cylinders_on' leg (same stream with the reference's unconditional cylinder branch)")
@@ -523,11 +542,13 @@ def main():
     # ---- the work proves itself: first frames of the last timed step vs the CPU oracle (every rank checks its own shard)
     parity = None
     if not args.no_parity_check:
-        n_chk = min(U, 64)
+        # EVERY distinct frame of the step (64 of 4 096 used to be checked): the oracle does ~500 frames/s per core and
+        # the box has dozens of cores -- a few seconds outside every timed region.  (--parity-frames bounds it.)
+        n_chk = min(U, args.parity_frames if args.parity_frames > 0 else U)
         if args.u16:
-            chk = unique_dev[:n_chk].cpu().numpy().view(np.uint16).astype(np.float32) * np.float32(0.2)
+            chk = lambda a, c: unique_dev[a:a + c].cpu().numpy().view(np.uint16).astype(np.float32) * np.float32(0.2)  # noqa: E731
         else:
-            chk = unique_dev[:n_chk].cpu().numpy()
+            chk = lambda a, c: unique_dev[a:a + c].cpu().numpy()  # noqa: E731
         if gather_check is not None:
             step()  # the extra steps above ran the same frames; make the last batch's results current again
             drain()

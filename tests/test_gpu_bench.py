@@ -35,7 +35,7 @@ def test_self_spawned_launcher_with_gather():
     assert g["payload_bytes_per_frame"] <= 1229, g  # <= 1.2 KB per frame on the TUM-like stream
     assert "exposed_ms_per_step" in g
     pc = out["parity_check"]
-    assert pc["frames"] == 64 and pc["labels_equal"] and pc["counts_equal"] and pc["segments_bitwise"] and pc["all_ranks_ok"]
+    assert pc["frames"] == 256 and pc["labels_equal"] and pc["counts_equal"] and pc["segments_bitwise"] and pc["all_ranks_ok"]
 
 
 def test_gather_to_root_path():
@@ -50,7 +50,7 @@ def test_default_workload_proves_its_work():
     out = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "512", "--no-cpu-baseline"])
     assert out["ranks"]["launcher"] == "single process"
     pc = out["parity_check"]
-    assert pc["frames"] == 64 and pc["labels_equal"] and pc["segments_bitwise"] and pc["planes"] > 0
+    assert pc["frames"] == 512 and pc["labels_equal"] and pc["segments_bitwise"] and pc["planes"] > 0
     cyl = out["cylinders_on"]
     assert cyl["value"] > 0 and cyl["parity_check"]["labels_equal"] and cyl["parity_check"]["cylinders_bitwise"]
     assert set(cyl["kernel_ms"]) == {"cape_cell_moments_kernel", "cape_cell_plane_kernel", "cape_grow_kernel"}
