@@ -184,7 +184,7 @@ struct cape_handle_s
     size_t evPending = 0;           // triples [0, evPending) hold unread measurements
     bool timing = false;
     cape_timings tm{};
-    unsigned long long* phaseTicks = nullptr; // device, 4 u64: ticks in grow / merge / refine of the timed calls (StageBParams::phaseTicks)
+    unsigned long long* phaseTicks = nullptr; // device, max_batch x 4 u64: ticks in grow / merge / refine of the timed calls (StageBParams::phaseTicks)
     // cape_set_log_callback
     cape_log_fn logFn = nullptr;
     void* logUser = nullptr;
@@ -689,7 +689,10 @@ int fold_timings(cape_handle_s* h)
     if (h->phaseTicks && h->tm.calls > 0)
     {
         unsigned long long ticks[4] = {0, 0, 0, 0};
-        CAPE_HIP_TRY(hipMemcpy(ticks, h->phaseTicks, sizeof ticks, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> slots((size_t)h->cfg.max_batch * 4);
+        CAPE_HIP_TRY(hipMemcpy(slots.data(), h->phaseTicks, slots.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < slots.size(); ++i)
+            ticks[i & 3] += slots[i];
         const double all = (double)ticks[0] + (double)ticks[1] + (double)ticks[2];
         if (all > 0)
         {
@@ -861,8 +864,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     }
     CAPE_ALLOC(dalloc(h->debugCycles, B * cape::kProfileSlots));
     CAPE_ALLOC(hipMemset(h->debugCycles, 0, B * cape::kProfileSlots * 8));
-    CAPE_ALLOC(dalloc(h->phaseTicks, 4));
-    CAPE_ALLOC(hipMemset(h->phaseTicks, 0, 4 * 8));
+    CAPE_ALLOC(dalloc(h->phaseTicks, B * 4));
+    CAPE_ALLOC(hipMemset(h->phaseTicks, 0, B * 4 * 8));
     h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
     if (h->resultsOnHost)
     {
@@ -2262,7 +2265,7 @@ int cape_reset_timings(cape_handle h)
     const int rc = fold_timings(h);
     h->tm = cape_timings{};
     if (h->phaseTicks)
-        CAPE_HIP_TRY(hipMemset(h->phaseTicks, 0, 4 * 8));
+        CAPE_HIP_TRY(hipMemset(h->phaseTicks, 0, (size_t)h->cfg.max_batch * 4 * 8));
     return rc;
 }
 

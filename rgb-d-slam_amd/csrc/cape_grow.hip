@@ -75,7 +75,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
     const unsigned long long tPhase = p.phaseTicks ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
     auto book_grow_ticks = [&]() {
         if (p.phaseTicks && lane == 0)
-            atomicAdd(&p.phaseTicks[0], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
+            atomicAdd(&p.phaseTicks[(size_t)frame * 4], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
     };
     const size_t cellBase = (size_t)frame * C;
 

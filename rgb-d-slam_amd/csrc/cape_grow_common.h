@@ -233,7 +233,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
     {
         tMerge = __builtin_amdgcn_s_memtime();
         if (lane == 0)
-            atomicAdd(&p.phaseTicks[0], tMerge - tPhase);
+            atomicAdd(&p.phaseTicks[(size_t)frame * 4 + 0], tMerge - tPhase);
     }
     double* const s_seg = L.s_seg;
     unsigned long long* const s_adj = L.s_adj;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
     {
         tRefine = __builtin_amdgcn_s_memtime();
         if (lane == 0)
-            atomicAdd(&p.phaseTicks[1], tRefine - tMerge);
+            atomicAdd(&p.phaseTicks[(size_t)frame * 4 + 1], tRefine - tMerge);
     }
     // =========================================================================================
     // add_planes_to_primitives (:562-648) + compute_plane_segment_boundary (:650-703)
@@ -560,7 +560,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
         if (p.phaseTicks)
-            atomicAdd(&p.phaseTicks[2], (unsigned long long)__builtin_amdgcn_s_memtime() - tRefine);
+            atomicAdd(&p.phaseTicks[(size_t)frame * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memtime() - tRefine);
     }
 }
 

@@ -121,8 +121,9 @@ struct StageBParams
     unsigned long long* debugCycles; // [frames][kProfileSlots] shader-clock ticks per phase (only in -DCAPE_B_PROFILE builds)
     // The reference's stage buckets inside stage B (primitive_detection.cpp:140-160): shader-clock ticks every frame's wave spent
     // in [0] grow_planes_and_cylinders, [1] merge_planes, [2] add_planes / add_cylinders_to_primitives, summed over the timed calls
-    // (three fire-and-forget atomics per frame); nullptr unless the handle's timing is on.  cape_get_timings splits the grow
-    // kernels' event time in these proportions.
+    // -- four u64 PER FRAME SLOT of the batch (three fire-and-forget atomics per frame, each on the frame's own words: 4 096 waves
+    // adding to three shared words cost the kernel 70 us); nullptr unless the handle's timing is on.  cape_get_timings sums the
+    // slots and splits the grow kernels' event time in these proportions.
     unsigned long long* phaseTicks;
     int countersCleared;     // 1: stage A2 zeroed redoList[0] / needCylinder[0] (StageAParams::clear0/1); 0: launch_grow does
     int a2RowsPerTile;       // cell rows per workgroup of stage A2: the vertical edges into rows k * a2RowsPerTile are evaluated here

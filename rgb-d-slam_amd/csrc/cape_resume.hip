@@ -907,7 +907,7 @@ template <typename MaskT> __global__ __launch_bounds__(kGroupThreads, 2) void ca
                 {
                     p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
                     if (p.phaseTicks)
-                        atomicAdd(&p.phaseTicks[0], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
+                        atomicAdd(&p.phaseTicks[(size_t)frame * 4], (unsigned long long)__builtin_amdgcn_s_memtime() - tPhase);
                 }
                 handedOn = true;
             }
