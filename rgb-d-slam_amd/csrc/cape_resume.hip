@@ -127,6 +127,70 @@ template <int STRIDE> __device__ __forceinline__ void chain_consume(const double
         acc += b[i * STRIDE];
 }
 
+// The same chain over a chunk parked in PAIRS: element i of quantity q lives at buf[((i >> 1) * STRIDE + q) * 2 + (i & 1)], so one
+// 16-byte LDS read brings the lane's operands of two consecutive cells -- half the LDS instructions per addend, the adds and
+// their order unchanged.  Eight pairs in flight (round 3's attempt kept sixteen 16-byte operands twice over and spilled).
+template <int STRIDE> __device__ __forceinline__ void chain_consume_pairs(const double* buf, int off, int cn, double& acc)
+{
+    const double2* b = reinterpret_cast<const double2*>(buf) + off; // pair j of this lane's quantity: b[j * STRIDE]
+    const int pairs = cn >> 1;
+    int j = 0;
+    constexpr int G = 8;
+    if (pairs >= G)
+    {
+        double2 va[G], vb[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            va[u] = b[u * STRIDE];
+        for (; j + 2 * G <= pairs; j += 2 * G)
+        {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                vb[u] = b[(j + G + u) * STRIDE];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+            {
+                acc += va[u].x;
+                acc += va[u].y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 3 * G <= pairs)
+            {
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+                    va[u] = b[(j + 2 * G + u) * STRIDE];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+            {
+                acc += vb[u].x;
+                acc += vb[u].y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + G <= pairs)
+        {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+            {
+                acc += va[u].x;
+                acc += va[u].y;
+            }
+            j += G;
+        }
+    }
+    for (; j < pairs; ++j)
+    {
+        const double2 v = b[j * STRIDE];
+        acc += v.x;
+        acc += v.y;
+    }
+    if (cn & 1)
+        acc += b[pairs * STRIDE].x;
+}
+
 // returns with nSeg / nCylLabels / rngPos / status updated; nCylFits is incremented by the caller.  Every branch that
 // decides what the workgroup does next is taken on values all 256 lanes hold identically.
 template <typename MaskT>
@@ -160,10 +224,15 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
         auto park = [&](int k) {
             if (wave == 0 || k >= K)
                 return;
-            double* rec = g.s_stage + (k & 1) * kStageDoubles + (tid - 64) * 6;
-            *reinterpret_cast<double2*>(rec) = make_double2(r0.x * r0.x, r0.y * r0.x);
-            *reinterpret_cast<double2*>(rec + 2) = make_double2(r0.y * r0.y, r1.x * r0.x);
-            *reinterpret_cast<double2*>(rec + 4) = make_double2(r1.x * r0.y, r1.x * r1.x);
+            // parked in pairs of cells (chain_consume_pairs): quantity e of cell c at ((c >> 1) * 6 + e) * 2 + (c & 1)
+            const int c = tid - 64;
+            double* rec = g.s_stage + (k & 1) * kStageDoubles + (size_t)(c >> 1) * 12 + (c & 1);
+            rec[0] = r0.x * r0.x;
+            rec[2] = r0.y * r0.x;
+            rec[4] = r0.y * r0.y;
+            rec[6] = r1.x * r0.x;
+            rec[8] = r1.x * r0.y;
+            rec[10] = r1.x * r1.x;
         };
         const int e = lane < 6 ? lane : 0;
         double acc = 0.0;
@@ -179,7 +248,7 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             {
                 const int c0 = (k % chunksPerHalf) * kCovChunk;
                 const int cn = (N - c0 < kCovChunk) ? (N - c0) : kCovChunk;
-                chain_consume<6>(g.s_stage + (k & 1) * kStageDoubles, e, cn, acc);
+                chain_consume_pairs<6>(g.s_stage + (k & 1) * kStageDoubles, e, cn, acc);
             }
             __syncthreads();
         }
