@@ -552,6 +552,18 @@ int cape_debug_rectify_flagged(cape_handle h, int32_t* count);
  * taken, and the slots the call could use.  reserved > slots means the queue overflowed and waves walked rungs they could not
  * enqueue -- impossible in the shipped library (the queue holds every task a batch can spawn), forced by a test build. */
 int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* tickets, uint32_t* slots);
+/* the work lists of the last cape_match_polygons (profiling; synchronises): 32 words -- [0..3] pairs each capacity tier of the
+ * intersection kernel was handed, [8 + 4 * tier + reason] pairs that left tier `tier` for a larger one because of reason 1 = ring
+ * vertices, 2 = slab boundaries, 3 = edges over one slab */
+int cape_debug_match_lists(cape_handle h, uint32_t* words32);
+
+/* The seed of the reference's random engine (src/utils/random.hpp:59-64): 0 under MAKE_DETERMINISTIC -- the default here, and the
+ * mode BASELINE.json's bit-exactness is stated for --, `std::time(0)` taken once at process start otherwise.  The engine is
+ * thread_local and find_primitives runs on a fresh thread per frame (rgbd_slam.cpp:291), so EVERY frame restarts the sequence at
+ * the seed: the handle keeps the first 40 000 doubles of mt19937(seed) + uniform_real_distribution on the device and this call
+ * regenerates them (it waits for the handle's work in flight).  A caller that wants the reference's non-deterministic build passes
+ * its own time(0). */
+int cape_set_rng_seed(cape_handle h, uint32_t seed);
 
 /* outputs::log / log_warning / log_error of the path (the reference's src/outputs/logger.hpp), for a caller that wants the
  * reference's own lines: level 0 = log, 1 = log_warning, 2 = log_error.  The messages find_primitives prints on the hot path,

@@ -780,6 +780,7 @@ struct Rng
     // the reference runs it on a fresh std::async thread each frame (rgbd_slam.cpp:291), seed 0 = MAKE_DETERMINISTIC
     std::mt19937 engine{0u};
     std::uniform_real_distribution<double> dist{0.0, 1.0};
+    explicit Rng(unsigned seed = 0u) : engine(seed) {}
     double next_double() { return dist(engine); }
     unsigned next_uint(unsigned maxValue)
     {
@@ -1268,7 +1269,7 @@ void Oracle::find_primitives(const float* cloud, const float* depth, FrameResult
     std::vector<CylinderSeg> cylinderSegments;
     std::vector<int32_t> gridPlane(cells, 0), gridCyl(cells, 0);
     std::vector<uint8_t> isUnassigned(cells, 0);
-    Rng rng; // fresh thread_local engine per call (see Rng)
+    Rng rng(cfg_.rngSeed); // fresh thread_local engine per call (see Rng)
 
     out = FrameResult();
 
@@ -1693,6 +1694,9 @@ void* cape_oracle_create(int width, int height, double fx, double fy, double cx,
     c.cylinders = cylinders != 0;
     return new Handle(c);
 }
+
+// utils::Random::_seed of a build without MAKE_DETERMINISTIC (random.hpp:59-64): the next frames restart their engine at `seed`
+void cape_oracle_set_rng_seed(void* h, unsigned seed) { static_cast<Handle*>(h)->oracle.set_rng_seed(seed); }
 
 void cape_oracle_destroy(void* h) { delete static_cast<Handle*>(h); }
 

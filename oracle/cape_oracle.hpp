@@ -43,6 +43,8 @@ struct Config
     int width = 640, height = 480;
     double fx = 550, fy = 550, cx = 320, cy = 240; // Parameters::load_defaut, src/parameters.cpp:59-74
     bool cylinders = true; // false: "plane-only" = skip primitive_detection.cpp:385-388
+    unsigned rngSeed = 0;  // utils::Random::_seed (random.hpp:59-64): 0 under MAKE_DETERMINISTIC, std::time(0) at process start otherwise;
+                           // the engine is thread_local and find_primitives runs on a fresh thread per frame: every frame restarts at it
 };
 
 // src/features/primitives/plane_segment.hpp:122-139
@@ -122,6 +124,7 @@ class Oracle
     int vCells() const { return vCells_; }
     int cells() const { return totalCells_; }
     const Config& config() const { return cfg_; }
+    void set_rng_seed(unsigned seed) { cfg_.rngSeed = seed; }
 
     // ScreenCoordinate::to_camera_coordinates, point_coordinates.cpp:150-167 (x,y in f64)
     void back_project(double col, double row, double z, double out[3]) const;

@@ -37,6 +37,7 @@ def lib(path=None):
         L.cape_oracle_create.restype = C.c_void_p
         L.cape_oracle_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
         L.cape_oracle_destroy.argtypes = [C.c_void_p]
+        L.cape_oracle_set_rng_seed.argtypes = [C.c_void_p, C.c_uint]
         L.cape_oracle_cells.argtypes = [C.c_void_p]
         L.cape_oracle_run.argtypes = [C.c_void_p, C.c_void_p]
         L.cape_oracle_run_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -83,6 +84,10 @@ class Oracle:
         self.width, self.height = width, height
         self.h = self.L.cape_oracle_create(width, height, fx, fy, cx, cy, 1 if cylinders else 0)
         self.cells = self.L.cape_oracle_cells(self.h)
+
+    def set_rng_seed(self, seed):
+        """utils::Random::_seed of a reference build without MAKE_DETERMINISTIC (random.hpp:59-64): every frame restarts there."""
+        self.L.cape_oracle_set_rng_seed(self.h, int(seed) & 0xFFFFFFFF)
 
     def __del__(self):
         try:

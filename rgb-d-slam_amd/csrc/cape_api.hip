@@ -425,6 +425,18 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
 
 int fold_timings(cape_handle_s* h);
 
+// utils::Random (src/utils/random.hpp:17-30, :59-64): the first kRngTable doubles of mt19937(seed) + uniform_real_distribution(0, 1)
+// (libstdc++ on the host = the reference's own generator)
+std::vector<double> rng_table(uint32_t seed)
+{
+    std::vector<double> rng(kRngTable);
+    std::mt19937 engine(seed);
+    std::uniform_real_distribution<double> dist(0.0, 1.0);
+    for (auto& v : rng)
+        v = dist(engine);
+    return rng;
+}
+
 // next free event set for one timed kernel chain (creates / recycles on demand)
 int acquire_events(cape_handle_s* h, int frames, cape_handle_s::EvTriple** out)
 {
@@ -913,14 +925,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         return r;
     };
     const std::vector<float> rc = ratios(acol, h->hCells), rr = ratios(brow, h->vCells);
-    std::vector<double> rng(kRngTable);
-    {
-        // utils::Random (src/utils/random.hpp:17-30) under MAKE_DETERMINISTIC: mt19937(0) + uniform_real_distribution
-        std::mt19937 engine(0u);
-        std::uniform_real_distribution<double> dist(0.0, 1.0);
-        for (auto& v : rng)
-            v = dist(engine);
-    }
+    const std::vector<double> rng = rng_table(0u); // MAKE_DETERMINISTIC's seed; cape_set_rng_seed changes it
     {
         // _Xpre / _Ypre of Depth_Map_Transformation::init_matrices (depth_map_transformation.cpp:156-161)
         std::vector<float> xp(acol.begin(), acol.end()), yp(brow.begin(), brow.end());
@@ -2226,6 +2231,30 @@ int cape_log_records(const cape_frame_record* records, int32_t n_frames, cape_lo
     for (int f = 0; f < n_frames; ++f)
         lines += log_frame(fn, user, records[f], f);
     return lines;
+}
+
+int cape_debug_match_lists(cape_handle h, uint32_t* words32)
+{
+    if (!h || !words32)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad argument");
+    std::memset(words32, 0, 32 * sizeof(uint32_t));
+    if (!h->matchLists)
+        return CAPE_OK;
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(hipDeviceSynchronize());
+    CAPE_HIP_TRY(hipMemcpy(words32, h->matchLists, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CAPE_OK;
+}
+
+int cape_set_rng_seed(cape_handle h, uint32_t seed)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h)); // a grow kernel in flight may still be drawing from the table
+    const std::vector<double> rng = rng_table(seed);
+    CAPE_HIP_TRY(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
+    return CAPE_OK;
 }
 
 int cape_set_log_callback(cape_handle h, cape_log_fn fn, void* user)

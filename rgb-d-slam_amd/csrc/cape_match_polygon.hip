@@ -37,9 +37,18 @@ constexpr int kWaves = 2; // frames per workgroup of the gate / select kernels
 // wave's dependent LDS round trips and only other waves fill the gaps.  The small instance takes ~95 % of the pairs; a pair
 // that exceeds one of an instance's capacities moves to the next one's work list.
 template <int TIER> struct Tier;
+#ifndef CAPE_MP_T0_STACK
+#define CAPE_MP_T0_STACK 6
+#endif
+#ifndef CAPE_MP_T0_XS
+#define CAPE_MP_T0_XS 256
+#endif
+#ifndef CAPE_MP_T0_GROUPS
+#define CAPE_MP_T0_GROUPS 4
+#endif
 template <> struct Tier<0>
 {
-    static constexpr int kRing = 32, kXs = 256, kStack = 6, kWavesPerGroup = 2, kGroupsPerCu = 4;
+    static constexpr int kRing = 32, kXs = CAPE_MP_T0_XS, kStack = CAPE_MP_T0_STACK, kWavesPerGroup = 2, kGroupsPerCu = CAPE_MP_T0_GROUPS;
 };
 template <> struct Tier<1>
 {
@@ -712,7 +721,11 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                 again = (is_nan_code(result, kNanStack) && later_stack<TIER>() > T::kStack) || (is_nan_code(result, kNanSlabs) && later_xs<TIER>() > T::kXs) ||
                         (is_nan_code(result, kNanRing) && later_ring<TIER>() > T::kRing);
             if (again)
+            {
                 p.pairLists[(size_t)(TIER + 1) * p.pairCapacity + atomicAdd(&p.listCounts[TIER + 1], 1u)] = pair;
+                // why the pair moves on (cape_debug_match_lists: words 8 + 4 * tier + reason; a handful of atomics per batch)
+                atomicAdd(&p.listCounts[8 + 4 * TIER + (is_nan_code(result, kNanRing) ? 1 : (is_nan_code(result, kNanSlabs) ? 2 : 3))], 1u);
+            }
             else
                 out.inter_area[j][i] = result;
         }
@@ -784,7 +797,7 @@ template <int TIER> static hipError_t launch_tier(const MatchPolygonParams& p, i
 
 hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipStream_t stream)
 {
-    if (const hipError_t e = hipMemsetAsync(p.listCounts, 0, kTiers * sizeof(unsigned), stream); e != hipSuccess)
+    if (const hipError_t e = hipMemsetAsync(p.listCounts, 0, 32 * sizeof(unsigned), stream); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(cape_polygon_gate_kernel, dim3((nFrames + kGateFrames - 1) / kGateFrames), dim3(64 * kGateFrames), 0, stream, p, nFrames);
     if (const hipError_t e = hipGetLastError(); e != hipSuccess)

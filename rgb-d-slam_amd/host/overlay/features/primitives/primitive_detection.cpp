@@ -158,6 +158,15 @@ void Primitive_Detection::set_detailed_statistics(bool on) noexcept
         cape_enable_timing(s.handle, on ? 1 : 0);
 }
 
+void Primitive_Detection::set_random_seed(uint32_t seed) noexcept
+{
+    _randomSeed = seed;
+    if (_single.handle)
+        cape_set_rng_seed(_single.handle, seed);
+    for (Shard& s : _shards)
+        cape_set_rng_seed(s.handle, seed);
+}
+
 Primitive_Detection::Primitive_Detection(const uint width, const uint height) : _width(width), _height(height)
 {
     if (const char* env = std::getenv("CAPE_DETAILED_STATISTICS"))
@@ -206,6 +215,8 @@ bool Primitive_Detection::make_shard(Shard& s, int device, int maxBatch) noexcep
             return false;
         }
         cape_set_log_callback(s.handle, &forward_log, nullptr);
+        if (_randomSeed != 0)
+            cape_set_rng_seed(s.handle, _randomSeed);
         if (_detailedStatistics)
             cape_enable_timing(s.handle, 1);
         cape_layout lay {};

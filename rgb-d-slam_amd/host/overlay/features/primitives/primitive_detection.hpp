@@ -71,6 +71,9 @@ class Primitive_Detection
     // primitive_detection.cpp:69-117 -- need HIP events around the kernels and three atomics per frame inside the grow kernel
     // (cape_enable_timing): a few microseconds on the one-frame call, hence opt-in (also: environment CAPE_DETAILED_STATISTICS=1).
     void set_detailed_statistics(bool on) noexcept;
+    // The reference's utils::Random::_seed (src/utils/random.hpp:59-64): 0 under MAKE_DETERMINISTIC (the default here), std::time(0)
+    // of the process otherwise; every frame's RANSAC restarts there (thread_local engine on a fresh thread per frame).
+    void set_random_seed(uint32_t seed) noexcept;
     [[nodiscard]] int shard_count() const noexcept { return static_cast<int>(_shards.size()); }
 
     // candidate matches between consecutive frames still resident on the device after find_primitives_batch with ONE
@@ -173,6 +176,7 @@ class Primitive_Detection
     mutable double _hostRefineTime = 0.0;  // seconds the host spent in collect(): containers + the polygons it builds itself (part of _refineTime)
     mutable double _hostResetTime = 0.0;   // seconds spent clearing the output containers (the host's share of reset_data)
     bool _detailedStatistics = false;
+    uint32_t _randomSeed = 0;
 
     // remove copy functions, like the reference (primitive_detection.hpp:228-230)
     Primitive_Detection(const Primitive_Detection&) = delete;

@@ -142,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "cape_match_polygons", "cape_match_polygons_pose", "cape_copy_polygon_matches",
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
-    "cape_debug_polygon_queue", "cape_set_log_callback", "cape_log_records",
+    "cape_debug_polygon_queue", "cape_set_log_callback", "cape_log_records", "cape_debug_match_lists", "cape_set_rng_seed",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -424,6 +424,16 @@ class Extractor:
         n = C.c_int32(0)
         _check(self.L, self.L.cape_debug_rectify_flagged(self.h, C.byref(n)), "cape_debug_rectify_flagged")
         return n.value
+
+    def set_rng_seed(self, seed):
+        """cape_set_rng_seed: the reference's utils::Random::_seed (0 = MAKE_DETERMINISTIC, the default)."""
+        _check(self.L, self.L.cape_set_rng_seed(self.h, C.c_uint32(int(seed) & 0xFFFFFFFF)), "cape_set_rng_seed")
+
+    def match_lists(self):
+        """the tier work lists of the last match_polygons: (pairs per tier, {(tier, reason): pairs that moved on})"""
+        w = (C.c_uint32 * 32)()
+        _check(self.L, self.L.cape_debug_match_lists(self.h, w), "cape_debug_match_lists")
+        return list(w[:4]), {(t, r): int(w[8 + 4 * t + r]) for t in range(4) for r in (1, 2, 3) if w[8 + 4 * t + r]}
 
     def polygon_queue(self):
         """(slots reserved, tickets taken, slots usable) of the task queue of the last build_polygons (tests)."""

@@ -270,3 +270,34 @@ def test_log_callback_gets_the_batch_once(oracle_mod):
         assert L.cape_copy_results(h, n, rec.ctypes.data_as(C.c_void_p), None, None, None) == 0
         assert len([ln for ln in lines if ln[0] == max_batch]) == 2 * n
         L.cape_destroy(h)
+
+
+@pytest.mark.parametrize("max_batch", [1, 6])
+def test_random_seed_of_a_non_deterministic_reference_build(oracle_mod, max_batch):
+    """SURVEY section 5, determinism: the reference seeds its RANSAC engine with 0 under MAKE_DETERMINISTIC and with time(0) of the
+    process otherwise (random.hpp:59-64); every frame restarts there.  cape_set_rng_seed regenerates the handle's draw table: the
+    device must follow the oracle bit for bit for ANY seed, on both kinds of handle (results in pinned host memory / in HBM), and go
+    back to the deterministic mode with seed 0."""
+    from cape_amd import Extractor, synth
+    from test_gpu_parity import compare_frame
+
+    rng = np.random.default_rng(2)
+    base = synth.tunnel(seed=3, frame=40)
+    frames = [base, base * np.float32(1.03), synth.room(seed=4, frame=9)]
+    frames.append(frames[0] + (rng.standard_normal(base.shape) * 5).astype(np.float32) * (base > 0))
+    frames = np.stack(frames)[: max(1, min(4, max_batch))]
+    intr = _intr()
+    orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+    ex = Extractor(640, 480, cylinders=True, max_batch=max_batch, **intr)
+    seen = []
+    for seed in (0, 1742515200, 7, 0):
+        orc.set_rng_seed(seed)
+        ex.set_rng_seed(seed)
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        for f in range(n):
+            compare_frame(orc.run(frames[f]), ex, res, f, check_cells=False)
+        seen.append(res.cyl_labels.copy())
+    assert np.array_equal(seen[0], seen[3]), "seed 0 again: the deterministic mode"
+    assert res.records["header"]["n_cylinders"].sum() >= 1
+    ex.close()
