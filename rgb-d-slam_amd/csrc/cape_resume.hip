@@ -27,6 +27,13 @@ constexpr int kGroupThreads = 256;
 constexpr int kProducers = kGroupThreads - 64;      // waves 1-3 stage the chunks of the ordered passes
 constexpr int kCovChunk = kProducers;                // cells per chunk of the covariance passes: one cell per producer lane
 constexpr int kLlsChunk = 64;                        // cells per chunk of the combined LLS / merged-plane pass (18 f64 each)
+#ifndef CAPE_G_ROUNDS
+#define CAPE_G_ROUNDS 6
+#endif
+constexpr int kCellRounds = CAPE_G_ROUNDS;           // RANSAC: cells a lane keeps in registers (12 VGPRs each)
+// ballots a wave may park per hypothesis: a pass over the cells parks kCellRounds words, a region takes ceil(m / (64 * wph * kCellRounds))
+// passes -- at most this many words for m <= cells (also on grids of fewer than 64 * kCellRounds cells, where ceil(cells / 64) is too few)
+__host__ __device__ constexpr int ransac_ballot_words(int cells) { return kCellRounds * ((cells + 64 * kCellRounds - 1) / (64 * kCellRounds)); }
 constexpr int kHypPerWave = 4;                       // RANSAC, regions beyond the register cache: hypotheses a wave scores per pass over the cells
 constexpr int kXchDoubles = 64 + 2 * 32;             // exchange area: broadcasts + reductions (64), two halves of RANSAC batch partials (16 sums, 16 counts)
 constexpr int kStageDoubles = kLlsChunk * 18;        // doubles per half of the double buffer (>= kCovChunk * 6)
@@ -65,7 +72,7 @@ struct GroupCtx
     int total;                  // _cellActivatedCount
     unsigned short* s_ids;      // idsLeft
     unsigned char* s_idmask;    // idsLeftMask
-    unsigned long long* s_inl;  // RANSAC: 2 batches x 4 waves x kHypPerWave x ceil(C / 64) ballots, the inliers of the hypotheses being scored
+    unsigned long long* s_inl;  // RANSAC: 2 batches x 4 waves x kHypPerWave x ransac_ballot_words(C) ballots, the inliers of the hypotheses being scored
     unsigned char* s_best;      // finalInlierIndexes as flags
     double* scratch;            // [N][kCylStride] projected normals / centroids / n.c / parked exact-path cost
     double* s_stage;            // 2 x kStageDoubles
@@ -354,10 +361,6 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             // two per batch, each wave every other round of 64 cells): one reduction per wave and batch, the inlier sets travel as
             // wave ballots in LDS (no per-lane bit bookkeeping, no byte array of the streamed path), the replay carries the index
             // of the best hypothesis instead of its five parameters, and the winner's flags are written once per batch.
-#ifndef CAPE_G_ROUNDS
-#define CAPE_G_ROUNDS 6
-#endif
-            constexpr int kCellRounds = CAPE_G_ROUNDS;           // cells a lane keeps in registers (12 VGPRs each)
             const int wph = m > 64 * kCellRounds ? 2 : 1;        // waves per hypothesis
             const int sub = wave & (wph - 1), hloc = wave >> (wph - 1);
             const int chunkCells = 64 * wph * kCellRounds;       // cells of one pass over the register cache
@@ -366,7 +369,7 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
             // hypotheses per wave, so that the loads are paid once per eight hypotheses (two pairs of waves), not once per two
             const int hpw = cached ? 1 : kHypPerWave;
             const int hpb = (4 / wph) * hpw;                     // hypotheses per batch: hypothesis h of a batch belongs to wave (pair) h / hpw
-            const int nInlWords = (g.C + 63) >> 6;               // ballots a wave may park per batch
+            const int nInlWords = ransac_ballot_words(g.C);      // ballots a wave may park per hypothesis
             double2 cqa[kCellRounds], cqb[kCellRounds], cqc[kCellRounds];
             auto fetch_cells = [&](int j0) {
 #pragma unroll
@@ -839,7 +842,7 @@ size_t resume_group_lds_bytes(int cells)
     b = (b + 3) & ~(size_t)3;
     b += (size_t)cells * 4;                             // s_ids, s_idmask, s_best (the boundary phase's s_zc afterwards)
     b = (b + 7) & ~(size_t)7;
-    b += (size_t)2 * 4 * kHypPerWave * (((size_t)cells + 63) / 64) * 8; // s_inl
+    b += (size_t)2 * 4 * kHypPerWave * (size_t)ransac_ballot_words(cells) * 8; // s_inl
 #ifdef CAPE_B_PROFILE
     b = ((b + 15) & ~(size_t)15) + 8 * kProfileSlots;
 #endif

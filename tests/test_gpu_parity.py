@@ -780,7 +780,7 @@ def test_cylinder_schedules_agree(oracle_mod):
 
 
 @pytest.mark.parametrize("mode", ["wave", "group", "off"])
-@pytest.mark.parametrize("w,h,n", [(640, 480, 48), (1280, 960, 12)])
+@pytest.mark.parametrize("w,h,n", [(640, 480, 48), (1280, 960, 12), (320, 240, 24)])  # (320x240: 192 cells, fewer than one pass of the workgroup finisher's register cache)
 def test_cylinder_resume_modes(oracle_mod, monkeypatch, mode, w, h, n):
     """A frame that reaches a cylinder candidate is parked by the plane-only pass and finished by one wavefront (the RESUME
     instance of the grow kernel), by one workgroup (cape_resume.hip) or -- CAPE_RESUME=off, the round-2 schedule -- grown
