@@ -1019,3 +1019,63 @@ def test_one_frame_chain_many_calls_in_a_row(monkeypatch):
             n = ex.extract_host(frames[k])
             same(ex.results(n, with_boundary=False), 0, k)
     ex.close()
+
+
+def _checkerboard_of_facets(W=1280, H=960, tile=100, seed=3):
+    """Tilted facets in a checkerboard -- four orientations, no two neighbours alike, a depth step between neighbours: every facet is a
+    plane segment of its own (116 of them at 1280x960 with 100-px tiles)."""
+    from cape_amd import synth
+
+    s = W / 640.0
+    intr = {k: v * s for k, v in synth.DEFAULT_INTRINSICS.items()}
+    u = (np.arange(W) - intr["cx"]) / intr["fx"]
+    v = (np.arange(H) - intr["cy"]) / intr["fy"]
+    X, Y = np.meshgrid(u, v)
+    rng = np.random.default_rng(seed)
+    tilts = [(0.5, 0.0), (-0.5, 0.0), (0.0, 0.5), (0.0, -0.5)]
+    z = np.zeros((H, W))
+    for ty in range(0, H, tile):
+        for tx in range(0, W, tile):
+            nx, ny = tilts[((tx // tile) % 2) + 2 * ((ty // tile) % 2)]
+            d = 2000.0 + 120.0 * (((tx // tile) * 7 + (ty // tile) * 13) % 9)
+            sl = (slice(ty, min(ty + tile, H)), slice(tx, min(tx + tile, W)))
+            z[sl] = d / (1.0 + nx * X[sl] + ny * Y[sl])
+    z += rng.normal(0, 0.6, z.shape)
+    return np.round(z).astype(np.float32), intr
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+def test_more_than_64_plane_segments_is_flagged_not_silent(oracle_mod, cyl):
+    """The capacity limit the reference does not have: `_planeSegments` is an unbounded vector
+    (primitive_detection.hpp:206), a frame record holds CAPE_MAX_PLANES = 64.  A checkerboard of 116 facets (the oracle: 116 plane
+    segments) must come back FLAGGED -- CAPE_FRAME_PLANE_OVERFLOW, at most 64 segments, the capacity warning through the log callback --
+    and must not disturb the frames around it in the batch, call after call.  (What a spill instance would have to do instead is in
+    DESIGN; this test pins the behaviour that exists.)"""
+    import cape_amd
+    from cape_amd import Extractor, synth
+
+    W, H = 1280, 960
+    big, intr = _checkerboard_of_facets(W, H)
+    orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
+    assert len(orc.run(big).segments) == 116
+    room = synth.room(seed=1, frame=0, width=W, height=H, intr=intr)
+    tunnel = synth.tunnel(seed=1, frame=0, width=W, height=H, intr=intr)
+    frames = np.stack([room, big, tunnel, big])
+    want = {0: orc.run(room), 2: orc.run(tunnel)}
+    ex = Extractor(W, H, cylinders=cyl, max_batch=len(frames), **intr)
+    lines = []
+    ex.set_log_callback(lambda level, msg, frame: lines.append((level, msg, frame)))
+    for rep in range(2):
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        hdr = res.records["header"]
+        for f in (1, 3):
+            assert int(hdr["status"][f]) & 1, "more than 64 plane segments must be flagged CAPE_FRAME_PLANE_OVERFLOW"
+            assert 0 < int(hdr["n_plane_segments"][f]) <= 64 and int(hdr["n_planes"][f]) <= 64
+            assert int(res.plane_labels[f].max()) <= 64
+        for f in (0, 2):
+            assert int(hdr["status"][f]) & 1 == 0
+            compare_frame(want[f], ex, res, f, check_cells=False)
+    warned = [ln for ln in lines if "per-frame capacity exceeded" in ln[1]]
+    assert sorted(ln[2] for ln in warned) == [1, 1, 3, 3] and all(ln[0] == 1 for ln in warned)
+    ex.close()
