@@ -29,11 +29,18 @@
 extern "C" {
 #endif
 
+/* ABI number of this header: bumped whenever a struct below changes size or meaning (cape_abi_version() returns the library's;
+ * a binding built against another number must not call it).  2 = round 6: cape_frame_header grew by next_record / segment_base
+ * (frames of more than 64 plane segments continue in spill records), cape_config by spill_records, cape_timings holds the
+ * reference's five buckets (12 fields), the frame status carries bit 7 and a count in bits 8..15. */
+#define CAPE_ABI_VERSION 2
+
 #define CAPE_CELL_SIZE 20          /* parameters::detection::depthMapPatchSize_px, src/parameters.hpp:79-80 */
-#define CAPE_MAX_PLANES 64         /* capacity of _planeSegments per frame (reference: unbounded std::vector); frames with
-                                      up to 32 segments run entirely in the fast kernels, the others are redone by a
-                                      64-segment instance */
-#define CAPE_MAX_CYLINDERS 64      /* capacity of cylinder2regionMap per frame (records live in HBM only: no LDS cost) */
+#define CAPE_MAX_PLANES 64         /* plane segments ONE RECORD holds.  _planeSegments is an unbounded std::vector in the reference
+                                      (primitive_detection.hpp:206): a frame with more continues in spill records, see
+                                      cape_frame_header.next_record.  Frames with up to 32 segments run entirely in the fast
+                                      kernels, up to 64 in a 64-segment instance, the others in the general instance */
+#define CAPE_MAX_CYLINDERS 64      /* cylinder labels one record holds (cylinder2regionMap, likewise unbounded: same chain) */
 
 typedef enum cape_status
 {
@@ -60,7 +67,8 @@ enum
 /* per-frame status bits (cape_frame_header.status) */
 enum
 {
-    CAPE_FRAME_PLANE_OVERFLOW = 1u << 0,    /* more than CAPE_MAX_PLANES (64) plane segments: frame truncated */
+    CAPE_FRAME_PLANE_OVERFLOW = 1u << 0,    /* the handle's pool of spill records (cape_config.spill_records) ran out while this frame
+                                               needed one more: the frame is truncated at the records it got */
     CAPE_FRAME_BOUNDARY_OVERFLOW = 1u << 1, /* boundary point capacity exceeded */
     CAPE_FRAME_CYL_OVERFLOW = 1u << 2,
     CAPE_FRAME_BIN_NEAR_EDGE = 1u << 3,     /* a cell's histogram angle fell within 1e-9 of a bin edge (libm tie risk) */
@@ -82,8 +90,8 @@ enum
  */
 typedef struct cape_config
 {
-    int32_t width;      /* multiple of 20, <= 1280 */
-    int32_t height;     /* multiple of 20, <= 1280 */
+    int32_t width;      /* multiple of 20; at most 256 cells wide (5120 px) and 65 535 cells in all -- grids up to 64 x 64 cells */
+    int32_t height;     /* multiple of 20     (1280 x 1280 px) run in the fast kernels, larger ones in the general instance    */
     double fx, fy, cx, cy;
     uint32_t flags;     /* CAPE_FLAG_* */
     int32_t device;     /* HIP device ordinal */
@@ -93,6 +101,9 @@ typedef struct cape_config
                             cut in k sub-batches that alternate between two internal streams (forked from / joined
                             into the caller's stream), so the latency-bound grow kernel of one sub-batch overlaps
                             the streaming cell kernel of the next */
+    int32_t spill_records; /* records (each with its own boundary slab) in the handle's spill pool, shared by the frames of a batch
+                            that hold more than 64 plane segments or cylinder labels; 0 = max(8, max_batch / 8).  A frame needs
+                            ceil(n / 64) - 1 of them; at most cells / max(1, min(6, uint(0.0065 cells))) segments can exist */
 } cape_config;
 
 typedef struct cape_handle_s* cape_handle;
@@ -111,10 +122,10 @@ typedef struct cape_plane_segment
     double out_normal[3];   /* Plane::_parametrization normal (one more normalisation) ; valid if is_output */
     double cov[9];          /* Plane_Segment::get_point_cloud_covariance(), row-major ; valid if is_output */
     uint32_t point_count;
-    uint32_t merge_label;   /* planeMergeLabels[i] */
+    uint32_t merge_label;   /* planeMergeLabels[i]: index in the FRAME's segment list (may point into an earlier record of the chain) */
     uint32_t planar;
     uint32_t is_output;     /* root of its merge group, planar and >= 3 boundary points: becomes a `Plane` */
-    uint32_t boundary_offset; /* first point in the frame's boundary array */
+    uint32_t boundary_offset; /* first point in the boundary slab of the record that holds this segment */
     uint32_t boundary_count;
 } cape_plane_segment;
 
@@ -128,18 +139,25 @@ typedef struct cape_cylinder
 
 typedef struct cape_frame_header
 {
-    int32_t n_plane_segments; /* _planeSegments.size() */
-    int32_t n_planes;         /* number of segments with is_output (= planeContainer.size() before polygon tests) */
-    int32_t n_cylinder_labels;/* cylinder2regionMap.size() */
-    int32_t n_cylinders;      /* cylinderContainer.size() */
-    int32_t n_boundary_points;
+    int32_t n_plane_segments; /* _planeSegments.size() -- counted FROM THIS RECORD ON: the frame's first record holds the whole
+                                 frame's count, the record itself the first min(64, n) of them, the rest follow next_record */
+    int32_t n_planes;         /* number of segments with is_output (= planeContainer.size() before polygon tests), from this record on */
+    int32_t n_cylinder_labels;/* cylinder2regionMap.size(), from this record on (the record holds the first min(64, n)) */
+    int32_t n_cylinders;      /* cylinderContainer.size(), from this record on */
+    int32_t n_boundary_points;/* points in THIS record's boundary slab */
     int32_t n_seeds;          /* iterations of the seed loop (debug) */
     uint32_t status;          /* CAPE_FRAME_* */
     int32_t n_planar_cells;
+    int32_t next_record;      /* -1, or the index in the handle's record array (>= max_batch: a spill record) of the record that
+                                 continues this frame: segments / cylinders 64.. of it, with its own boundary slab, polygons, vertices */
+    int32_t segment_base;     /* index of segments[0] (and cylinders[0]) of this record in the frame's lists: 0, 64, 128, ... */
 } cape_frame_header;
 
-/* Fixed-capacity per-frame record (stays on the producing GPU / goes to its host; the multi-GPU gather ships the packed
- * lists below). */
+/* Fixed-capacity record (stays on the producing GPU / goes to its host; the multi-GPU gather ships the packed lists below).
+ * The handle's record array holds max_batch records -- record f is frame f of the batch -- followed by the spill pool
+ * (cape_config.spill_records).  A frame with more than 64 plane segments (a checkerboard of small facets) or cylinder labels is a
+ * CHAIN of records linked by header.next_record; every record of the chain owns a boundary slab, a polygon row and a vertex slab
+ * at its own index, so whatever consumes "record i" (polygons, the host conversion) works on spill records unchanged. */
 typedef struct cape_frame_record
 {
     cape_frame_header header;
@@ -265,7 +283,9 @@ typedef struct cape_timings
      *                 cape_build_polygons or the host class; the overlay adds its own clock for it)
      * grow / merge / refine share the stage-B kernels: every frame's wave books the shader-clock ticks it spends in each of the
      * three (three atomics per frame, only while timing is on) and grow_s -- the kernels' HIP-event time -- is split in those
-     * proportions: grow_phase_s + merge_s + refine_s == grow_s. */
+     * proportions: grow_phase_s + merge_s + refine_s == grow_s.  The split is an ESTIMATE weighted by wave occupancy, not three wall
+     * times: a frame that is redone books its grow ticks in both passes, the workgroup finisher books one of its four waves, and only
+     * the SUM of the three is measured (the HIP events). */
     double reset_s, init_s, grow_phase_s, merge_s, refine_s;
 } cape_timings;
 
@@ -496,6 +516,17 @@ int cape_sync_results(cape_handle h, void* stream);
 int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* records, int32_t* plane_labels,
                       int32_t* cyl_labels, double* boundary);
 
+/* The spill pool of the last cape_extract (synchronous): *used = spill records handed out (a frame's chain is followed through
+ * header.next_record, spill record k has index max_batch + k), *capacity = cape_config.spill_records as resolved at create,
+ * *frames = frames of the batch that went through the general instance.  Any pointer may be NULL. */
+int cape_spill_info(cape_handle h, int32_t* used, int32_t* capacity, int32_t* frames);
+/* Synchronous D2H of spill records [first, first + count) -- record indices max_batch + first ... -- and their boundary slabs
+ * (count x boundary_capacity x 3 doubles).  Either pointer may be NULL. */
+int cape_copy_spill(cape_handle h, int32_t first, int32_t count, cape_frame_record* records, double* boundary);
+/* The polygon rows (count x CAPE_MAX_PLANES) and vertex slabs (count x boundary_capacity x 2 doubles) of the same spill records,
+ * after cape_build_polygons (which builds the polygons of every spill record in use together with the batch's). */
+int cape_copy_spill_polygons(cape_handle h, int32_t first, int32_t count, cape_polygon* polygons, double* vertices);
+
 /* Handles created with max_batch <= 8 (the reference's call pattern: one frame per call) keep records, label grids and
  * boundary points in pinned, device-mapped HOST memory: the kernels write them over PCIe directly and no device-to-host
  * copy exists on the latency path.  cape_host_results waits for the handle's stream and returns pointers to that memory
@@ -531,6 +562,8 @@ int cape_copy_seed_sequence(cape_handle h, int32_t frame, int32_t* seeds_out, in
  * pending events, folds them into the running sums and returns the sums; cape_reset_timings zeroes them. */
 int cape_enable_timing(cape_handle h, int32_t enable);
 int cape_get_timings(cape_handle h, cape_timings* out);
+/* the same for a caller compiled against another revision of cape_timings: writes min(out_bytes, sizeof(cape_timings)) bytes */
+int cape_get_timings_sized(cape_handle h, void* out, uint64_t out_bytes);
 int cape_reset_timings(cape_handle h);
 
 /* Debug / parity: evaluate device scalar math (f64 sqrt / div, ocml acos / atan2, the eigen-solver and plane fit)
@@ -584,6 +617,8 @@ int cape_log_records(const cape_frame_record* records, int32_t n_frames, cape_lo
 
 const char* cape_last_error(void);
 const char* cape_version(void);
+/* CAPE_ABI_VERSION of the library that was loaded: a binding compares it with the header it was built against before anything else */
+int32_t cape_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // There is no CPU fallback: without a HIP device cape_create fails with CAPE_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -21,8 +22,8 @@ hipError_t launch_cell_moments(const StageAParams& p, int nFrames, hipStream_t s
 hipError_t launch_cell_plane(const StageAParams& p, int nFrames, hipStream_t stream);
 hipError_t launch_cell_strips(const StageAParams& p, int nFrames, uint32_t* frameCounters, hipStream_t stream);
 int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
-hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side = nullptr, hipEvent_t fork = nullptr,
-                       hipEvent_t done = nullptr);
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done,
+                       const GenParams* gen);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 size_t grow_state_bytes(int cells);
 bool resume_group_fits(const StageBParams& p);
@@ -69,7 +70,11 @@ __global__ void cape_signal_kernel(uint32_t* flag, uint32_t seq)
 }
 
 constexpr int kHostResultFrames = 8; // see cape_handle_s::resultsOnHost
-constexpr int kRngTable = 40000; // upper bound on RANSAC draws per frame (cylinder section)
+// RANSAC draws a frame can ask for (the table of the first draws of mt19937(seed) the handle keeps on the device): a run_ransac_loop
+// takes at most 43 x 3 draws and every loop but a region's last removes at least six cells (cylinder_segment.cpp:154), so a frame of
+// C cells runs at most C / 6 + (regions <= C / 6) loops: 43 C draws bound it.  40 000 covers the 640 x 480 grid's 33 024 as before.
+constexpr int kRngTableMin = 40000;
+int rng_table_size(int cells) { const int need = 43 * cells + 129; return need > kRngTableMin ? need : kRngTableMin; }
 
 // Every entry point that allocates, copies, launches or synchronises runs with the HANDLE's device current, whatever
 // the calling thread had selected (one process may drive several GPUs, torch may leave another device current), and
@@ -119,6 +124,15 @@ struct cape_handle_s
     double* cylScratch = nullptr;
     uint32_t* needCylinder = nullptr; // [0] count, [1..] frames the plane-only pass handed to the cylinder kernel
     uint32_t* redoList = nullptr;     // [0] count, [1..] frames that need more than 32 plane-segment slots
+    // the general grow instance (cape_grow_general.hip): frames of more than 64 plane segments / cylinder labels, every frame of a grid
+    // beyond 64 x 64 cells
+    uint32_t* spillList = nullptr;    // [0] count, [1..] frames the 64-segment instance handed on
+    uint32_t* spillCounters = nullptr; // [0] records handed out of the pool by the call in flight, [1] frames through the general instance
+    unsigned char* genScratch = nullptr;
+    int spillRecords = 0;             // records of the pool = record indices [max_batch, max_batch + spillRecords)
+    bool generalAll = false;          // the grid is beyond the fast kernels' 64 x 64 cells: the general instance grows every frame
+    int rngCount = 0;                 // doubles of the RANSAC draw table (rng_table_size)
+    cape::GenParams gen{};
     // one-frame handles (max_batch <= kHostResultFrames): stage A runs as ONE launch of strip workgroups (cape_cell_strip_kernel);
     // a counter per frame tells the strip that finishes last.  nullptr: the two throughput kernels (debug knob CAPE_STAGE_A=bands)
     uint32_t* stripCounters = nullptr;
@@ -189,6 +203,7 @@ struct cape_handle_s
     cape_log_fn logFn = nullptr;
     void* logUser = nullptr;
     bool logPending = false; // a batch has been extracted whose records have not been through the callback yet
+    int logDone = 0;         // ... frames [0, logDone) of it have (a cape_copy_results of fewer frames than the batch delivers the rest later)
     // sub-batch pipelining (cfg.sub_batches > 1)
     hipStream_t pipeStream[2] = {nullptr, nullptr};
     hipEvent_t pipeFork = nullptr;
@@ -233,6 +248,7 @@ struct cape_handle_s
     double* matchPoses = nullptr;   // cape_match_polygons_pose: max_batch x 16 doubles, allocated on first use
     double* matchPosesStage = nullptr; // pinned twin the caller's poses are copied into before the call returns
     hipEvent_t matchPosesFree = nullptr; // recorded behind the H2D copy out of the twin: its next writer waits for it
+    bool matchPosesBusy = false;         // ... once it has been recorded
     cape_frame_match_exact* matchesExact = nullptr;
     unsigned* matchLists = nullptr; // counters (padded to 64 entries) + 4 lists of max_batch x 256 pairs
     int computeUnits = 0;           // CUs of the handle's device (queried on first use)
@@ -274,6 +290,9 @@ void free_all(cape_handle_s* h)
     (void)hipFree(h->cylScratch);
     (void)hipFree(h->needCylinder);
     (void)hipFree(h->redoList);
+    (void)hipFree(h->spillList);
+    (void)hipFree(h->spillCounters);
+    (void)hipFree(h->genScratch);
     (void)hipFree(h->stripCounters);
     (void)hipFree(h->doneCounter);
     (void)hipFree(h->resumeList);
@@ -419,6 +438,7 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
         b.growState += F * (size_t)b.growStateStride;
     }
     b.redoList += 2 * F;
+    b.spillList += 2 * F;
     b.seed_sequence += F * C;
     b.debugCycles += F * cape::kProfileSlots;
 }
@@ -427,9 +447,9 @@ int fold_timings(cape_handle_s* h);
 
 // utils::Random (src/utils/random.hpp:17-30, :59-64): the first kRngTable doubles of mt19937(seed) + uniform_real_distribution(0, 1)
 // (libstdc++ on the host = the reference's own generator)
-std::vector<double> rng_table(uint32_t seed)
+std::vector<double> rng_table(uint32_t seed, int count)
 {
-    std::vector<double> rng(kRngTable);
+    std::vector<double> rng((size_t)count);
     std::mt19937 engine(seed);
     std::uniform_real_distribution<double> dist(0.0, 1.0);
     for (auto& v : rng)
@@ -541,6 +561,8 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     a2.clear1 = b.needCylinder;
     a2.clear2 = b.resumeList;
     a2.clear2Buckets = b.resumeList ? b.resumeBucketStride : 0u;
+    a2.clear3 = b.spillList;
+    a2.clear4 = h->spillCounters;
     // A frame read straight from pinned host memory arrives at the link's pace (~34 us for 1.2 MB): the band kernel streams it in
     // and the plane kernel's 17 us follow; a strip's tail behind its last pixel is as long, so nothing is gained there (measured,
     // profiles/r04_single_frame_latency.txt).  With the frame in HBM the one-launch form is 5-10 us faster.
@@ -574,7 +596,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
     const bool oneFrameChain = h->resultsOnHost && h->doneFlag && h->doneCounter && frames <= kHostResultFrames;
     if (oneFrameChain)
     {
-        bb.allFrames = 1;
+        bb.allFrames = h->generalAll ? 0 : 1;
         bb.doneFlag = h->doneFlag;
         bb.doneCounter = h->doneCounter;
         bb.doneSeq = ++h->doneSeq;
@@ -616,10 +638,10 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         if (probe)
             h->callsSinceProbe = 0;
     }
-    CAPE_HIP_TRY(cape::launch_grow(bb, frames, st, h->sideStream, h->sideFork, h->sideDone));
-    if (h->sideStream && bb.needCylinder)
+    CAPE_HIP_TRY(cape::launch_grow(bb, frames, st, h->generalAll ? nullptr : h->sideStream, h->sideFork, h->sideDone, &h->gen));
+    if (h->sideStream && bb.needCylinder && !h->generalAll)
         h->sidePending = true;
-    if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0)
+    if (bb.needCylinder && bb.twoPass && h->handedOverFrames == 0 && !h->generalAll)
     {
         CAPE_HIP_TRY(hipMemcpyAsync(h->handedOverHost, bb.needCylinder, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         if (bb.resumeList)
@@ -676,6 +698,8 @@ int wait_results(cape_handle_s* h)
 
 int fold_timings(cape_handle_s* h)
 {
+    if (h->evPending == 0 && h->tm.calls > 0)
+        return CAPE_OK; // nothing timed since the last fold: the sums (and the tick slots behind the split) are unchanged
     for (size_t i = 0; i < h->evPending; ++i)
     {
         auto& t = h->evPool[i];
@@ -716,8 +740,9 @@ int fold_timings(cape_handle_s* h)
     return CAPE_OK;
 }
 
-// the reference's hot-path log lines of one frame, from its record (cape_set_log_callback)
-int log_frame(cape_log_fn fn, void* user, const cape_frame_record& r, int frame)
+// the reference's hot-path log lines of one frame, from its record (cape_set_log_callback).  `next`: where the records a frame
+// continues in (cape_frame_header::next_record) are found -- null if the caller has none of them at hand
+template <typename NextFn> int log_frame(cape_log_fn fn, void* user, const cape_frame_record& r, int frame, NextFn next)
 {
     int lines = 0;
     const uint32_t st = r.header.status;
@@ -727,12 +752,21 @@ int log_frame(cape_log_fn fn, void* user, const cape_frame_record& r, int frame)
         fn(0, "Plane segment is not planar after merge", frame, user);
     if (st & CAPE_FRAME_INVALID_SEED) // ends the seed loop: the last line of the grow step
         fn(1, "Could not find a single plane segment: invalid seed", frame, user), ++lines;
-    const int n = r.header.n_plane_segments < CAPE_MAX_PLANES ? r.header.n_plane_segments : CAPE_MAX_PLANES;
-    for (int i = 0; i < n; ++i)
+    // (a chain only ever points FORWARD in the record array -- a spill record's index is beyond the batch's and its successor's beyond
+    // its own --, so a zero-filled or damaged link cannot loop)
+    int at = frame;
+    for (const cape_frame_record* q = &r; q;)
     {
-        const cape_plane_segment& s = r.segments[i];
-        if (s.merge_label == (uint32_t)i && s.planar && s.boundary_count < 3)
-            fn(1, "Could not find a correct boundary polygon, rejecting plane segment", frame, user), ++lines;
+        const int n = q->header.n_plane_segments < CAPE_MAX_PLANES ? q->header.n_plane_segments : CAPE_MAX_PLANES;
+        for (int i = 0; i < n; ++i)
+        {
+            const cape_plane_segment& s = q->segments[i];
+            if (s.merge_label == (uint32_t)(i + q->header.segment_base) && s.planar && s.boundary_count < 3)
+                fn(1, "Could not find a correct boundary polygon, rejecting plane segment", frame, user), ++lines;
+        }
+        const int nxt = q->header.next_record;
+        q = nxt > at ? next(nxt) : nullptr;
+        at = nxt;
     }
     if (st & (CAPE_FRAME_PLANE_OVERFLOW | CAPE_FRAME_CYL_OVERFLOW | CAPE_FRAME_BOUNDARY_OVERFLOW))
         fn(1, "find_primitives: per-frame capacity exceeded, primitive list truncated", frame, user), ++lines;
@@ -742,9 +776,22 @@ void log_batch(cape_handle_s* h, const cape_frame_record* records, int n)
 {
     if (!h->logFn || !h->logPending || !records)
         return;
-    h->logPending = false;
-    for (int f = 0; f < n && f < h->lastFrames; ++f)
-        (void)log_frame(h->logFn, h->logUser, records[f], f);
+    const int upTo = n < h->lastFrames ? n : h->lastFrames;
+    // spill records (frames of more than 64 plane segments) are fetched from the handle's pool when a frame points at one
+    cape_frame_record spill;
+    auto next = [&](int idx) -> const cape_frame_record* {
+        if (idx < h->cfg.max_batch || idx >= h->cfg.max_batch + h->spillRecords)
+            return nullptr;
+        if (h->resultsOnHost)
+            return h->records + idx;
+        return hipMemcpy(&spill, h->records + idx, sizeof(spill), hipMemcpyDeviceToHost) == hipSuccess ? &spill : nullptr;
+    };
+    for (int f = h->logDone; f < upTo; ++f) // every frame of the batch once, whichever copy brings it to the host first
+        (void)log_frame(h->logFn, h->logUser, records[f], f, next);
+    if (upTo > h->logDone)
+        h->logDone = upTo;
+    if (h->logDone >= h->lastFrames)
+        h->logPending = false;
 }
 
 } // namespace
@@ -752,7 +799,8 @@ void log_batch(cape_handle_s* h, const cape_frame_record* records, int n)
 extern "C" {
 
 const char* cape_last_error(void) { return g_lastError.c_str(); }
-const char* cape_version(void) { return "cape_hip 0.1 (gfx950)"; }
+const char* cape_version(void) { return "cape_hip 0.2 (gfx950)"; }
+int32_t cape_abi_version(void) { return CAPE_ABI_VERSION; }
 
 int cape_device_count(int32_t* count_out)
 {
@@ -771,9 +819,13 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     if (!cfg || !out)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % CAPE_CELL_SIZE || cfg->height % CAPE_CELL_SIZE ||
-        cfg->width > 1280 || cfg->height > 1280 || cfg->max_batch <= 0)
-        return fail(CAPE_ERR_INVALID_ARGUMENT, "width/height must be positive multiples of 20, <= 1280; max_batch > 0");
+    // any image the reference's constructor takes (primitive_detection.cpp:26-67: whole cells of 20 px) up to the widths of the
+    // index types used here: 16-bit cell numbers (65 535 cells), one stage-A2 tile row per workgroup (256 cells = 5120 px wide)
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % CAPE_CELL_SIZE || cfg->height % CAPE_CELL_SIZE || cfg->max_batch <= 0 ||
+        cfg->spill_records < 0)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "width/height must be positive multiples of 20; max_batch > 0; spill_records >= 0");
+    if (cfg->width / CAPE_CELL_SIZE > 256 || (long long)(cfg->width / CAPE_CELL_SIZE) * (cfg->height / CAPE_CELL_SIZE) > 65535)
+        return fail(CAPE_ERR_UNSUPPORTED, "cell grid beyond 256 cells wide (5120 px) or 65 535 cells");
     if (!(cfg->fx > 0) || !(cfg->fy > 0))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "focal lengths must be positive");
     if (cfg->flags & ~(uint32_t)(CAPE_FLAG_CYLINDERS | CAPE_FLAG_ASYNC_SECOND_PASS))
@@ -810,6 +862,20 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     h->cells = h->hCells * h->vCells;
     h->boundaryCap = cfg->boundary_capacity > 0 ? cfg->boundary_capacity : 2 * h->cells;
     const size_t B = (size_t)cfg->max_batch, C = (size_t)h->cells;
+    h->generalAll = h->hCells > 64 || h->vCells > 64; // beyond "one lane per grid row, one mask word per row"
+    if (const char* e = std::getenv("CAPE_GROW")) // debug knob: "general" sends every frame through the general instance
+    {
+        if (std::string(e) == "general")
+            h->generalAll = true;
+        else if (std::string(e) != "fast")
+        {
+            delete h;
+            return fail(CAPE_ERR_INVALID_ARGUMENT, "CAPE_GROW must be general or fast");
+        }
+    }
+    h->spillRecords = cfg->spill_records > 0 ? cfg->spill_records : std::max(8, cfg->max_batch / 8);
+    h->rngCount = rng_table_size(h->cells);
+    const size_t R = B + (size_t)h->spillRecords; // records / boundary slabs: the batch's, then the spill pool
 
 #define CAPE_ALLOC(expr)                                                                                     \
     do                                                                                                       \
@@ -827,7 +893,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(dalloc(h->brow, cfg->height));
     CAPE_ALLOC(dalloc(h->ratioCol, h->hCells));
     CAPE_ALLOC(dalloc(h->ratioRow, h->vCells));
-    CAPE_ALLOC(dalloc(h->rng, kRngTable));
+    CAPE_ALLOC(dalloc(h->rng, (size_t)h->rngCount));
     CAPE_ALLOC(dalloc(h->cellSums, B * C * cape::kSumStride));
     CAPE_ALLOC(dalloc(h->cellPlane, B * C * cape::kPlaneStride));
     CAPE_ALLOC(dalloc(h->cellScore, B * C));
@@ -855,6 +921,10 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         CAPE_ALLOC(hipEventCreateWithFlags(&h->handedOverReady, hipEventDisableTiming));
     }
     CAPE_ALLOC(dalloc(h->redoList, 2 * B + 2));
+    CAPE_ALLOC(dalloc(h->spillList, 2 * B + 2));
+    CAPE_ALLOC(hipMemset(h->spillList, 0, (2 * B + 2) * sizeof(uint32_t)));
+    CAPE_ALLOC(dalloc(h->spillCounters, 2));
+    CAPE_ALLOC(hipMemset(h->spillCounters, 0, 2 * sizeof(uint32_t)));
     {
         const char* stageA = std::getenv("CAPE_STAGE_A");
         if (cfg->max_batch <= kHostResultFrames && cfg->sub_batches <= 1 && !(stageA && std::string(stageA) == "bands"))
@@ -881,19 +951,19 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     h->resultsOnHost = cfg->max_batch <= kHostResultFrames;
     if (h->resultsOnHost)
     {
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->records), B * sizeof(cape_frame_record), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->records), R * sizeof(cape_frame_record), hipHostMallocMapped | hipHostMallocCoherent));
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->planeLabels), B * C * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->cylLabels), B * C * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
-        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), B * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->boundary), R * (size_t)h->boundaryCap * 3 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         CAPE_ALLOC(hipHostMalloc(reinterpret_cast<void**>(&h->doneFlag), 64, hipHostMallocMapped | hipHostMallocCoherent));
         *h->doneFlag = 0;
     }
     else
     {
-        CAPE_ALLOC(dalloc(h->records, B));
+        CAPE_ALLOC(dalloc(h->records, R));
         CAPE_ALLOC(dalloc(h->planeLabels, B * C));
         CAPE_ALLOC(dalloc(h->cylLabels, B * C));
-        CAPE_ALLOC(dalloc(h->boundary, B * (size_t)h->boundaryCap * 3));
+        CAPE_ALLOC(dalloc(h->boundary, R * (size_t)h->boundaryCap * 3));
     }
 
     // ---- constant tables
@@ -925,7 +995,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         return r;
     };
     const std::vector<float> rc = ratios(acol, h->hCells), rr = ratios(brow, h->vCells);
-    const std::vector<double> rng = rng_table(0u); // MAKE_DETERMINISTIC's seed; cape_set_rng_seed changes it
+    const std::vector<double> rng = rng_table(0u, h->rngCount); // MAKE_DETERMINISTIC's seed; cape_set_rng_seed changes it
     {
         // _Xpre / _Ypre of Depth_Map_Transformation::init_matrices (depth_map_transformation.cpp:156-161)
         std::vector<float> xp(acol.begin(), acol.end()), yp(brow.begin(), brow.end());
@@ -940,9 +1010,9 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     CAPE_ALLOC(hipMemcpy(h->ratioRow, rr.data(), rr.size() * sizeof(float), hipMemcpyHostToDevice));
     CAPE_ALLOC(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
     if (h->resultsOnHost)
-        std::memset(h->records, 0, B * sizeof(cape_frame_record));
+        std::memset(h->records, 0, R * sizeof(cape_frame_record));
     else
-        CAPE_ALLOC(hipMemset(h->records, 0, B * sizeof(cape_frame_record)));
+        CAPE_ALLOC(hipMemset(h->records, 0, R * sizeof(cape_frame_record)));
 
     // ---- kernel parameter blocks
     cape::StageAParams& a = h->pa;
@@ -1003,6 +1073,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.cylScratch = h->cylScratch;
     b.needCylinder = h->needCylinder;
     b.redoList = h->redoList;
+    b.spillList = h->spillList;
     b.resumeList = h->resumeList;
     b.resumeBucketStride = h->resumeList ? (uint32_t)(2 * B + 2) : 0u;
     b.growState = h->growState;
@@ -1021,14 +1092,44 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     }
     b.twoPass = h->needCylinder ? 1 : 0;
     b.ldsLimitBytes = h->ldsLimit;
-    if (cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > (size_t)h->ldsLimit)
+    if (!h->generalAll && cape::grow_lds_bytes(h->cells, (cfg->flags & CAPE_FLAG_CYLINDERS) != 0, CAPE_MAX_PLANES) > (size_t)h->ldsLimit)
+        h->generalAll = true; // (a device with less LDS than the 64-segment instance wants: the general instance needs 20 KB)
     {
-        free_all(h);
-        delete h;
-        return fail(CAPE_ERR_UNSUPPORTED, "cell grid too large for the LDS-resident grow kernel on this device (" +
-                                                  std::to_string(ldsLimit) + " bytes of LDS per workgroup)");
+        // the general instance: a persistent grid of waves, one scratch slot each (two workgroups per CU hold its 64 KB of LDS; a handle
+        // whose frames only reach it through the spill list gets by with fewer)
+        const bool cyl = (cfg->flags & CAPE_FLAG_CYLINDERS) != 0;
+        cape::GenParams& g = h->gen;
+        g.slotBytes = cape::general_slot_bytes(h->cells, h->hCells, h->vCells, cyl, b.minCellActivated, &g.capSeg, &g.capCyl);
+        g.ldsBytes = (int)cape::general_lds_bytes(h->cells, h->hCells, h->vCells, cyl, g.capSeg, g.capCyl, h->ldsLimit);
+        if (g.ldsBytes <= 0)
+        {
+            free_all(h);
+            delete h;
+            return fail(CAPE_ERR_UNSUPPORTED, "this device offers too little LDS per workgroup for the grow kernels (" + std::to_string(ldsLimit) + " bytes)");
+        }
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        size_t slots = h->generalAll ? (size_t)2 * cus : (size_t)std::min(cus, 64);
+        if (const char* e = std::getenv("CAPE_GENERAL_SLOTS"))
+            slots = (size_t)std::max(1, std::atoi(e));
+        slots = std::min(slots, B);
+        while (slots > 1 && slots * g.slotBytes > ((size_t)2 << 30)) // keep the scratch under 2 GB whatever the grid
+            slots /= 2;
+        g.scratchSlots = (int)slots;
+        CAPE_ALLOC(hipMalloc(reinterpret_cast<void**>(&h->genScratch), slots * g.slotBytes));
+        g.scratch = h->genScratch;
+        g.spillAlloc = h->spillCounters;
+        g.genFrames = h->spillCounters + 1;
+        g.poolRecords = h->records + B;
+        g.poolBoundary = h->boundary + B * (size_t)h->boundaryCap * 3;
+        g.poolCapacity = h->spillRecords;
+        g.poolBase = cfg->max_batch;
+        g.rowWords = (h->hCells + 63) / 64;
+        g.allFrames = h->generalAll ? 1 : 0;
     }
-    if (h->needCylinder)
+    if (h->needCylinder && !h->generalAll)
     {
         hipDeviceProp_t prop;
         const int perCu = cape::grow_waves_per_cu(h->pb);
@@ -1041,7 +1142,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     b.phaseTicks = nullptr; // set per launch (launch_chain) while timing is on
     b.seed_sequence = h->seedSeq;
     b.rngTable = h->rng;
-    b.rngCount = kRngTable;
+    b.rngCount = h->rngCount;
     // cylinder_segment.cpp:132
     b.ransacMaxIterations = static_cast<int>(static_cast<unsigned>(logf(1.0f - 0.8f) / logf(1.0f - powf(0.33f, 3.0f))));
 
@@ -1116,6 +1217,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
         return fail(CAPE_ERR_INVALID_ARGUMENT, "depth must be aligned to four pixels (16 bytes of float32, 8 bytes of uint16)");
     h->lastFrames = n_frames;
     h->logPending = n_frames > 0; // cape_set_log_callback: this batch's records have not reached the host yet
+    h->logDone = 0;
     h->polygonFrames = 0; // the polygons on the device belong to the previous batch
     h->matchExactFrames = 0; // and so do the polygon matches
     if (n_frames == 0)
@@ -1132,6 +1234,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     if (h->cfg.sub_batches > 1 && n_frames >= 2 * h->cfg.sub_batches)
     {
         // fork: both internal streams wait for everything already enqueued on the caller's stream
+        CAPE_HIP_TRY(hipMemsetAsync(h->spillCounters, 0, 2 * sizeof(uint32_t), stream));
         CAPE_HIP_TRY(hipEventRecord(h->pipeFork, stream));
         for (auto& st : h->pipeStream)
             CAPE_HIP_TRY(hipStreamWaitEvent(st, h->pipeFork, 0));
@@ -1168,13 +1271,15 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
             a.clear1 = b.needCylinder;
             a.clear2 = b.resumeList;
             a.clear2Buckets = b.resumeList ? b.resumeBucketStride : 0u;
+            a.clear3 = b.spillList;
+            a.clear4 = nullptr; // (the pool's counters are shared by the sub-batches: cleared once, in front of the fork)
             CAPE_HIP_TRY(cape::launch_cell_plane(a, f1 - f0, h->pipeStream[1]));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[2], h->pipeStream[1]));
             b.a2RowsPerTile = cape::cell_plane_rows_per_tile(a, f1 - f0);
             b.countersCleared = 1;
             b.phaseTicks = t ? h->phaseTicks : nullptr;
-            CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1]));
+            CAPE_HIP_TRY(cape::launch_grow(b, f1 - f0, h->pipeStream[1], nullptr, nullptr, nullptr, &h->gen));
             if (t)
                 CAPE_HIP_TRY(hipEventRecord(t->e[3], h->pipeStream[1]));
         }
@@ -1938,7 +2043,7 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h);
-    const size_t B = (size_t)h->cfg.max_batch;
+    const size_t B = (size_t)h->cfg.max_batch + (size_t)h->spillRecords; // a polygon row / vertex slab per record, spill pool included
     if (!h->polygons)
     {
         if (h->resultsOnHost)
@@ -1977,6 +2082,9 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     p.vertices = reinterpret_cast<double2*>(h->polyVertices);
     p.boundaryCapacity = h->boundaryCap;
     p.prof = h->debugCycles;
+    p.poolBase = h->cfg.max_batch;
+    p.poolCapacity = h->spillRecords;
+    p.poolUsed = h->spillCounters;
 #ifdef CAPE_POLY_PROFILE
     CAPE_HIP_TRY(hipMemsetAsync(h->debugCycles, 0, (size_t)n_frames * cape::kProfileSlots * 8, stream));
     CAPE_HIP_TRY(hipMemsetAsync(h->debugCycles + 6, 0xFF, 2 * 8, stream)); // the two minima of the task kernel's timeline
@@ -2031,15 +2139,15 @@ static int match_polygons_impl(cape_handle h, int32_t n_frames, const double* pr
         if (!h->matchPoses)
             CAPE_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->matchPoses), (size_t)h->cfg.max_batch * 16 * sizeof(double)));
         if (!h->matchPosesStage)
-        {
             CAPE_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->matchPosesStage), (size_t)h->cfg.max_batch * 16 * sizeof(double), hipHostMallocDefault));
+        if (!h->matchPosesFree) // (its own guard: a failed creation must not leave the stage without its event for good)
             CAPE_HIP_TRY(hipEventCreateWithFlags(&h->matchPosesFree, hipEventDisableTiming));
-        }
-        else
+        if (h->matchPosesBusy)
             CAPE_HIP_TRY(hipEventSynchronize(h->matchPosesFree));
         std::memcpy(h->matchPosesStage, prev_to_cur, poseBytes);
         CAPE_HIP_TRY(hipMemcpyAsync(h->matchPoses, h->matchPosesStage, poseBytes, hipMemcpyHostToDevice, stream));
         CAPE_HIP_TRY(hipEventRecord(h->matchPosesFree, stream));
+        h->matchPosesBusy = true;
         p.poses = h->matchPoses;
     }
     p.records = h->records;
@@ -2105,6 +2213,70 @@ int cape_copy_polygons(cape_handle h, int32_t n_frames, cape_polygon* polygons, 
         CAPE_HIP_TRY(hipMemcpy(polygons, h->polygons, n * CAPE_MAX_PLANES * sizeof(cape_polygon), kind));
     if (vertices)
         CAPE_HIP_TRY(hipMemcpy(vertices, h->polyVertices, n * (size_t)h->boundaryCap * 2 * sizeof(double), kind));
+    return CAPE_OK;
+}
+
+int cape_spill_info(cape_handle h, int32_t* used, int32_t* capacity, int32_t* frames)
+{
+    if (!h)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
+    CAPE_ON_DEVICE(h);
+    uint32_t c[2] = {0u, 0u};
+    if (h->lastFrames > 0)
+    {
+        if (h->resultsOnHost)
+        {
+            if (const int rc = wait_results(h); rc != CAPE_OK)
+                return rc;
+        }
+        else
+            CAPE_HIP_TRY(drain_handle(h));
+        CAPE_HIP_TRY(hipMemcpy(c, h->spillCounters, sizeof(c), hipMemcpyDeviceToHost));
+    }
+    if (used)
+        *used = (int32_t)std::min<uint32_t>(c[0], (uint32_t)h->spillRecords);
+    if (capacity)
+        *capacity = h->spillRecords;
+    if (frames)
+        *frames = (int32_t)c[1];
+    return CAPE_OK;
+}
+
+int cape_copy_spill(cape_handle h, int32_t first, int32_t count, cape_frame_record* records, double* boundary)
+{
+    if (!h || first < 0 || count < 0 || first + count > h->spillRecords)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / spill record range");
+    CAPE_ON_DEVICE(h);
+    if (h->resultsOnHost)
+    {
+        if (const int rc = wait_results(h); rc != CAPE_OK)
+            return rc;
+    }
+    else
+        CAPE_HIP_TRY(drain_handle(h));
+    const size_t at = (size_t)h->cfg.max_batch + (size_t)first, n = (size_t)count;
+    const hipMemcpyKind kind = h->resultsOnHost ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+    if (records && n)
+        CAPE_HIP_TRY(hipMemcpy(records, h->records + at, n * sizeof(cape_frame_record), kind));
+    if (boundary && n)
+        CAPE_HIP_TRY(hipMemcpy(boundary, h->boundary + at * (size_t)h->boundaryCap * 3, n * (size_t)h->boundaryCap * 3 * sizeof(double), kind));
+    return CAPE_OK;
+}
+
+int cape_copy_spill_polygons(cape_handle h, int32_t first, int32_t count, cape_polygon* polygons, double* vertices)
+{
+    if (!h || first < 0 || count < 0 || first + count > h->spillRecords)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / spill record range");
+    if (!h->polygons || h->polygonFrames <= 0)
+        return fail(CAPE_ERR_CAPACITY, "no cape_build_polygons has run on the current batch");
+    CAPE_ON_DEVICE(h);
+    CAPE_HIP_TRY(drain_handle(h));
+    const size_t at = (size_t)h->cfg.max_batch + (size_t)first, n = (size_t)count;
+    const hipMemcpyKind kind = h->resultsOnHost ? hipMemcpyHostToHost : hipMemcpyDeviceToHost;
+    if (polygons && n)
+        CAPE_HIP_TRY(hipMemcpy(polygons, h->polygons + at * CAPE_MAX_PLANES, n * CAPE_MAX_PLANES * sizeof(cape_polygon), kind));
+    if (vertices && n)
+        CAPE_HIP_TRY(hipMemcpy(vertices, h->polyVertices + at * (size_t)h->boundaryCap * 2, n * (size_t)h->boundaryCap * 2 * sizeof(double), kind));
     return CAPE_OK;
 }
 
@@ -2228,8 +2400,10 @@ int cape_log_records(const cape_frame_record* records, int32_t n_frames, cape_lo
     if (!records || !fn || n_frames < 0)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null records / callback or negative frame count");
     int lines = 0;
+    // (a chain is followed as far as the caller's array reaches: records + pool copied together hold all of it)
+    auto next = [&](int idx) -> const cape_frame_record* { return idx >= 0 && idx < n_frames ? records + idx : nullptr; };
     for (int f = 0; f < n_frames; ++f)
-        lines += log_frame(fn, user, records[f], f);
+        lines += log_frame(fn, user, records[f], f, next);
     return lines;
 }
 
@@ -2252,7 +2426,7 @@ int cape_set_rng_seed(cape_handle h, uint32_t seed)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "null handle");
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(drain_handle(h)); // a grow kernel in flight may still be drawing from the table
-    const std::vector<double> rng = rng_table(seed);
+    const std::vector<double> rng = rng_table(seed, h->rngCount);
     CAPE_HIP_TRY(hipMemcpy(h->rng, rng.data(), rng.size() * sizeof(double), hipMemcpyHostToDevice));
     return CAPE_OK;
 }
@@ -2283,6 +2457,18 @@ int cape_get_timings(cape_handle h, cape_timings* out)
     if (rc != CAPE_OK)
         return rc;
     *out = h->tm;
+    return CAPE_OK;
+}
+
+int cape_get_timings_sized(cape_handle h, void* out, uint64_t out_bytes)
+{
+    if (!h || !out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    CAPE_ON_DEVICE(h);
+    const int rc = fold_timings(h);
+    if (rc != CAPE_OK)
+        return rc;
+    std::memcpy(out, &h->tm, (size_t)std::min<uint64_t>(out_bytes, sizeof(cape_timings)));
     return CAPE_OK;
 }
 

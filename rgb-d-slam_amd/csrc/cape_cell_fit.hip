@@ -197,6 +197,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? CAPE_A2_WAVES : 4) void c
                 for (int c = 1; c <= kResumeClasses; ++c)
                     p.clear2[(size_t)c * p.clear2Buckets] = 0u;
         }
+        if (p.clear3)
+            *p.clear3 = 0u;
+        if (p.clear4)
+            p.clear4[0] = p.clear4[1] = 0u; // records handed out of the spill pool, frames through the general instance
     }
     const int HC = p.hCells, VC = p.vCells;
     const int rowsPerTile = THREADS / HC > 0 ? THREADS / HC : 1;
@@ -341,6 +345,10 @@ template <bool U16> __global__ __launch_bounds__(kStripThreads) void cape_cell_s
                 for (int c = 1; c <= kResumeClasses; ++c)
                     p.clear2[(size_t)c * p.clear2Buckets] = 0u;
         }
+        if (p.clear3)
+            *p.clear3 = 0u;
+        if (p.clear4)
+            p.clear4[0] = p.clear4[1] = 0u; // records handed out of the spill pool, frames through the general instance
     }
     const int HC = p.hCells, VC = p.vCells;
     const int stripsPerRow = (HC + kStripCells - 1) / kStripCells;

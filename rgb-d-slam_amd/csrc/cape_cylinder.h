@@ -52,7 +52,9 @@ namespace cape {
 #define CAPE_CYL_COUNT(k, v)
 #endif
 
-struct CylCtx
+// LabT: the type of a cell label in the instance's working grids -- a byte in the LDS-resident instances (<= 64 segments),
+// 16 bits in the general instance (cape_grow_general.hip: any number of segments)
+template <typename LabT> struct CylCtxT
 {
     const StageBParams* p;
     int lane;
@@ -68,12 +70,14 @@ struct CylCtx
     double* scratch;              // [N][kCylStride] projected normals / projected centroids / their dot product
     double* s_stage;              // kStageChunk x 10 f64 staging buffer (cape_staged.h)
     double* s_seg;
-    unsigned char* s_lab;
-    unsigned char* s_cyl;
-    cape_frame_record* rec;
+    LabT* s_lab;
+    LabT* s_cyl;
+    cape_cylinder* cylOut;        // where cylinder label k's record goes (the frame record's array; the general instance's scratch)
+    int maxCylinders;             // ... and how many it holds
     int maxPlanes;                // segment slots of this kernel instance
     unsigned long long* dbg;      // per-frame phase ticks (profiling builds)
 };
+using CylCtx = CylCtxT<unsigned char>;
 
 // The RANSAC distance pass.  The cells a lane evaluates (idsLeft[lane + 64 k]) do not change during one
 // run_ransac_loop, so with up to kCylCacheRounds x 64 cells left (the whole 640x480 grid) their six projected coordinates
@@ -188,7 +192,10 @@ template <int STRIDE> __device__ __forceinline__ double ordered_sum_lds(const do
 }
 
 // returns with nSeg / nCylLabels / rngPos / status updated; nCylFits is incremented by the caller
-__device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLabels, int nCylFits, int& rngPos,
+// planeOverflow: the instance is out of segment slots OR out of cylinder slots -- either way the frame goes to the next larger
+// instance (the 64-segment one, then the general one, whose capacities are the grid's own bounds)
+template <typename LabT>
+__device__ inline void cylinder_fitting(const CylCtxT<LabT>& c, int& nSeg, int& nCylLabels, int nCylFits, int& rngPos,
                                         uint32_t& status, bool& planeOverflow)
 {
     const StageBParams& p = *c.p;
@@ -647,18 +654,18 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             ++nSeg;
             for (int i = lane; i < N; i += 64)
                 if (c.s_best[i])
-                    c.s_lab[c.s_list[i]] = (unsigned char)nSeg;
+                    c.s_lab[c.s_list[i]] = (LabT)nSeg;
         }
         else
         {
-            if (nCylLabels >= CAPE_MAX_CYLINDERS)
+            if (nCylLabels >= c.maxCylinders)
             {
-                status |= CAPE_FRAME_CYL_OVERFLOW;
+                planeOverflow = true;
                 return;
             }
             if (lane == 0)
             {
-                cape_cylinder* o = &c.rec->cylinders[nCylLabels];
+                cape_cylinder* o = &c.cylOut[nCylLabels];
                 o->axis[0] = ax; o->axis[1] = ay; o->axis[2] = az;
                 o->radius = __builtin_nan(""); // shape_primitives.cpp:17-24 over a copy whose _segmentCount is 0
                 o->kept = 0;
@@ -667,7 +674,7 @@ __device__ inline void cylinder_fitting(const CylCtx& c, int& nSeg, int& nCylLab
             ++nCylLabels;
             for (int i = lane; i < N; i += 64)
                 if (c.s_best[i])
-                    c.s_cyl[c.s_list[i]] = (unsigned char)nCylLabels;
+                    c.s_cyl[c.s_list[i]] = (LabT)nCylLabels;
         }
         CAPE_CYL_SYNC();
         CAPE_CYL_TICK(22); // model selection + labels

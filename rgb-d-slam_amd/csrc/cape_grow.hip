@@ -622,6 +622,14 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                             book_grow_ticks();
                             return;
                         }
+                        if (kRedo && p.spillList)
+                        {
+                            // more than a record holds: the general instance redoes the frame into a chain of records
+                            if (lane == 0)
+                                p.spillList[1 + atomicAdd(&p.spillList[0], 1u)] = (uint32_t)frame;
+                            book_grow_ticks();
+                            return;
+                        }
                         status |= CAPE_FRAME_PLANE_OVERFLOW;
                         stopAll = true;
                         break;
@@ -716,7 +724,8 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                     cc.s_seg = s_seg;
                     cc.s_lab = s_lab;
                     cc.s_cyl = s_cyl;
-                    cc.rec = p.records + frame;
+                    cc.cylOut = p.records[frame].cylinders;
+                    cc.maxCylinders = CAPE_MAX_CYLINDERS;
                     cc.maxPlanes = MAXP;
 #ifdef CAPE_B_PROFILE
                     cc.dbg = s_prof;
@@ -733,6 +742,13 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                         {
                             if (lane == 0)
                                 p.redoList[1 + atomicAdd(&p.redoList[0], 1u)] = (uint32_t)frame;
+                            book_grow_ticks();
+                            return;
+                        }
+                        if (kRedo && p.spillList)
+                        {
+                            if (lane == 0)
+                                p.spillList[1 + atomicAdd(&p.spillList[0], 1u)] = (uint32_t)frame;
                             book_grow_ticks();
                             return;
                         }
@@ -805,7 +821,9 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
             if (atomicAdd(p.doneCounter, 1u) == total - 1u)
             {
                 atomicExch(p.doneCounter, 0u); // ready for the next chain
-                __hip_atomic_store(p.doneFlag, p.doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // a frame handed to the general instance is not done yet: that kernel, enqueued right behind, signals instead
+                if (!(p.spillList && atomicAdd(&p.spillList[0], 0u) != 0u))
+                    __hip_atomic_store(p.doneFlag, p.doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -868,6 +886,7 @@ int grow_waves_per_cu(const StageBParams& p)
 
 hipError_t launch_resume_group(const StageBParams& p, int nFrames, hipStream_t stream); // cape_resume.hip
 bool resume_group_fits(const StageBParams& p);
+hipError_t launch_grow_general(const StageBParams& p, const GenParams& g, int nFrames, hipStream_t stream); // cape_grow_general.hip
 
 namespace {
 
@@ -902,9 +921,15 @@ hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t s
 // `side` (optional): the SECOND pass -- everything behind the plane-only kernel, or the cylinder kernel alone -- is enqueued on
 // this stream, forked from `stream` through `fork` and closed by `done`; `stream` itself does not wait for it (the caller of
 // the next entry point on this handle does).  A second handle's streaming kernels then run under this one's slow tail.
-hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done)
+// `gen`: the general instance (cape_grow_general.hip) -- with gen->allFrames it is the ONLY grow kernel of the handle (grids beyond
+// 64 x 64 cells); otherwise it runs last, behind the 64-segment instance and on the same stream, over the frames that instance
+// listed in p.spillList (more than one record holds; none, as a rule: its waves leave at once).
+hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done,
+                       const GenParams* gen)
 {
     const bool cyl = (p.flags & CAPE_FLAG_CYLINDERS) != 0;
+    if (gen && gen->allFrames)
+        return launch_grow_general(p, *gen, nFrames, stream);
     if (!cyl)
         side = nullptr;
     hipStream_t second = side ? side : stream;
@@ -922,6 +947,8 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
             CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));
         else
             CAPE_LAUNCH_TRY((launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream)));
+        if (gen && p.spillList)
+            CAPE_LAUNCH_TRY(launch_grow_general(p, *gen, nFrames, stream));
         return hipSuccess;
     }
     // counters of the two hand-over lists ([0] = count, [1..] = frames)
@@ -932,6 +959,8 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
         CAPE_LAUNCH_TRY((launch_grow_variant<false, kFastPlanes>(p, nFrames, stream)));
         if (p.redoList)
             CAPE_LAUNCH_TRY((launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream))); // frames with more than 32 segments (rare)
+        if (gen && p.redoList && p.spillList)
+            CAPE_LAUNCH_TRY(launch_grow_general(p, *gen, nFrames, stream));                      // ... with more than 64
         return hipSuccess;
     }
     if (!p.twoPass)
@@ -964,6 +993,8 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
     }
     if (p.redoList)
         CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, second)));
+    if (gen && p.redoList && p.spillList)
+        CAPE_LAUNCH_TRY(launch_grow_general(p, *gen, nFrames, second));
     if (side)
         CAPE_LAUNCH_TRY(hipEventRecord(done, side));
     return hipSuccess;

@@ -559,6 +559,8 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
         rec->header.n_seeds = nSeeds;
         rec->header.status = status;
         rec->header.n_planar_cells = nPlanar;
+        rec->header.next_record = -1; // a frame of these instances fits its record (more than 64 segments: the general instance)
+        rec->header.segment_base = 0;
         if (p.phaseTicks)
             atomicAdd(&p.phaseTicks[(size_t)frame * 4 + 2], (unsigned long long)__builtin_amdgcn_s_memtime() - tRefine);
     }

@@ -68,6 +68,8 @@ struct StageAParams
     uint32_t* clear1; // stage A2, which always runs right before it on the same stream -- instead of memset nodes per call
     uint32_t* clear2;
     uint32_t clear2Buckets; // words between the resume list and each of its kResumeClasses cost-class lists (0: none), zeroed with clear2
+    uint32_t* clear3; // the spill list of the general grow instance: [0] frames listed
+    uint32_t* clear4; // ... and the allocation counter of the spill record pool (nullptr on a sub-batch: cleared once per call)
     double cosMergeA; // cos(18 * pi / 180), plane_segment.cpp:324 (the edge predicates of stage A2)
     int smallBatchFrames; // host side: batches up to this many frames run the latency-oriented kernel instances
     int minZeroPointCount; // floor(400 * 0.7f) = 280, plane_segment.hpp:33-34
@@ -104,6 +106,8 @@ struct StageBParams
     // cylinder branch; the cylinder kernel then redoes exactly the listed frames.  nullptr: single pass.
     uint32_t* needCylinder;
     uint32_t* redoList;      // same layout: frames that need more than kFastPlanes segment slots; nullptr = truncate + flag
+    uint32_t* spillList;     // same layout: frames the 64-segment instance ran out of record capacity on (more than 64 plane segments or
+                             // cylinder labels): the general instance (cape_grow_general.hip) redoes them into a chain of records
     // Hand-over WITH state (round 3): when the plane-only pass reaches a cylinder candidate after its seed loop has ended, it
     // parks what it has -- segments so far, the recorded regions with their fits, cell lists, labels -- in growState and
     // appends the frame to resumeList; the RESUME instance of the cylinder kernel picks the frame up at that region instead
@@ -136,6 +140,27 @@ struct StageBParams
     uint32_t* doneCounter;   // device: waves of the signalling kernel that are through
     uint32_t doneSeq;
 };
+
+// The general grow instance (cape_grow_general.hip): any grid size, any number of plane segments.  One wavefront per frame, its
+// working set carved out of LDS as far as that reaches and out of a scratch slot in HBM beyond; results go into a chain of
+// records (cape_frame_header::next_record) taken from the handle's spill pool.
+struct GenParams
+{
+    uint32_t* spillAlloc;            // records handed out of the pool by the call in flight (one counter per handle)
+    uint32_t* genFrames;             // frames that went through this instance in the call in flight (cape_spill_info)
+    cape_frame_record* poolRecords;  // the pool: record index poolBase + k
+    double* poolBoundary;            // k-th boundary slab of the pool (boundaryCapacity x 3 doubles each)
+    int poolCapacity, poolBase;
+    unsigned char* scratch;          // scratchSlots x slotBytes
+    size_t slotBytes;
+    int scratchSlots;
+    int ldsBytes;                    // dynamic LDS of the launch
+    int capSeg, capCyl;              // most plane segments / cylinder labels a frame of this grid can hold
+    int rowWords;                    // 64-bit words per bit row of the cell grid
+    int allFrames;                   // 1: wave k takes frames k, k + waves, ... of the call; 0: the frames on StageBParams::spillList
+};
+size_t general_slot_bytes(int cells, int hCells, int vCells, bool cylinders, int minCellActivated, int* capSeg, int* capCyl);
+size_t general_lds_bytes(int cells, int hCells, int vCells, bool cylinders, int capSeg, int capCyl, int ldsLimit);
 
 // N3: Depth_Map_Transformation::rectify_depth
 struct RectifyParams
@@ -221,6 +246,10 @@ struct PolygonParams
     uint32_t parkStride;      // boundaryCapacity + 2 * CAPE_MAX_PLANES (a plane's hull: length + at most count + 1 indices)
     int computeUnits;
     int originInCentroid;     // cape_debug_polygon only: the polygon's origin is read from the record's centroid field
+    // spill records (frames of more than 64 plane segments, cape_frame_header::next_record): record poolBase + k, k < min(*poolUsed,
+    // poolCapacity), is handled like one more frame -- every array above is indexed by the RECORD index and sized for the pool too
+    int poolBase = 0, poolCapacity = 0;
+    const uint32_t* poolUsed = nullptr;
     unsigned long long* prof; // [frames][kProfileSlots] phase ticks of a -DCAPE_POLY_PROFILE build (cape_debug_cycles), else unused
 };
 

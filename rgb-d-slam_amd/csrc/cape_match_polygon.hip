@@ -453,7 +453,9 @@ __device__ __forceinline__ int valid_planes(const cape_frame_record& rec, const 
     const bool isOut = lane < nSeg && rec.segments[lane].is_output != 0;
     const unsigned flags = isOut ? pol[lane].flags : 0u;
     const bool ok = isOut && (flags & CAPE_POLY_VALID) != 0 && pol[lane].vertex_count >= 3;
-    hostOnly = __ballot(isOut && (flags & CAPE_POLY_OVERFLOW) != 0) != 0ull;
+    // (a frame that continues in spill records -- more than 64 plane segments -- is the host class's as well: its kept planes are
+    // not all in this record)
+    hostOnly = __ballot(isOut && (flags & CAPE_POLY_OVERFLOW) != 0) != 0ull || rec.header.next_record >= 0;
     const unsigned long long m = __ballot(ok);
     // lane k takes the k-th set bit
     int seg = -1;

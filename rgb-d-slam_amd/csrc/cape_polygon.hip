@@ -1424,13 +1424,28 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
 {
     __shared__ unsigned s_cnt[kSizeBuckets + 1], s_base[kSizeBuckets + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frame = blockIdx.x * kListFrames + wave;
+    // virtual frames: the batch's records [0, nFrames), then the spill records in use (record index poolBase + k)
+    const int vframe = blockIdx.x * kListFrames + wave;
+    int frame = vframe;
+    bool live = vframe < nFrames;
+    if (!live && p.poolUsed && vframe - nFrames < p.poolCapacity && (unsigned)(vframe - nFrames) < *p.poolUsed)
+    {
+        frame = p.poolBase + (vframe - nFrames);
+        live = true;
+        if (pass == 0) // (the batch's rows were cleared by launch_polygons' memset; the pool's only where they are in use)
+        {
+            cape_polygon* row = p.polygons + (size_t)frame * CAPE_MAX_PLANES + lane;
+            uint32_t* w = reinterpret_cast<uint32_t*>(row);
+            for (int k = 0; k < (int)(sizeof(cape_polygon) / 4); ++k)
+                w[k] = 0u;
+        }
+    }
     if (threadIdx.x <= kSizeBuckets)
         s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     bool isOut = false;
     int nPts = 0;
-    if (frame < nFrames)
+    if (live)
     {
         const cape_frame_record& rec = p.records[frame];
         isOut = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
@@ -1536,7 +1551,7 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
             return e;
     if (const hipError_t e = hipMemsetAsync(p.queue, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
         return e;
-    const size_t wanted = polygon_queue_slots((size_t)nFrames);
+    const size_t wanted = polygon_queue_slots((size_t)nFrames + (size_t)p.poolCapacity);
     const size_t queue = wanted < (size_t)p.queueCapacity ? wanted : (size_t)p.queueCapacity;
     if (const hipError_t e = hipMemsetAsync(p.queue + kPolyListHeader, 0xFF, queue * sizeof(uint32_t), stream); e != hipSuccess)
         return e;
@@ -1544,13 +1559,13 @@ hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stre
         return e;
     for (int pass = 0; pass < 2; ++pass)
     {
-        hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames, pass);
+        hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + p.poolCapacity + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames, pass);
         if (const hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
     const int ldsSmall = (int)polygon_lds_bytes(kPolySmallPoints), ldsLarge = (int)polygon_lds_bytes(kPolyMaxPoints);
     // persistent grids: as many workgroups as the device holds at once (four waves per SIMD), never more than there can be planes
-    const int maxPlanes = nFrames * CAPE_MAX_PLANES;
+    const int maxPlanes = (nFrames + p.poolCapacity) * CAPE_MAX_PLANES;
     const int gridSmall = std::min(std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits * CAPE_POLY_OCC), (int)(kPolyQuitSlots / kPolyWavesPerGroup));
     const int gridLarge = std::min((maxPlanes + kPolyWavesPerGroup - 1) / kPolyWavesPerGroup, p.computeUnits);
     hipLaunchKernelGGL(cape_polygon_task_kernel, dim3(gridSmall), dim3(64 * kPolyWavesPerGroup), (size_t)ldsSmall * kPolyWavesPerGroup + 64, stream, p,

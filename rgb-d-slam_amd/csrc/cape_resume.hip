@@ -806,7 +806,7 @@ __device__ inline void cylinder_fitting_group(const GroupCtx& g, int& nSeg, int&
         {
             if (nCylLabels >= CAPE_MAX_CYLINDERS)
             {
-                status |= CAPE_FRAME_CYL_OVERFLOW;
+                planeOverflow = true; // out of cylinder slots: like a full segment list, the frame goes to the next larger instance
                 return;
             }
             if (tid == 0)

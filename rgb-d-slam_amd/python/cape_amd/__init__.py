@@ -13,7 +13,8 @@ PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # rgb-d-sl
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
 LIB_PATH = os.environ.get("CAPE_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libcape_hip.so")  # env: kernel experiments
 
-CAPE_MAX_PLANES = 64
+CAPE_ABI_VERSION = 2
+CAPE_MAX_PLANES = 64      # per RECORD: a frame with more continues in spill records (header.next_record)
 CAPE_MAX_CYLINDERS = 64
 CAPE_FLAG_CYLINDERS = 1
 CAPE_FLAG_ASYNC_SECOND_PASS = 2
@@ -34,7 +35,8 @@ class CapeError(RuntimeError):
 class cape_config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_double), ("fy", C.c_double),
                 ("cx", C.c_double), ("cy", C.c_double), ("flags", C.c_uint32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("boundary_capacity", C.c_int32), ("sub_batches", C.c_int32)]
+                ("max_batch", C.c_int32), ("boundary_capacity", C.c_int32), ("sub_batches", C.c_int32),
+                ("spill_records", C.c_int32)]
 
 
 class cape_layout(C.Structure):
@@ -71,7 +73,8 @@ PLANE_SEGMENT_DTYPE = np.dtype([
 CYLINDER_DTYPE = np.dtype([("axis", "<f8", 3), ("radius", "<f8"), ("kept", "<u4"), ("region", "<u4")], align=True)
 HEADER_DTYPE = np.dtype([
     ("n_plane_segments", "<i4"), ("n_planes", "<i4"), ("n_cylinder_labels", "<i4"), ("n_cylinders", "<i4"),
-    ("n_boundary_points", "<i4"), ("n_seeds", "<i4"), ("status", "<u4"), ("n_planar_cells", "<i4")], align=True)
+    ("n_boundary_points", "<i4"), ("n_seeds", "<i4"), ("status", "<u4"), ("n_planar_cells", "<i4"),
+    ("next_record", "<i4"), ("segment_base", "<i4")], align=True)
 FRAME_RECORD_DTYPE = np.dtype([
     ("header", HEADER_DTYPE), ("segments", PLANE_SEGMENT_DTYPE, CAPE_MAX_PLANES),
     ("cylinders", CYLINDER_DTYPE, CAPE_MAX_CYLINDERS)], align=True)
@@ -143,6 +146,7 @@ EXPORTED_SYMBOLS = [
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
     "cape_debug_polygon_queue", "cape_set_log_callback", "cape_log_records", "cape_debug_match_lists", "cape_set_rng_seed",
+    "cape_abi_version", "cape_spill_info", "cape_copy_spill", "cape_copy_spill_polygons", "cape_get_timings_sized",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -215,6 +219,13 @@ def load_library():
     L.cape_copy_seed_sequence.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.cape_last_error.restype = C.c_char_p
     L.cape_version.restype = C.c_char_p
+    L.cape_abi_version.restype = C.c_int32
+    L.cape_spill_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.cape_copy_spill.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    L.cape_copy_spill_polygons.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    L.cape_get_timings_sized.argtypes = [vp, vp, C.c_uint64]
+    if L.cape_abi_version() != CAPE_ABI_VERSION:
+        raise CapeError(f"{LIB_PATH} speaks ABI {L.cape_abi_version()}, this binding {CAPE_ABI_VERSION}: rebuild the library")
     _lib = L
     return L
 
@@ -225,23 +236,57 @@ def _check(L, code, what):
 
 
 class FrameResults:
-    """Host copy of one batch: records (structured array), label grids, boundary points."""
+    """Host copy of one batch: records (structured array), label grids, boundary points -- and the spill records of the frames
+    that hold more than 64 plane segments / cylinder labels (cape_frame_header.next_record), with their boundary slabs."""
 
-    def __init__(self, records, plane_labels, cyl_labels, boundary):
+    def __init__(self, records, plane_labels, cyl_labels, boundary, max_batch=None, spill_records=None, spill_boundary=None):
         self.records = records
         self.plane_labels = plane_labels
         self.cyl_labels = cyl_labels
         self.boundary = boundary
+        self.max_batch = max_batch
+        self.spill_records = spill_records
+        self.spill_boundary = spill_boundary
+
+    def chain(self, f):
+        """[(record, boundary slab or None)] of frame f: its own record, then the spill records it continues in."""
+        out = [(self.records[f], None if self.boundary is None else self.boundary[f])]
+        nxt = int(self.records["header"]["next_record"][f])
+        while self.max_batch is not None and nxt >= self.max_batch:  # (a spill record's index lies beyond the batch's records)
+            k = nxt - self.max_batch
+            if self.spill_records is None or not 0 <= k < len(self.spill_records):
+                raise CapeError(f"frame {f} continues in record {nxt}, which was not copied")
+            out.append((self.spill_records[k], None if self.spill_boundary is None else self.spill_boundary[k]))
+            nxt = int(self.spill_records["header"]["next_record"][k])
+        return out
 
     def segments(self, f):
-        n = int(self.records["header"]["n_plane_segments"][f])
-        return self.records["segments"][f][:n]
+        """_planeSegments of frame f, in order (the chain's records concatenated)."""
+        parts = [rec["segments"][: min(CAPE_MAX_PLANES, max(0, int(rec["header"]["n_plane_segments"])))] for rec, _ in self.chain(f)]
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+    def cylinder_labels(self, f):
+        """cylinder2regionMap's records of frame f, in order."""
+        parts = [rec["cylinders"][: min(CAPE_MAX_CYLINDERS, max(0, int(rec["header"]["n_cylinder_labels"])))] for rec, _ in self.chain(f)]
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def planes(self, f):
         s = self.segments(f)
         return s[s["is_output"] == 1]
 
+    def plane_boundaries(self, f):
+        """the boundary points of every output plane of frame f, in plane order."""
+        out = []
+        for rec, slab in self.chain(f):
+            n = min(CAPE_MAX_PLANES, max(0, int(rec["header"]["n_plane_segments"])))
+            for seg in rec["segments"][:n]:
+                if seg["is_output"] == 1:
+                    o, c = int(seg["boundary_offset"]), int(seg["boundary_count"])
+                    out.append(slab[o:o + c])
+        return out
+
     def boundary_points(self, f, seg):
+        """points of a segment of frame f's OWN record (a segment of a spill record lives in that record's slab: plane_boundaries)."""
         o, c = int(seg["boundary_offset"]), int(seg["boundary_count"])
         return self.boundary[f, o:o + c]
 
@@ -250,10 +295,10 @@ class Extractor:
     """Thin owner of a cape_handle (mirrors the ctor pair of reference src/rgbd_slam.cpp:48-57)."""
 
     def __init__(self, width=640, height=480, fx=550.0, fy=550.0, cx=320.0, cy=240.0, cylinders=False, device=0,
-                 max_batch=64, boundary_capacity=0, sub_batches=0, async_second_pass=False):
+                 max_batch=64, boundary_capacity=0, sub_batches=0, async_second_pass=False, spill_records=0):
         self.L = load_library()
         flags = (CAPE_FLAG_CYLINDERS if cylinders else 0) | (CAPE_FLAG_ASYNC_SECOND_PASS if async_second_pass else 0)
-        cfg = cape_config(width, height, fx, fy, cx, cy, flags, device, max_batch, boundary_capacity, sub_batches)
+        cfg = cape_config(width, height, fx, fy, cx, cy, flags, device, max_batch, boundary_capacity, sub_batches, spill_records)
         self.h = C.c_void_p()
         _check(self.L, self.L.cape_create(C.byref(cfg), C.byref(self.h)), "cape_create")
         lay = cape_layout()
@@ -351,7 +396,31 @@ class Extractor:
                                                 pl.ctypes.data_as(C.c_void_p), cl.ctypes.data_as(C.c_void_p),
                                                 bd.ctypes.data_as(C.c_void_p) if with_boundary else None),
                "cape_copy_results")
-        return FrameResults(rec, pl, cl, bd)
+        srec = sbd = None
+        if (rec["header"]["next_record"] >= self.max_batch).any():  # a frame of more than 64 plane segments / cylinder labels: fetch the pool
+            used = self.spill_info()[0]
+            srec, sbd = self.spill(0, used, with_boundary)
+        return FrameResults(rec, pl, cl, bd, self.max_batch, srec, sbd)
+
+    def spill_info(self):
+        """(spill records in use, pool capacity, frames that went through the general grow instance) of the last batch."""
+        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(self.L, self.L.cape_spill_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "cape_spill_info")
+        return a.value, b.value, c.value
+
+    def spill(self, first, count, with_boundary=True):
+        rec = np.zeros(count, FRAME_RECORD_DTYPE)
+        bd = np.zeros((count, self.boundary_capacity, 3), np.float64) if with_boundary else None
+        _check(self.L, self.L.cape_copy_spill(self.h, first, count, rec.ctypes.data_as(C.c_void_p),
+                                              bd.ctypes.data_as(C.c_void_p) if with_boundary else None), "cape_copy_spill")
+        return rec, bd
+
+    def spill_polygons(self, first, count):
+        pol = np.zeros((count, CAPE_MAX_PLANES), POLYGON_DTYPE)
+        ver = np.zeros((count, self.boundary_capacity, 2), np.float64)
+        _check(self.L, self.L.cape_copy_spill_polygons(self.h, first, count, pol.ctypes.data_as(C.c_void_p), ver.ctypes.data_as(C.c_void_p)),
+               "cape_copy_spill_polygons")
+        return pol, ver
 
     # ---- N1 on the device: boundary polygons of the last batch ---------------------------------------
     def build_polygons(self, n_frames, stream=0):

@@ -29,8 +29,8 @@ def test_struct_sizes_match_header(hip_library):
 
     assert cape_amd.PLANE_SEGMENT_DTYPE.itemsize == 30 * 8 + 6 * 4
     assert cape_amd.CYLINDER_DTYPE.itemsize == 40
-    assert cape_amd.HEADER_DTYPE.itemsize == 32
-    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 32 + 64 * 264 + 64 * 40
+    assert cape_amd.HEADER_DTYPE.itemsize == 40  # ABI 2: + next_record, segment_base
+    assert cape_amd.FRAME_RECORD_DTYPE.itemsize == 40 + 64 * 264 + 64 * 40
     assert cape_amd.PACKED_HEADER_DTYPE.itemsize == 48 and cape_amd.PACKED_FRAME_DTYPE.itemsize == 24
     assert cape_amd.PACKED_PLANE_DTYPE.itemsize == 152 and cape_amd.PACKED_CYLINDER_DTYPE.itemsize == 32
     assert cape_amd.CELL_STATS_DTYPE.itemsize == 18 * 8 + 6 * 4

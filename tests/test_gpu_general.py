@@ -1,0 +1,129 @@
+"""The general grow instance (csrc/cape_grow_general.hip): any cell grid, any number of plane segments.
+
+The reference's detector takes any image size (primitive_detection.cpp:26-67) and keeps its segments in an unbounded vector
+(primitive_detection.hpp:206).  The fast kernels hold a grid row in one 64-bit mask and a frame's segments in 64 slots; whatever is
+beyond either goes through the general instance -- and must equal the oracle bit for bit like everything else.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import compare_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _intr(width):
+    from cape_amd import synth
+
+    return {k: v * width / 640.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
+
+
+def _mix(W, H, n, intr):
+    from cape_amd import synth
+
+    gens = (synth.room, synth.tunnel, synth.tumlike)
+    return np.stack([gens[k % 3](seed=3 + k % 5, frame=7 * k, width=W, height=H, intr=intr) for k in range(n)])
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+@pytest.mark.parametrize("size", [(640, 480), (1280, 960), (100, 60), (1280, 20)])
+def test_general_instance_equals_the_oracle_on_the_fast_kernels_grids(oracle_mod, monkeypatch, size, cyl):
+    """CAPE_GROW=general (read at cape_create) sends EVERY frame of a handle through the general instance: on the grids the fast kernels
+    serve -- 32 x 24, 64 x 48, a 5 x 3 toy grid, a single cell row -- it must reproduce the oracle like they do."""
+    from cape_amd import Extractor
+
+    W, H = size
+    intr = _intr(W)
+    frames = _mix(W, H, 6, intr)
+    orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
+    monkeypatch.setenv("CAPE_GROW", "general")
+    ex = Extractor(W, H, cylinders=cyl, max_batch=len(frames), **intr)
+    monkeypatch.delenv("CAPE_GROW")
+    for rep in range(2):
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        assert ex.spill_info()[2] == n, "every frame went through the general instance"
+        for f in range(n):
+            compare_frame(orc.run(frames[f]), ex, res, f, check_cells=(rep == 0))
+    ex.close()
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+@pytest.mark.parametrize("size", [(1920, 1080), (1080, 1920), (2560, 1440), (1300, 1300)])
+def test_grids_beyond_64_cells_equal_the_oracle(oracle_mod, size, cyl):
+    """1920 x 1080 (96 x 54 cells), its portrait twin (54 x 96), 2560 x 1440 (128 x 72) and 65 x 65 cells: a room / tunnel / desk mix,
+    every observable of compare_frame incl. the per-cell fits of stage A on these widths."""
+    from cape_amd import Extractor
+
+    W, H = size
+    intr = _intr(W)
+    frames = _mix(W, H, 6, intr)
+    orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
+    ex = Extractor(W, H, cylinders=cyl, max_batch=len(frames), **intr)
+    for rep in range(2):
+        n = ex.extract_host(frames)
+        res = ex.results(n)
+        for f in range(n):
+            compare_frame(orc.run(frames[f]), ex, res, f, check_cells=(rep == 0))
+    # one frame at a time on a handle of its own (results in pinned host memory, the general kernel signals the host)
+    one = Extractor(W, H, cylinders=cyl, max_batch=1, **intr)
+    for f in (1, 4):
+        n = one.extract_host(frames[f])
+        compare_frame(orc.run(frames[f]), one, one.results(n), 0, check_cells=False)
+    one.close()
+    ex.close()
+
+
+def test_one_frame_handle_follows_a_spilled_frame(oracle_mod):
+    """The reference's call pattern -- one frame per call, results in pinned host memory, the host spinning on the chain's completion
+    word: a 116-segment frame makes the 64-segment instance hand over to the general kernel, whose last wave signals instead."""
+    from cape_amd import Extractor, synth
+    from test_gpu_parity import _checkerboard_of_facets
+
+    W, H = 1280, 960
+    big, intr = _checkerboard_of_facets(W, H)
+    room = synth.room(seed=2, frame=3, width=W, height=H, intr=intr)
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    want = {id(big): orc.run(big), id(room): orc.run(room)}
+    ex = Extractor(W, H, cylinders=True, max_batch=1, **intr)
+    for fr in (room, big, room, big, big, room):
+        n = ex.extract_host(fr)
+        res = ex.results(n)
+        compare_frame(want[id(fr)], ex, res, 0, check_cells=False)
+        assert (int(res.records["header"]["next_record"][0]) >= 1) == (fr is big)
+    ex.close()
+
+
+def test_more_than_64_cylinder_labels(oracle_mod):
+    """cylinder2regionMap is as unbounded as _planeSegments: a field of thin pipes gives more cylinder labels than a record's 64 --
+    if the oracle finds that many on this scene the chain must carry them (else the test only pins equality)."""
+    from cape_amd import Extractor
+
+    W, H = 1280, 960
+    intr = _intr(W)
+    u = (np.arange(W) - intr["cx"]) / intr["fx"]
+    v = (np.arange(H) - intr["cy"]) / intr["fy"]
+    X, Y = np.meshgrid(u, v)
+    rng = np.random.default_rng(11)
+    z = np.full((H, W), 6000.0)
+    pitch, rad = 160, 70.0
+    for k, x0 in enumerate(range(pitch // 2, W, pitch)):
+        for j, y0 in enumerate(range(0, H, 240)):
+            # a vertical pipe segment: depth bulges towards the camera across its width, phase-shifted from row block to row block
+            cx = x0 + (20 if j % 2 else -20)
+            dx = (np.arange(W) - cx)
+            bulge = np.sqrt(np.clip(rad * rad - dx * dx, 0, None))
+            sl = slice(y0, min(y0 + 240, H))
+            zz = 2500.0 + 150.0 * ((k + 2 * j) % 5) - 6.0 * bulge
+            m = np.abs(dx) < rad
+            z[sl, m] = zz[m]
+    z += rng.normal(0, 0.5, z.shape)
+    frame = np.round(z).astype(np.float32)
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    want = orc.run(frame)
+    ex = Extractor(W, H, cylinders=True, max_batch=2, **intr)
+    n = ex.extract_host(np.stack([frame, frame]))
+    res = ex.results(n)
+    for f in range(n):
+        compare_frame(want, ex, res, f, check_cells=False)
+    ex.close()

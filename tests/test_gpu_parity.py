@@ -62,7 +62,8 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert np.array_equal(segs["planar"], o[:, 19].astype(np.uint32)), "segment planar"
     # cylinders (axis bitwise vs the oracle; radius NaN by the reference's quirk)
     assert hdr["n_cylinders"] == len(orc_res.cylinders), "cylinder container size"
-    kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+    kept = res.cylinder_labels(f)
+    assert len(kept) == hdr["n_cylinder_labels"]
     kept = kept[kept["kept"] == 1]
     assert len(kept) == len(orc_res.cylinders)
     if len(kept):
@@ -70,12 +71,13 @@ def compare_frame(orc_res, ex, res, f, check_cells=True):
         assert np.isnan(kept["radius"]).all()
     planes = res.planes(f)
     assert len(planes) == len(orc_res.planes) == hdr["n_planes"]
+    bounds = res.plane_boundaries(f)  # (follows the frame's spill records, if it has more than 64 segments)
     for k, pl in enumerate(planes):
         o = orc_res.planes[k]
         assert np.array_equal(_bits(pl["out_normal"]), _bits(o[0:3])), "plane normal"
         assert _bits(pl["d"]) == _bits(o[3:4])[0], "plane d"
         assert np.array_equal(_bits(pl["cov"]), _bits(o[10:19])), "point cloud covariance"
-        b_gpu = res.boundary_points(f, pl)
+        b_gpu = bounds[k]
         b_orc = orc_res.boundary[k]
         # the reference's point order is nondeterministic (parallel forEach): compare as sets
         assert sorted(map(tuple, _bits(b_gpu).tolist())) == sorted(map(tuple, _bits(b_orc).tolist())), "boundary points"
@@ -1045,23 +1047,23 @@ def _checkerboard_of_facets(W=1280, H=960, tile=100, seed=3):
 
 
 @pytest.mark.parametrize("cyl", [False, True])
-def test_more_than_64_plane_segments_is_flagged_not_silent(oracle_mod, cyl):
-    """The capacity limit the reference does not have: `_planeSegments` is an unbounded vector
-    (primitive_detection.hpp:206), a frame record holds CAPE_MAX_PLANES = 64.  A checkerboard of 116 facets (the oracle: 116 plane
-    segments) must come back FLAGGED -- CAPE_FRAME_PLANE_OVERFLOW, at most 64 segments, the capacity warning through the log callback --
-    and must not disturb the frames around it in the batch, call after call.  (What a spill instance would have to do instead is in
-    DESIGN; this test pins the behaviour that exists.)"""
-    import cape_amd
+def test_more_than_64_plane_segments_spill_into_a_record_chain(oracle_mod, cyl):
+    """`_planeSegments` is an unbounded vector in the reference (primitive_detection.hpp:206); a frame record holds CAPE_MAX_PLANES = 64.
+    A checkerboard of 116 facets (the oracle: 116 plane segments) must come back WHOLE: the 64-segment instance hands the frame to the
+    general instance (cape_grow_general.hip), which writes a chain of records -- the frame's own and one of the handle's spill pool
+    (header.next_record) -- and every observable of compare_frame equals the oracle's, for the big frames and for the frames around
+    them in the batch, call after call.  No capacity warning reaches the log callback."""
     from cape_amd import Extractor, synth
 
     W, H = 1280, 960
     big, intr = _checkerboard_of_facets(W, H)
     orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
-    assert len(orc.run(big).segments) == 116
+    want_big = orc.run(big)
+    assert len(want_big.segments) == 116
     room = synth.room(seed=1, frame=0, width=W, height=H, intr=intr)
     tunnel = synth.tunnel(seed=1, frame=0, width=W, height=H, intr=intr)
     frames = np.stack([room, big, tunnel, big])
-    want = {0: orc.run(room), 2: orc.run(tunnel)}
+    want = {0: orc.run(room), 1: want_big, 2: orc.run(tunnel), 3: want_big}
     ex = Extractor(W, H, cylinders=cyl, max_batch=len(frames), **intr)
     lines = []
     ex.set_log_callback(lambda level, msg, frame: lines.append((level, msg, frame)))
@@ -1069,13 +1071,46 @@ def test_more_than_64_plane_segments_is_flagged_not_silent(oracle_mod, cyl):
         n = ex.extract_host(frames)
         res = ex.results(n)
         hdr = res.records["header"]
-        for f in (1, 3):
-            assert int(hdr["status"][f]) & 1, "more than 64 plane segments must be flagged CAPE_FRAME_PLANE_OVERFLOW"
-            assert 0 < int(hdr["n_plane_segments"][f]) <= 64 and int(hdr["n_planes"][f]) <= 64
-            assert int(res.plane_labels[f].max()) <= 64
-        for f in (0, 2):
-            assert int(hdr["status"][f]) & 1 == 0
+        assert ex.spill_info() == (2, 8, 2), "two frames through the general instance, one spill record each"
+        for f in range(4):
+            assert int(hdr["status"][f]) & 0x7 == 0, "no capacity flag"
+            assert (int(hdr["next_record"][f]) >= len(frames)) == (f in (1, 3))
             compare_frame(want[f], ex, res, f, check_cells=False)
+        for f in (1, 3):
+            assert int(hdr["n_plane_segments"][f]) == 116 and int(res.plane_labels[f].max()) == 116
+            chain = res.chain(f)
+            assert len(chain) == 2 and int(chain[1][0]["header"]["segment_base"]) == 64
+            assert int(chain[1][0]["header"]["n_plane_segments"]) == 116 - 64 and int(chain[1][0]["header"]["next_record"]) == -1
+    assert not [ln for ln in lines if "per-frame capacity exceeded" in ln[1]]
+    ex.close()
+
+
+def test_spill_pool_exhausted_is_flagged_not_silent(oracle_mod):
+    """The pool of spill records is a memory budget (cape_config.spill_records), not an algorithmic limit: with ONE spill record and two
+    116-segment frames in the batch, one of them gets the record and equals the oracle, the other is flagged CAPE_FRAME_PLANE_OVERFLOW,
+    truncated at its own record's 64 segments, and warned about through the log callback; the frames around them are untouched."""
+    from cape_amd import Extractor, synth
+
+    W, H = 1280, 960
+    big, intr = _checkerboard_of_facets(W, H)
+    orc = oracle_mod.Oracle(W, H, cylinders=False, **intr)
+    want_big = orc.run(big)
+    room = synth.room(seed=1, frame=0, width=W, height=H, intr=intr)
+    frames = np.stack([big, room, big])
+    ex = Extractor(W, H, cylinders=False, max_batch=len(frames), spill_records=1, **intr)
+    lines = []
+    ex.set_log_callback(lambda level, msg, frame: lines.append((level, msg, frame)))
+    n = ex.extract_host(frames)
+    res = ex.results(n)
+    hdr = res.records["header"]
+    flagged = [f for f in (0, 2) if int(hdr["status"][f]) & 1]
+    whole = [f for f in (0, 2) if not int(hdr["status"][f]) & 1]
+    assert len(flagged) == 1 and len(whole) == 1
+    compare_frame(want_big, ex, res, whole[0], check_cells=False)
+    f = flagged[0]
+    assert int(hdr["n_plane_segments"][f]) == 64 and int(hdr["next_record"][f]) == -1
+    assert np.array_equal(res.plane_labels[f], want_big.plane_labels), "the label grid is the whole frame's even when the records ran out"
+    compare_frame(orc.run(room), ex, res, 1, check_cells=False)
     warned = [ln for ln in lines if "per-frame capacity exceeded" in ln[1]]
-    assert sorted(ln[2] for ln in warned) == [1, 1, 3, 3] and all(ln[0] == 1 for ln in warned)
+    assert [ln[2] for ln in warned] == [f]
     ex.close()
