@@ -186,7 +186,9 @@ enum
 enum
 {
     CAPE_PACKED_PLANES_DROPPED = 1u << 0,   /* cape_packed_header.overflow */
-    CAPE_PACKED_CYLINDERS_DROPPED = 1u << 1
+    CAPE_PACKED_CYLINDERS_DROPPED = 1u << 1,
+    CAPE_PACKED_LABELS_CLIPPED = 1u << 2    /* a frame of the shard holds more than 255 plane segments / cylinder labels: its label
+                                               grids (one byte per cell on the wire) read 255 where the label is larger */
 };
 typedef struct cape_packed_header
 {
@@ -198,7 +200,7 @@ typedef struct cape_packed_header
     int32_t planes_capacity;
     int32_t cylinders_capacity;
     uint32_t overflow;          /* CAPE_PACKED_*_DROPPED */
-    uint32_t status_or;         /* OR of the frames' CAPE_FRAME_* bits */
+    uint32_t status_or;         /* OR of the frames' CAPE_FRAME_* flag bits (bits 0..7; the count in bits 8..15 of a frame's status is not folded) */
     int32_t cells;
     int32_t frames_capacity;
     uint32_t flags;             /* CAPE_GATHER_* */
@@ -232,7 +234,7 @@ typedef struct cape_packed_cylinder
 typedef struct cape_gather_config
 {
     int32_t frames_capacity;     /* largest shard (frames per rank) this handle will pack; <= max_batch */
-    int32_t planes_per_frame;    /* budget: planes_capacity = frames_capacity x planes_per_frame; 0 = 16; CAPE_MAX_PLANES never overflows */
+    int32_t planes_per_frame;    /* budget: planes_capacity = frames_capacity x planes_per_frame; 0 = 16; <= 4096 */
     int32_t cylinders_per_frame; /* 0 = 8 */
     uint32_t flags;              /* CAPE_GATHER_LABELS */
 } cape_gather_config;

@@ -1774,6 +1774,8 @@ int pack_into_next_slot(cape_handle_s* h, int n_frames, int first_frame, hipStre
     unsigned char* base = h->packed[slot];
     cape::PackParams p{};
     p.records = h->records;
+    p.recordsBase = h->records;
+    p.poolBase = h->cfg.max_batch;
     p.planeLabelsIn = h->planeLabels;
     p.cylLabelsIn = h->cylLabels;
     p.header = reinterpret_cast<cape_packed_header*>(base);
@@ -1805,9 +1807,9 @@ int cape_gather_configure(cape_handle h, const cape_gather_config* cfg, cape_gat
     if (c.cylinders_per_frame == 0)
         c.cylinders_per_frame = 8;
     if (c.frames_capacity <= 0 || c.frames_capacity > h->cfg.max_batch || c.planes_per_frame < 0 ||
-        c.planes_per_frame > CAPE_MAX_PLANES || c.cylinders_per_frame < 0 || c.cylinders_per_frame > CAPE_MAX_CYLINDERS ||
+        c.planes_per_frame > 4096 || c.cylinders_per_frame < 0 || c.cylinders_per_frame > 4096 ||
         (c.flags & ~(uint32_t)CAPE_GATHER_LABELS))
-        return fail(CAPE_ERR_INVALID_ARGUMENT, "frames_capacity in [1, max_batch], planes/cylinders per frame in [1, 64], known flags");
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "frames_capacity in [1, max_batch], planes/cylinders per frame in [1, 4096], known flags");
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize()); // nothing may still read the old slots
     cape_gather_layout L;
@@ -2385,12 +2387,12 @@ int cape_debug_polygon_queue(cape_handle h, uint32_t* reserved, uint32_t* ticket
     CAPE_ON_DEVICE(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     cape::PolygonParams p;
-    cape::polygon_bind_scratch(p, h->polyLadder, (size_t)h->cfg.max_batch, h->boundaryCap);
+    cape::polygon_bind_scratch(p, h->polyLadder, (size_t)h->cfg.max_batch + (size_t)h->spillRecords, h->boundaryCap);
     uint32_t hd[2] = {0, 0};
     CAPE_HIP_TRY(hipMemcpy(hd, p.queue, sizeof hd, hipMemcpyDeviceToHost));
     *reserved = hd[0];
     *tickets = hd[1];
-    const size_t wanted = cape::polygon_queue_slots((size_t)h->polygonFrames);
+    const size_t wanted = cape::polygon_queue_slots((size_t)h->polygonFrames + (size_t)h->spillRecords); // (the batch + the spill pool)
     *slots = (uint32_t)(wanted < (size_t)p.queueCapacity ? wanted : (size_t)p.queueCapacity);
     return CAPE_OK;
 }

@@ -45,10 +45,12 @@ __global__ __launch_bounds__(kScanThreads) void cape_pack_scan_kernel(PackParams
     unsigned st = 0;
     for (int f = f0; f < f1; ++f)
     {
-        const cape_frame_header& h = p.records[f].header;
+        const cape_frame_header& h = p.records[f].header; // (a frame's first record holds the whole frame's counts)
         sp += h.n_planes;
         sc += h.n_cylinders;
-        st |= h.status;
+        st |= h.status & 0xFFu; // the flag bits; bits 8..15 are a per-frame COUNT (not-planar-after-merge), which an OR would garble
+        if (h.n_plane_segments > 255 || h.n_cylinder_labels > 255)
+            st |= 1u << 31; // label grids travel as bytes: folded into hd.overflow below
     }
     s_p[t] = sp;
     s_c[t] = sc;
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(kScanThreads) void cape_pack_scan_kernel(PackParams
         hd.planes_capacity = p.planesCapacity;
         hd.cylinders_capacity = p.cylindersCapacity;
         hd.overflow = (s_p[t] > p.planesCapacity ? CAPE_PACKED_PLANES_DROPPED : 0u) |
-                      (s_c[t] > p.cylindersCapacity ? CAPE_PACKED_CYLINDERS_DROPPED : 0u);
-        hd.status_or = s_status;
+                      (s_c[t] > p.cylindersCapacity ? CAPE_PACKED_CYLINDERS_DROPPED : 0u) |
+                      (((s_status >> 31) && (p.flags & CAPE_GATHER_LABELS)) ? CAPE_PACKED_LABELS_CLIPPED : 0u);
+        hd.status_or = s_status & 0xFFu;
         hd.cells = p.cells;
         hd.frames_capacity = p.framesCapacity;
         hd.flags = p.flags;
@@ -124,13 +127,19 @@ __global__ __launch_bounds__(256) void cape_pack_copy_kernel(PackParams p)
             }
         return;
     }
-    const cape_frame_record& rec = p.records[frame];
     const cape_packed_frame pf = p.frames[frame];
+    // a frame of more than 64 plane segments / cylinder labels is a chain of records (cape_frame_header::next_record, an index into
+    // the handle's record array): the planes and cylinders of every record of the chain, in order
+    int planesBefore = 0, cylsBefore = 0;
+    for (const cape_frame_record* recp = &p.records[frame]; recp; recp = recp->header.next_record >= p.poolBase ? p.recordsBase + recp->header.next_record : nullptr)
+    {
+    const cape_frame_record& rec = *recp;
     // planes: k-th kept segment (is_output) -> planes[plane_offset + k]
     {
         const bool keep = lane < rec.header.n_plane_segments && rec.segments[lane].is_output != 0;
         const unsigned long long m = __ballot(keep);
-        const int k = __popcll(m & ((1ull << lane) - 1ull));
+        const int k = planesBefore + __popcll(m & ((1ull << lane) - 1ull));
+        planesBefore += __popcll(m);
         const int dst = pf.plane_offset + k;
         if (keep && dst < p.planesCapacity)
         {
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void cape_pack_copy_kernel(PackParams p)
             for (int q = 0; q < 9; ++q)
                 o.sums[q] = s.sums[q];
             o.point_count = s.point_count;
-            o.segment = (uint32_t)lane;
+            o.segment = (uint32_t)(rec.header.segment_base + lane);
             p.planes[dst] = o;
         }
     }
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(256) void cape_pack_copy_kernel(PackParams p)
     {
         const bool keep = lane < rec.header.n_cylinder_labels && rec.cylinders[lane].kept != 0;
         const unsigned long long m = __ballot(keep);
-        const int k = __popcll(m & ((1ull << lane) - 1ull));
+        const int k = cylsBefore + __popcll(m & ((1ull << lane) - 1ull));
+        cylsBefore += __popcll(m);
         const int dst = pf.cylinder_offset + k;
         if (keep && dst < p.cylindersCapacity)
         {
@@ -165,13 +175,16 @@ __global__ __launch_bounds__(256) void cape_pack_copy_kernel(PackParams p)
             p.cylinders[dst] = o;
         }
     }
+    }
     if (p.flags & CAPE_GATHER_LABELS)
     {
-        // _gridPlaneSegmentMap / _gridCylinderSegMap (primitive_detection.hpp:212-214): labels <= 64 travel as bytes
+        // _gridPlaneSegmentMap / _gridCylinderSegMap (primitive_detection.hpp:212-214) travel as bytes; a label beyond 255 (a frame of
+        // that many segments) is clipped to 255 and the header says so (CAPE_PACKED_LABELS_CLIPPED)
         for (int i = lane; i < C; i += 64)
         {
-            p.planeLabels8[(size_t)frame * C + i] = (uint8_t)p.planeLabelsIn[(size_t)frame * C + i];
-            p.cylLabels8[(size_t)frame * C + i] = (uint8_t)p.cylLabelsIn[(size_t)frame * C + i];
+            const int32_t a = p.planeLabelsIn[(size_t)frame * C + i], b = p.cylLabelsIn[(size_t)frame * C + i];
+            p.planeLabels8[(size_t)frame * C + i] = (uint8_t)(a > 255 ? 255 : a);
+            p.cylLabels8[(size_t)frame * C + i] = (uint8_t)(b > 255 ? 255 : b);
         }
     }
 }

@@ -214,6 +214,8 @@ struct MatchPolygonParams
 struct PackParams
 {
     const cape_frame_record* records;
+    const cape_frame_record* recordsBase; // the handle's record array (what cape_frame_header::next_record indexes)
+    int poolBase;                         // first record index of the spill pool (= max_batch)
     const int32_t* planeLabelsIn;
     const int32_t* cylLabelsIn;
     cape_packed_header* header;

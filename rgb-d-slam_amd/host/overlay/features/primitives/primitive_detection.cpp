@@ -270,7 +270,62 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
     // (the frame's log lines -- invalid seed, not planar after merge, rejected boundary, capacity -- came through forward_log when
     //  the record reached the host)
     planes.reserve(r.header.n_planes);
-    const double* bnd = shard.boundary ? shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3 : nullptr;
+    // A frame is a CHAIN of records: its own, then -- beyond 64 plane segments or cylinder labels, the reference's vectors are
+    // unbounded (primitive_detection.hpp:206) -- spill records of the handle's pool (cape_frame_header::next_record), each with a
+    // boundary slab, a polygon row and a vertex slab of its own.  The spill records of a frame are fetched here, one by one: rare.
+    struct Part
+    {
+        const cape_frame_record* rec;
+        const double* bnd;           // boundary slab (null: not read back)
+        const cape_polygon* pol;     // polygon row (null: no device polygons)
+        const double* ver;           // vertex slab
+    };
+    struct SpillCopy
+    {
+        cape_frame_record rec;
+        std::vector<double> bnd, ver;
+        std::vector<cape_polygon> pol;
+    };
+    std::vector<Part> parts;
+    std::vector<std::unique_ptr<SpillCopy>> spill;
+    parts.push_back({&r, shard.boundary ? shard.boundary + static_cast<size_t>(f) * _boundaryCapacity * 3 : nullptr,
+                     shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES] : nullptr,
+                     shard.devicePolygons ? shard.vertexCopy.data() + static_cast<size_t>(f) * _boundaryCapacity * 2 : nullptr});
+    for (int next = r.header.next_record; next >= shard.maxBatch;)
+    {
+        auto sc = std::make_unique<SpillCopy>();
+        sc->bnd.resize(static_cast<size_t>(_boundaryCapacity) * 3);
+        bool ok = cape_copy_spill(shard.handle, next - shard.maxBatch, 1, &sc->rec, sc->bnd.data()) == CAPE_OK;
+        if (ok && shard.devicePolygons)
+        {
+            sc->pol.resize(CAPE_MAX_PLANES);
+            sc->ver.resize(static_cast<size_t>(_boundaryCapacity) * 2);
+            ok = cape_copy_spill_polygons(shard.handle, next - shard.maxBatch, 1, sc->pol.data(), sc->ver.data()) == CAPE_OK;
+        }
+        if (!ok)
+        {
+            outputs::log_error(std::string("find_primitives: a frame's spill record could not be read: ") + cape_last_error());
+            break;
+        }
+        parts.push_back({&sc->rec, sc->bnd.data(), shard.devicePolygons ? sc->pol.data() : nullptr, shard.devicePolygons ? sc->ver.data() : nullptr});
+        next = sc->rec.header.next_record > next ? sc->rec.header.next_record : -1; // (a chain only points forward)
+        spill.push_back(std::move(sc));
+    }
+    // the frame's plane segments in order, each with the slabs of the record that holds it
+    struct SegRef
+    {
+        const cape_plane_segment* s;
+        const cape_polygon* dp;
+        const double* bnd;
+        const double* ver;
+    };
+    std::vector<SegRef> segs;
+    for (const Part& part : parts)
+    {
+        const int n = part.rec->header.n_plane_segments < CAPE_MAX_PLANES ? part.rec->header.n_plane_segments : CAPE_MAX_PLANES;
+        for (int i = 0; i < n; ++i)
+            segs.push_back({&part.rec->segments[i], part.pol ? part.pol + i : nullptr, part.bnd, part.ver});
+    }
     // the output planes whose polygon the host class builds (one-frame calls, CAPE_POLY_OVERFLOW planes of a batch): built side
     // by side when there are several, then emplaced in segment order like the reference's loop (:577-631)
     struct HostPolygon
@@ -280,19 +335,16 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         std::string error;
     };
     std::vector<HostPolygon> hostPolygons;
-    for (int i = 0; i < r.header.n_plane_segments; ++i)
-    {
-        const cape_plane_segment& s = r.segments[i];
-        const cape_polygon* dp = shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i] : nullptr;
-        if (s.is_output && !(dp && !(dp->flags & CAPE_POLY_OVERFLOW)))
-            hostPolygons.push_back({i, nullptr, std::string()});
-    }
+    for (size_t i = 0; i < segs.size(); ++i)
+        if (segs[i].s->is_output && !(segs[i].dp && !(segs[i].dp->flags & CAPE_POLY_OVERFLOW)))
+            hostPolygons.push_back({static_cast<int>(i), nullptr, std::string()});
     auto build_host_polygon = [&](int k) {
         HostPolygon& hp = hostPolygons[static_cast<size_t>(k)];
-        const cape_plane_segment& s = r.segments[hp.segment];
+        const SegRef& ref = segs[static_cast<size_t>(hp.segment)];
+        const cape_plane_segment& s = *ref.s;
         try
         {
-            if (!bnd)
+            if (!ref.bnd)
             {
                 hp.error = "boundary points of the plane were not read back";
                 return;
@@ -300,7 +352,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
             const Plane_Segment planeSegment(s);
             std::vector<vector3> orderedBoundary;
             orderedBoundary.reserve(s.boundary_count);
-            const double* p = bnd + static_cast<size_t>(s.boundary_offset) * 3;
+            const double* p = ref.bnd + static_cast<size_t>(s.boundary_offset) * 3;
             for (uint32_t q = 0; q < s.boundary_count; ++q)
                 orderedBoundary.emplace_back(p[3 * q], p[3 * q + 1], p[3 * q + 2]);
             // :622 -- the SEGMENT's normal and centre, not the plane's re-normalised ones
@@ -332,9 +384,9 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         for (size_t k = 0; k < hostPolygons.size(); ++k)
             build_host_polygon(static_cast<int>(k));
     size_t nextHost = 0;
-    for (int i = 0; i < r.header.n_plane_segments; ++i)
+    for (const SegRef& ref : segs)
     {
-        const cape_plane_segment& s = r.segments[i];
+        const cape_plane_segment& s = *ref.s;
         if (!s.is_output) // merged away, not planar, or fewer than 3 boundary points (:577-612)
             continue;
         const Plane_Segment planeSegment(s);
@@ -343,7 +395,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
             // device polygon of this segment, if the batch built them: the ring goes through the reference's
             // Polygon(ring, xAxis, yAxis, center) constructor (polygon.cpp:236-266) -- no hull on the host.  A plane with more
             // boundary points than the device kernel takes (CAPE_POLY_OVERFLOW) was built by the host class above.
-            const cape_polygon* dp = shard.devicePolygons ? &shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i] : nullptr;
+            const cape_polygon* dp = ref.dp;
             if (dp && !(dp->flags & CAPE_POLY_OVERFLOW))
             {
                 if (!(dp->flags & CAPE_POLY_VALID) || dp->vertex_count < 3)
@@ -351,7 +403,7 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
                     outputs::log_error("Polyfit error: Geometry has invalid self-intersections or too few points");
                     continue;
                 }
-                const double* v = shard.vertexCopy.data() + (static_cast<size_t>(f) * _boundaryCapacity + dp->vertex_offset) * 2;
+                const double* v = ref.ver + static_cast<size_t>(dp->vertex_offset) * 2;
                 std::vector<vector2> ring;
                 ring.reserve(dp->vertex_count);
                 for (uint32_t k = 0; k < dp->vertex_count; ++k)
@@ -374,9 +426,13 @@ void Primitive_Detection::collect(const Shard& shard, int f, plane_container& pl
         }
     }
     cylinders.reserve(r.header.n_cylinders);
-    for (int i = 0; i < r.header.n_cylinder_labels; ++i)
-        if (r.cylinders[i].kept)
-            cylinders.emplace_back(Cylinder_Segment(r.cylinders[i]));
+    for (const Part& part : parts)
+    {
+        const int n = part.rec->header.n_cylinder_labels < CAPE_MAX_CYLINDERS ? part.rec->header.n_cylinder_labels : CAPE_MAX_CYLINDERS;
+        for (int i = 0; i < n; ++i)
+            if (part.rec->cylinders[i].kept)
+                cylinders.emplace_back(Cylinder_Segment(part.rec->cylinders[i]));
+    }
 }
 
 // one chunk (<= _maxBatch frames) through the C ABI: H2D copy + kernels + D2H of records and boundary points
@@ -407,7 +463,8 @@ bool Primitive_Detection::extract_chunk(Shard& shard, const float* depth, const 
         for (int f = 0; ok && !needPoints && f < m; ++f)
         {
             const cape_frame_record& r = shard.recordCopy[static_cast<size_t>(f)];
-            for (int i = 0; i < r.header.n_plane_segments && !needPoints; ++i)
+            const int nSeg = r.header.n_plane_segments < CAPE_MAX_PLANES ? r.header.n_plane_segments : CAPE_MAX_PLANES; // (this record's)
+            for (int i = 0; i < nSeg && !needPoints; ++i)
                 needPoints = r.segments[i].is_output && (shard.polygonCopy[static_cast<size_t>(f) * CAPE_MAX_PLANES + i].flags & CAPE_POLY_OVERFLOW);
         }
         shard.boundary = nullptr;

@@ -18,7 +18,7 @@ def pack_oracle(results, first_frame, layout, labels=False, status=None):
     st_or = 0
     for f, r in enumerate(results):
         st = int(status[f]) if status is not None else 0
-        st_or |= st
+        st_or |= st & 0xFF  # flag bits only: bits 8..15 of a frame's status are a count
         frames[f] = (po, len(r.planes), co, len(r.cylinders), st, len(r.segments))
         for k in range(len(r.planes)):
             o = r.planes[k]

@@ -14,7 +14,7 @@ def _bits(v):
     return np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
 
 
-def _check_frame(lines, tag, r):
+def _check_frame(lines, tag, r, min_area=1e3):
     """lines of one frame (prefix `tag`) against an OracleResult."""
     assert lines[0] == f"{tag}planes {len(r.planes)} cylinders {len(r.cylinders)}"
     P = [ln[len(tag):].split()[1:] for ln in lines if ln.startswith(tag + "P ")]
@@ -24,7 +24,7 @@ def _check_frame(lines, tag, r):
         # Plane::get_normal / get_d: the host re-normalises like Plane(planeSeg, polygon) does -- same bits as the oracle
         assert np.array_equal(_bits(vals), _bits(r.planes[k, 0:4]))
         # N1: the host-side boundary polygon is a valid ring spanning the candidate points (area in mm^2)
-        assert 3 <= int(p[4]) <= len(r.boundary[k]) and float(p[5]) > 1e3
+        assert 3 <= int(p[4]) <= len(r.boundary[k]) and float(p[5]) > min_area
         cov = np.array([float.fromhex(p[6]), float.fromhex(p[7])])
         assert np.array_equal(_bits(cov), _bits(r.planes[k, [10, 17]])), "get_point_cloud_covariance (0,0) and (2,1)"
     Cc = [ln[len(tag):].split()[1:] for ln in lines if ln.startswith(tag + "C ")]
@@ -125,3 +125,36 @@ def test_polygon_matcher_equals_host_selection(host_binaries, tmp_path):
     Y = [int(v) for v in [ln for ln in out.stdout.splitlines() if ln.startswith("Y ")][0].split()[1:]]
     n, host_one, host_three, matched, mismatches = Y
     assert n == len(frames) and host_one == 1 and host_three == 3 and matched >= n - 1 and mismatches == 0, Y
+
+
+@pytest.mark.parametrize("size", [(1280, 960, 100), (1920, 1080, 160)])
+def test_overlay_follows_record_chains_and_wide_grids(oracle_mod, host_binaries, tmp_path, size):
+    """Through the C++ overlay (find_primitives_batch): a frame of more than 64 plane segments -- the checkerboard of facets, a chain
+    of records on the device -- between ordinary frames, at 1280 x 960 (fast kernels + the general instance for the one frame) and at
+    1920 x 1080 (96 x 54 cells: the general instance for every frame).  Containers == oracle, device polygons == host class for every
+    plane incl. those of the spill records."""
+    from cape_amd import synth
+    from test_gpu_parity import _checkerboard_of_facets
+
+    W, H, tile = size  # (a facet must reach uint(0.0065 cells) cells to become a region: bigger tiles on the bigger grid)
+    exe = os.path.join(host_binaries, "test_shim.exe")
+    big, intr = _checkerboard_of_facets(W, H, tile=tile)
+    frames = np.stack([synth.room(seed=4, frame=1, width=W, height=H, intr=intr), big,
+                       synth.tunnel(seed=2, frame=6, width=W, height=H, intr=intr), big])
+    path = tmp_path / "batch.f32"
+    frames.tofile(path)
+    out = subprocess.run([exe, str(path), str(W), str(H), str(intr["fx"]), str(intr["fy"]), str(intr["cx"]), str(intr["cy"]),
+                          str(len(frames) - 1), "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    want = [orc.run(f) for f in frames]
+    assert len(want[1].segments) > 64
+    for k in range(len(frames)):
+        tag = f"B{k} "
+        # (a facet cut by the image border keeps a few nearly collinear candidates: a sliver of a polygon, no area to speak of)
+        _check_frame([ln for ln in lines if ln.startswith(tag)], tag, want[k], min_area=0.0)
+        dev = [ln[len(tag):] for ln in lines if ln.startswith(tag)]
+        host = [ln[len(tag):] for ln in lines if ln.startswith(f"H{k} ")]
+        assert dev == host and len(dev) > 0
+        assert f"V{k} 1" in lines

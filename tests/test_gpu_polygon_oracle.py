@@ -241,3 +241,52 @@ def test_device_polygons_1280x960_against_the_reference_algorithm(P):
     compared = stats["planes"] - stats["threw"] - len(stats["dissolve"])
     assert big >= 4, "the wide grid must show planes beyond the 256-point task kernel"
     assert compared >= 2 * n and stats["vertex_identical"] >= 0.98 * compared, stats
+
+
+def test_polygons_of_a_spilled_frame_against_the_reference_algorithm(P):
+    """A frame of 116 plane segments is a chain of two records; cape_build_polygons builds the polygons of the spill record's
+    planes with the batch's (its polygon row / vertex slab sit at the record's own index): every plane of the chain is compared
+    with the oracle of the reference's algorithm, the matcher leaves such a frame to the host class (CAPE_MATCH_EXACT_OVERFLOW)."""
+    import torch
+    from cape_amd import Extractor, synth, MATCH_EXACT_OVERFLOW
+    from test_gpu_parity import _checkerboard_of_facets
+
+    W, H = 1280, 960
+    big, intr = _checkerboard_of_facets(W, H)
+    room = synth.room(seed=1, frame=0, width=W, height=H, intr=intr)
+    frames = np.stack([room, big, big, room])
+    dev = torch.from_numpy(frames).cuda()
+    ex = Extractor(W, H, cylinders=True, max_batch=len(frames), **intr)
+    st = torch.cuda.current_stream().cuda_stream
+    n = len(frames)
+    ex.extract_device(dev.data_ptr(), n, st)
+    ex.build_polygons(n, st)
+    ex.match_polygons(n, 0, st)
+    res = ex.results(n)
+    pol, ver = ex.polygons(n)
+    used = ex.spill_info()[0]
+    assert used == 2
+    spol, sver = ex.spill_polygons(0, used)
+    stats = new_stats()
+    in_spill = 0
+    for f in range(n):
+        chain = res.chain(f)
+        assert len(chain) == (2 if f in (1, 2) else 1)
+        for part, (rec, slab) in enumerate(chain):
+            k = int(res.records["header"]["next_record"][f]) - ex.max_batch if part else None
+            prow, vslab = (pol[f], ver[f]) if part == 0 else (spol[k], sver[k])
+            for i in range(min(64, int(rec["header"]["n_plane_segments"]))):
+                s = rec["segments"][i]
+                if not s["is_output"]:
+                    continue
+                p = prow[i]
+                o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+                pts = slab[int(s["boundary_offset"]): int(s["boundary_offset"]) + int(s["boundary_count"])]
+                compare_plane(P, p, vslab[o:o + c], pts, s["normal"], _center(s), f"frame {f} record {part} segment {i}", stats)
+                in_spill += part
+    assert in_spill >= 40, "the planes of the spill records were compared too"
+    compared = stats["planes"] - stats["threw"] - len(stats["dissolve"])
+    assert stats["vertex_identical"] >= 0.98 * compared, stats
+    m = ex.polygon_matches(n)
+    assert [bool(int(m["flags"][f]) & MATCH_EXACT_OVERFLOW) for f in range(n)] == [False, True, True, True]
+    ex.close()
