@@ -427,7 +427,13 @@ def main():
                 gather = "torch"
                 gather_note = "native RCCL gather unavailable" + (f" ({err})" if err else " on another rank") + ": torch.distributed used"
                 if rank == 0:
-                    print("bench.py: " + gather_note, file=sys.stderr)
+                    print("bench.py: WARNING -- " + gather_note, file=sys.stderr)
+    # what RCCL itself reports per rank (cape_comm_info: ncclCommCount / ncclCommUserRank / ncclCommCuDevice next to the values
+    # cape_comm_init was given): the evidence that an N-GPU run had N ranks on N devices.  None when torch.distributed moved the bytes.
+    comm_infos = None
+    if gather == "native":
+        comm_infos = [None] * world
+        dist.all_gather_object(comm_infos, dict(ex.comm_info(), local_rank=dev_index))
     step_no = [0]
 
     def step():
@@ -683,6 +689,12 @@ def main():
             gather_check["path"] = gather + (" gather-to-root" if args.gather_root else " all-gather")
             if gather_note:
                 gather_check["note"] = gather_note
+            gather_check["native_rccl"] = gather == "native"
+            gather_check["torch_fallback_taken"] = bool(multi and args.gather == "native" and gather == "torch")
+            gather_check["rccl_comm"] = comm_infos if comm_infos is not None else "absent by design: the packed lists travelled through torch.distributed"
+            if comm_infos is not None:
+                gather_check["rccl_ranks_seen"] = sorted({int(c["nranks"]) for c in comm_infos})
+                gather_check["rccl_devices_seen"] = sorted({(int(c["rank"]), int(c["device"])) for c in comm_infos})
             out["gather"] = gather_check
         if world == 1 and not args.no_cpu_baseline:
             n_host = min(U, 64)

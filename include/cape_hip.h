@@ -492,6 +492,20 @@ int cape_copy_packed(cape_handle h, void* packed_host);
 int cape_comm_unique_id(void* id_out);
 int cape_comm_init(cape_handle h, const void* id, int32_t rank, int32_t world);
 int cape_comm_destroy(cape_handle h);
+/* What RCCL itself reports for the handle's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), next to what
+ * cape_comm_init was called with: a launcher prints it per rank so that a run on N GPUs can be seen to have had N ranks on N
+ * devices.  has_comm = 0 (and -1 in the RCCL fields) when the handle has no communicator -- e.g. when the caller moves the packed
+ * bytes with another transport (torch.distributed). */
+typedef struct cape_comm_info_t
+{
+    int32_t has_comm;       /* 1: cape_comm_init succeeded on this handle */
+    int32_t has_gather;     /* 1: the loaded librccl offers ncclGather (cape_gather_primitives_root) */
+    int32_t nranks, rank;   /* ncclCommCount, ncclCommUserRank (-1: not available) */
+    int32_t device;         /* ncclCommCuDevice: the HIP device RCCL bound the communicator to */
+    int32_t init_nranks, init_rank; /* world / rank passed to cape_comm_init */
+    int32_t handle_device;  /* cape_config.device */
+} cape_comm_info_t;
+int cape_comm_info(cape_handle h, cape_comm_info_t* out);
 /* One batch's exchange: cape_pack_primitives on `stream`, then ONE ncclAllGather of bytes_per_rank per rank on the
  * handle's own communication stream (behind an event, so it runs under whatever the caller enqueues next on `stream`).
  * recv_dev: world x bytes_per_rank device bytes, rank r's shard at r x bytes_per_rank; it must stay untouched until the

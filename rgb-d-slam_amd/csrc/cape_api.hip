@@ -38,6 +38,7 @@ int rccl_comm_init(void** comm, int world, const RcclUniqueId& id, int rank);
 int rccl_comm_destroy(void* comm);
 int rccl_all_gather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t stream);
 const char* rccl_error_string(int code);
+void rccl_comm_query(void* comm, int* count, int* rank, int* device);
 bool rccl_has_gather();
 int rccl_gather_bytes(const void* send, void* recv, size_t bytes, int root, void* comm, hipStream_t stream);
 hipError_t launch_count_primitives(const cape_frame_record* records, int nFrames, int32_t* out, hipStream_t stream);
@@ -1906,6 +1907,28 @@ int cape_comm_init(cape_handle h, const void* id_, int32_t rank, int32_t world)
     }
     h->commRank = rank;
     h->commWorld = world;
+    return CAPE_OK;
+}
+
+int cape_comm_info(cape_handle h, cape_comm_info_t* out)
+{
+    if (!h || !out)
+        return fail(CAPE_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->nranks = out->rank = out->device = -1;
+    out->handle_device = h->cfg.device;
+    if (!h->comm)
+        return CAPE_OK; // no communicator: has_comm = 0
+    out->has_comm = 1;
+    out->has_gather = cape::rccl_has_gather() ? 1 : 0;
+    CAPE_ON_DEVICE(h);
+    int count = -1, rank = -1, device = -1;
+    cape::rccl_comm_query(h->comm, &count, &rank, &device);
+    out->nranks = count;
+    out->rank = rank;
+    out->device = device;
+    out->init_nranks = h->commWorld;
+    out->init_rank = h->commRank;
     return CAPE_OK;
 }
 

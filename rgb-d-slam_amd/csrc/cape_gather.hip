@@ -265,6 +265,9 @@ struct RcclApi
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*Gather)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr; // RCCL extension; optional
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;    // what the communicator itself reports (cape_comm_info); optional
+    int (*CommUserRank)(void*, int*) = nullptr;
+    int (*CommCuDevice)(void*, int*) = nullptr;
     std::string error;
 };
 RcclApi g_rccl;
@@ -305,6 +308,9 @@ const char* rccl_load()
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
     g_rccl.Gather = reinterpret_cast<decltype(g_rccl.Gather)>(sym("ncclGather"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(sym("ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(sym("ncclCommUserRank"));
+    g_rccl.CommCuDevice = reinterpret_cast<decltype(g_rccl.CommCuDevice)>(sym("ncclCommCuDevice"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
     {
         g_rccl.error = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather";
@@ -325,6 +331,17 @@ bool rccl_has_gather() { return g_rccl.Gather != nullptr; }
 int rccl_gather_bytes(const void* send, void* recv, size_t bytes, int root, void* comm, hipStream_t stream)
 {
     return g_rccl.Gather(send, recv, bytes, /* ncclChar */ 0, root, comm, stream);
+}
+// what RCCL says about a communicator: -1 where the loaded library lacks the query
+void rccl_comm_query(void* comm, int* count, int* rank, int* device)
+{
+    *count = *rank = *device = -1;
+    if (g_rccl.CommCount && g_rccl.CommCount(comm, count) != 0)
+        *count = -1;
+    if (g_rccl.CommUserRank && g_rccl.CommUserRank(comm, rank) != 0)
+        *rank = -1;
+    if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(comm, device) != 0)
+        *device = -1;
 }
 const char* rccl_error_string(int code) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "rccl not loaded"; }
 

@@ -83,6 +83,7 @@ PACKED_MAGIC = 0x43415045
 GATHER_LABELS = 1
 PACKED_PLANES_DROPPED = 1
 PACKED_CYLINDERS_DROPPED = 2
+PACKED_LABELS_CLIPPED = 4
 COMM_ID_BYTES = 128
 PACKED_HEADER_DTYPE = np.dtype([
     ("magic", "<u4"), ("n_frames", "<i4"), ("first_frame", "<i4"), ("n_planes_total", "<i4"),
@@ -97,6 +98,10 @@ PACKED_PLANE_DTYPE = np.dtype([
 PACKED_CYLINDER_DTYPE = np.dtype([("axis", "<f8", 3), ("radius", "<f8")], align=True)
 assert (PACKED_HEADER_DTYPE.itemsize, PACKED_FRAME_DTYPE.itemsize, PACKED_PLANE_DTYPE.itemsize,
         PACKED_CYLINDER_DTYPE.itemsize) == (48, 24, 152, 32)
+
+
+class cape_comm_info_t(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("has_comm", "has_gather", "nranks", "rank", "device", "init_nranks", "init_rank", "handle_device")]
 
 
 class cape_gather_config(C.Structure):
@@ -146,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "cape_build_polygons", "cape_device_polygons", "cape_copy_polygons", "cape_debug_polygon",
     "cape_last_error", "cape_version", "cape_debug_eval", "cape_debug_cycles", "cape_debug_rectify_flagged", "cape_copy_seed_sequence",
     "cape_debug_polygon_queue", "cape_set_log_callback", "cape_log_records", "cape_debug_match_lists", "cape_set_rng_seed",
-    "cape_abi_version", "cape_spill_info", "cape_copy_spill", "cape_copy_spill_polygons", "cape_get_timings_sized",
+    "cape_comm_info", "cape_abi_version", "cape_spill_info", "cape_copy_spill", "cape_copy_spill_polygons", "cape_get_timings_sized",
 ]
 DEBUG_OPS = dict(sqrt=0, div=1, acos=2, atan2=3, quant=4, sqrtf=5, eigen3=6, fit_plane=7)
 
@@ -200,6 +205,7 @@ def load_library():
     L.cape_comm_unique_id.argtypes = [vp]
     L.cape_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
     L.cape_comm_destroy.argtypes = [vp]
+    L.cape_comm_info.argtypes = [vp, C.POINTER(cape_comm_info_t)]
     L.cape_gather_primitives.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
     L.cape_gather_wait.argtypes = [vp, vp, C.c_int32]
     L.cape_gather_primitives_root.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
@@ -552,6 +558,12 @@ class Extractor:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
         _check(self.L, self.L.cape_comm_init(self.h, buf, rank, world), "cape_comm_init")
+
+    def comm_info(self):
+        """what RCCL reports for the handle's communicator (cape_comm_info): dict; has_comm = 0 without one."""
+        info = cape_comm_info_t()
+        _check(self.L, self.L.cape_comm_info(self.h, C.byref(info)), "cape_comm_info")
+        return {n: int(getattr(info, n)) for n, _ in cape_comm_info_t._fields_}
 
     def comm_destroy(self):
         _check(self.L, self.L.cape_comm_destroy(self.h), "cape_comm_destroy")

@@ -16,6 +16,7 @@ def pack_oracle(results, first_frame, layout, labels=False, status=None):
     cyls = buf[layout["cylinders_offset"]: layout["cylinders_offset"] + Cy * PACKED_CYLINDER_DTYPE.itemsize].view(PACKED_CYLINDER_DTYPE)
     po = co = 0
     st_or = 0
+    clipped = False
     for f, r in enumerate(results):
         st = int(status[f]) if status is not None else 0
         st_or |= st & 0xFF  # flag bits only: bits 8..15 of a frame's status are a count
@@ -41,9 +42,11 @@ def pack_oracle(results, first_frame, layout, labels=False, status=None):
         co += len(r.cylinders)
         if labels:
             o1, o2 = layout["plane_labels_offset"], layout["cyl_labels_offset"]
-            buf[o1 + f * cells: o1 + (f + 1) * cells] = r.plane_labels.astype(np.uint8)
-            buf[o2 + f * cells: o2 + (f + 1) * cells] = r.cyl_labels.astype(np.uint8)
+            # one byte per cell on the wire: a label beyond 255 reads 255 (CAPE_PACKED_LABELS_CLIPPED in the header)
+            buf[o1 + f * cells: o1 + (f + 1) * cells] = np.minimum(r.plane_labels, 255).astype(np.uint8)
+            buf[o2 + f * cells: o2 + (f + 1) * cells] = np.minimum(r.cyl_labels, 255).astype(np.uint8)
+            clipped = clipped or len(r.segments) > 255 or int(r.cyl_labels.max(initial=0)) > 255
     hdr[0] = (PACKED_MAGIC, len(results), first_frame, po, co, P, Cy,
-              (PACKED_PLANES_DROPPED if po > P else 0) | (PACKED_CYLINDERS_DROPPED if co > Cy else 0), st_or, cells, F,
+              (PACKED_PLANES_DROPPED if po > P else 0) | (PACKED_CYLINDERS_DROPPED if co > Cy else 0) | (4 if clipped else 0), st_or, cells, F,
               GATHER_LABELS if labels else 0)
     return buf

@@ -32,6 +32,9 @@ def test_self_spawned_launcher_with_gather():
     g = out["gather"]
     assert g["ok"] and g["overflow"] == 0 and g["frames"] == 256
     assert g["path"].startswith("native")
+    # first-contact evidence for an N-GPU run: what RCCL itself reports for every rank's communicator (cape_comm_info)
+    assert g["native_rccl"] and not g["torch_fallback_taken"]
+    assert g["rccl_ranks_seen"] == [1] and g["rccl_devices_seen"] == [[0, 0]] and g["rccl_comm"][0]["has_comm"] == 1, g
     assert g["payload_bytes_per_frame"] <= 1229, g  # <= 1.2 KB per frame on the TUM-like stream
     assert "exposed_ms_per_step" in g
     pc = out["parity_check"]
@@ -72,6 +75,7 @@ def test_two_ranks_share_the_gpu_through_gloo(scaling):
     assert out["ranks"]["ms_per_step_max"] >= out["ranks"]["ms_per_step_min"] > 0
     g = out["gather"]
     assert g["ok"] and g["frames"] == total and g["overflow"] == 0 and g["path"].startswith("torch")
+    assert not g["native_rccl"] and isinstance(g["rccl_comm"], str) and "absent by design" in g["rccl_comm"]
     assert "exposed_ms_per_step" in g and g["planes"] > 0
     pc = out["parity_check"]
     assert pc["ranks_checked"] == 2 and pc["all_ranks_ok"] and pc["labels_equal"] and pc["segments_bitwise"]

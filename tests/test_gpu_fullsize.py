@@ -124,7 +124,7 @@ def test_configs4_1280x960_tunnel_1024_cylinders_match(oracle_mod):
         assert np.array_equal(g["inter"][: len(ap), : len(ac)], inter)
 
 
-def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
+def _every_frame(oracle_mod, scene, cyl, n, chunk=256, W=640, H=480, dev=None, after_extract=None):
     """ALL n frames of a batch against the oracle (the full-size batches were checked by sampling): label grids,
     counts, the seed-loop length, the log-line bits of the status word, every plane segment record and every output plane bit for
     bit, cylinder axes.  The oracle runs on a pool of threads (one Oracle object each; ctypes releases the GIL in the C call)."""
@@ -135,11 +135,13 @@ def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
     import torch
     from cape_amd import Extractor, synth_gpu
 
-    intr = _intr(scene)
-    dev = synth_gpu.stream(scene, 100, n, start=0, device="cuda", chunk=64)
-    ex = Extractor(640, 480, cylinders=cyl, max_batch=n, **intr)
+    intr = _intr(scene, W / 640.0)
+    if dev is None:
+        dev = synth_gpu.stream(scene, 100, n, start=0, device="cuda", chunk=64)
+    ex = Extractor(W, H, cylinders=cyl, max_batch=n, **intr)
     ex.extract_device(dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
-    res = ex.results(n, with_boundary=False)
+    extra = after_extract(ex, n) if after_extract else None  # (polygons / matches of the same batch, checked by the caller)
+    res = ex.results(n, with_boundary=after_extract is not None)
     local = threading.local()
 
     def bits(a):
@@ -148,7 +150,7 @@ def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
     def check(args):
         f, depth = args
         if not hasattr(local, "orc"):
-            local.orc = oracle_mod.Oracle(640, 480, cylinders=cyl, **intr)
+            local.orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
         r = local.orc.run(depth)
         hdr = res.records["header"][f]
         ok = (np.array_equal(res.plane_labels[f], r.plane_labels) and np.array_equal(res.cyl_labels[f], r.cyl_labels)
@@ -166,7 +168,7 @@ def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
         if ok and len(planes):
             ok = (np.array_equal(bits(planes["out_normal"]), bits(r.planes[:, 0:3])) and np.array_equal(bits(planes["d"]), bits(r.planes[:, 3]))
                   and np.array_equal(bits(planes["cov"]).reshape(len(planes), 9), bits(r.planes[:, 10:19])))
-        kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+        kept = res.cylinder_labels(f)
         kept = kept[kept["kept"] == 1]
         if ok and len(kept):
             ok = np.array_equal(bits(kept["axis"]), bits(r.cylinders[:, 0:3])) and bool(np.isnan(kept["radius"]).all())
@@ -181,9 +183,10 @@ def _every_frame(oracle_mod, scene, cyl, n, chunk=256):
                 n_cyl += ncy
                 if f >= 0:
                     bad.append(f)
-    ex.close()
+    if after_extract is None:
+        ex.close()
     assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
-    return n_planes, n_cyl
+    return (n_planes, n_cyl) if after_extract is None else (n_planes, n_cyl, ex, res, extra)
 
 
 def test_configs1_every_frame_of_the_4096_batch(oracle_mod):
@@ -200,3 +203,87 @@ def test_reference_faithful_mode_every_frame(oracle_mod, scene, n):
     assert n_planes + n_cyl > n // 2
     if scene != "tumlike":
         assert n_cyl > 50
+
+
+def test_configs4_1280x960_every_frame_of_a_room_tunnel_mix(oracle_mod):
+    """BASELINE.json configs[4], one-GPU leg, at the standard of the 640 x 480 batches: 1 024 frames of 1280 x 960,
+    a room / tunnel MIX (blocks of 64 consecutive frames of either trajectory), planes + cylinders + polygons + polygon
+    matches -- EVERY frame against the extraction oracle, every output plane's polygon and every frame pair's match decisions against
+    the oracle of the reference's polygon algorithm."""
+    import concurrent.futures as cf
+    import os
+
+    import torch
+    import cape_amd
+    import polygon_oracle_py as P
+    from cape_amd import synth_gpu
+    from test_gpu_polygon_oracle import AREA_RTOL, _center, compare_plane, new_stats
+
+    P.build()
+    n, W, H, blk = 1024, 1280, 960, 64
+    room = synth_gpu.stream("room", 100, n // 2, width=W, height=H, start=0, device="cuda", chunk=16)
+    tun = synth_gpu.stream("tunnel", 100, n // 2, width=W, height=H, start=0, device="cuda", chunk=16)
+    dev = torch.empty((n, H, W), dtype=room.dtype, device="cuda")
+    for b in range(n // blk):
+        src = room if b % 2 == 0 else tun
+        dev[b * blk:(b + 1) * blk] = src[(b // 2) * blk:(b // 2 + 1) * blk]
+    del room, tun
+
+    def after(ex, m):
+        st = torch.cuda.current_stream().cuda_stream
+        ex.build_polygons(m, st)
+        ex.match_polygons(m, 0, st)
+        return ex.polygons(m) + (ex.polygon_matches(m),)
+
+    n_planes, n_cyl, ex, res, (pol, ver, got) = _every_frame(oracle_mod, "room", True, n, chunk=128, W=W, H=H, dev=dev, after_extract=after)
+    assert n_planes > n and n_cyl > 32, (n_planes, n_cyl)
+    _properties_all_frames(res, n, ex.cells)
+    out = res.records["segments"]["is_output"][:n] == 1
+    assert not (pol["flags"][out] & cape_amd.POLY_OVERFLOW).any() and not (got["flags"] & cape_amd.MATCH_EXACT_OVERFLOW).any()
+
+    # ---- every output plane's polygon against the oracle of the reference's algorithm (threads: ctypes releases the GIL)
+    def planes_of(f):
+        st = new_stats()
+        keep = []
+        for i, s in enumerate(res.segments(f)):
+            if not s["is_output"]:
+                continue
+            p = pol[f, i]
+            o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+            ref = compare_plane(P, p, ver[f, o:o + c], res.boundary_points(f, s), s["normal"], _center(s), f"frame {f} segment {i}", st)
+            if ref is None:
+                keep = None  # a dissolved / degenerate / rejected hull: the frame's kept-plane list is not compared
+            elif keep is not None and ref.valid and ref.boundary_length() >= 3:
+                keep.append((i, np.asarray(s["out_normal"], np.float64), float(s["d"]), ref))
+        return st, keep
+
+    stats, kept = new_stats(), []
+    with cf.ThreadPoolExecutor(max(2, min(16, os.cpu_count() or 2))) as pool:
+        for st, keep in pool.map(planes_of, range(n)):
+            kept.append(keep)
+            for k in ("planes", "threw", "vertex_identical", "left_out_by_reference_rule"):
+                stats[k] += st[k]
+            stats["dissolve"] += st["dissolve"]
+            stats["degenerate"] = stats.get("degenerate", 0) + st.get("degenerate", 0)
+    compared = stats["planes"] - stats["threw"] - len(stats["dissolve"]) - stats.get("degenerate", 0)
+    assert compared > n and len(stats["dissolve"]) <= 0.08 * stats["planes"], stats
+    assert stats["vertex_identical"] >= 0.98 * compared, stats
+    # ---- every frame pair's match decisions against MapPlane::find_matches run by the oracle on its own polygons
+    pairs = decided = 0
+    for f in range(1, n):
+        if kept[f] is None or kept[f - 1] is None:
+            continue
+        prev, cur = kept[f - 1], kept[f]
+        assert [q[0] for q in prev] == list(got[f]["seg_prev"][: len(prev)]) and [q[0] for q in cur] == list(got[f]["seg_cur"][: len(cur)]), f
+        want, inter = P.find_matches([q[1:] for q in prev], [q[1:] for q in cur], None, advanced=False, allow_index0=False)
+        assert list(got[f]["match"][: len(prev)]) == want, f"frame {f}: {list(got[f]['match'][:len(prev)])} vs {want}"
+        decided += sum(1 for m in want if m >= 0)
+        for j in range(len(prev)):
+            for i in range(len(cur)):
+                a, b = float(got[f]["inter_area"][j][i]), float(inter[j, i])
+                if b < 0:
+                    continue
+                assert a >= 0 and abs(a - b) <= AREA_RTOL * max(b, float(cur[i][3].area)) + 1e-6, f"frame {f} pair ({j},{i}): {a} vs {b}"
+                pairs += 1
+    assert pairs > n // 2 and decided > n // 8, (pairs, decided)
+    ex.close()

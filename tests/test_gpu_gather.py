@@ -91,7 +91,11 @@ def test_native_rccl_gather(oracle_mod):
     ex, lay, intr = _setup(n, labels=True)
     uid = ex.comm_unique_id()
     assert len(uid) == 128
+    assert ex.comm_info()["has_comm"] == 0 and ex.comm_info()["nranks"] == -1
     ex.comm_init(uid, 0, 1)
+    info = ex.comm_info()  # what RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)
+    assert info["has_comm"] == 1 and (info["nranks"], info["rank"], info["device"]) == (1, 0, 0), info
+    assert (info["init_nranks"], info["init_rank"], info["handle_device"]) == (1, 0, 0)
     recv = torch.zeros(lay["bytes_per_rank"], dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     for rep in range(3):  # both staging slots get reused
@@ -214,3 +218,89 @@ def test_two_process_sharded_gather_on_one_gpu(oracle_mod):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_packed_lists_of_a_frame_of_116_segments(oracle_mod):
+    """A frame that continues in a spill record (more than 64 plane segments) is packed WHOLE: the pack kernel follows
+    cape_frame_header.next_record, the planes of the second record land behind those of the first with their frame-wide segment
+    index -- byte for byte what the oracle's lists give."""
+    from cape_amd import Extractor, synth
+    from cape_amd.dist import Shard
+    from packing import pack_oracle
+    from test_gpu_parity import _checkerboard_of_facets
+
+    W, H = 1280, 960
+    big, intr = _checkerboard_of_facets(W, H)
+    frames = np.stack([synth.room(seed=1, frame=0, width=W, height=H, intr=intr), big,
+                       synth.tunnel(seed=1, frame=0, width=W, height=H, intr=intr), big])
+    n = len(frames)
+    ex = Extractor(W, H, cylinders=True, max_batch=n, **intr)
+    lay = ex.gather_configure(n, 80, 8, labels=True)
+    ex.extract_host(frames)
+    ex.pack(n, first_frame=8)
+    got = ex.packed_host()
+    res = ex.results(n, with_boundary=False)
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    refs = [orc.run(f) for f in frames]
+    assert len(refs[1].planes) > 64
+    want = pack_oracle(refs, 8, lay, labels=True, status=res.records["header"]["status"])
+    sh = Shard(got, lay)
+    assert int(sh.header["overflow"]) == 0 and int(sh.header["n_planes_total"]) == sum(len(r.planes) for r in refs)
+    assert np.array_equal(got, want), "packed bytes differ from the oracle-built payload"
+    ex.close()
+
+
+def test_configs3_gather_leg_every_frame_with_labels(oracle_mod):
+    """BASELINE.json configs[3], the one-GPU leg of the sharded TUM-like stream at its full shard size (2 048 frames), label grids
+    on: what the native RCCL gather delivers -- plane lists, cylinder lists, both label grids of EVERY frame -- against the oracle
+    (threaded), not a sample."""
+    import concurrent.futures as cf
+    import threading
+
+    import torch
+    from cape_amd import Extractor, synth, synth_gpu
+    from cape_amd.dist import unpack_gathered
+
+    n = 2048
+    intr = dict(synth.TUM_FR1_INTRINSICS)
+    dev = synth_gpu.stream("tumlike", 2, n, start=0, device="cuda", chunk=64)
+    ex = Extractor(640, 480, cylinders=True, max_batch=n, **intr)
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_device(dev.data_ptr(), n, st)
+    n_pl, n_cy, most = ex.count_primitives(n)
+    lay = ex.gather_configure(n, planes_per_frame=int(np.ceil(1.15 * n_pl / n)) + 1, cylinders_per_frame=int(np.ceil(1.15 * n_cy / n)) + 1,
+                              labels=True)
+    ex.comm_init(ex.comm_unique_id(), 0, 1)
+    recv = torch.zeros(lay["bytes_per_rank"], dtype=torch.uint8, device="cuda")
+    ex.gather(n, 0, recv.data_ptr(), st)
+    ex.gather_wait(host_sync=True)
+    sh = unpack_gathered(recv.cpu().numpy(), 1, lay)[0]
+    assert int(sh.header["overflow"]) == 0 and int(sh.header["n_frames"]) == n and int(sh.header["n_planes_total"]) == n_pl
+    local = threading.local()
+
+    def bits(a):
+        return np.ascontiguousarray(a).view(np.uint64)
+
+    def check(args):
+        f, depth = args
+        if not hasattr(local, "orc"):
+            local.orc = oracle_mod.Oracle(640, 480, cylinders=True, **intr)
+        r = local.orc.run(depth)
+        planes, cyls = sh.frame_planes(f), sh.frame_cylinders(f)
+        ok = (len(planes) == len(r.planes) and len(cyls) == len(r.cylinders) and int(sh.frames[f]["n_plane_segments"]) == len(r.segments)
+              and np.array_equal(sh.plane_labels[f], r.plane_labels.astype(np.uint8)) and np.array_equal(sh.cyl_labels[f], r.cyl_labels.astype(np.uint8)))
+        if ok and len(planes):
+            ok = (np.array_equal(bits(planes["normal"]), bits(r.planes[:, 0:3])) and np.array_equal(bits(planes["d"]), bits(r.planes[:, 3]))
+                  and np.array_equal(planes["segment"], r.planes[:, 19].astype(np.uint32)))
+        if ok and len(cyls):
+            ok = np.array_equal(bits(cyls["axis"]), bits(r.cylinders[:, 0:3]))
+        return -1 if ok else f
+
+    bad = []
+    with cf.ThreadPoolExecutor(max(2, min(16, os.cpu_count() or 2))) as pool:
+        for c0 in range(0, n, 256):
+            host = dev[c0:c0 + 256].cpu().numpy()
+            bad += [f for f in pool.map(check, [(c0 + k, host[k]) for k in range(len(host))]) if f >= 0]
+    assert not bad, f"{len(bad)} of {n} gathered frames differ from the oracle, first: {bad[:8]}"
+    ex.comm_destroy()
+    ex.close()
