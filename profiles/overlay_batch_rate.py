@@ -10,7 +10,7 @@ intr=synth.TUM_FR1_INTRINSICS
 frames=np.stack([synth.tumlike(seed=7,frame=f) for f in range(16)])
 frames.tofile("/tmp/f.f32")
 exe="/root/repo/rgb-d-slam_amd/lib/latency_bench.exe"
-for B,Cn in ((1024,64),(1024,128),(1024,256)):
+for B,Cn in [(int(a.split(":")[0]),int(a.split(":")[1])) for a in sys.argv[1:]] or ((1024,64),(1024,128),(1024,256)):
     env=dict(os.environ,CAPE_BENCH_BATCH=str(B),CAPE_BENCH_CHUNK=str(Cn))
     out=subprocess.run([exe,"/tmp/f.f32","16","640","480",str(intr["fx"]),str(intr["fy"]),str(intr["cx"]),str(intr["cy"]),"1"],capture_output=True,text=True,env=env)
-    print("chunk",Cn); print("\n".join(l for l in out.stdout.splitlines() if l.startswith("overlay batch")))
+    print("batch",B,"chunk",Cn); print("\n".join(l for l in out.stdout.splitlines() if l.startswith("overlay batch")))

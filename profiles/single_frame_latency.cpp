@@ -135,16 +135,16 @@ int main(int argc, char** argv)
         }
         std::vector<rgbd_slam::features::primitives::plane_container> bp;
         std::vector<rgbd_slam::features::primitives::cylinder_container> bc;
-        for (int mode = 0; mode < 7; ++mode)
+        for (int mode = 0; mode < 9; ++mode)
         {
             // (more shards than devices: the handles' copies, kernels and host work overlap on the one device)
-            det.set_shard_count(mode == 3 ? 2 : mode == 4 ? 4 : mode >= 5 ? 0 : 1);
+            det.set_shard_count(mode == 3 || mode == 7 ? 2 : mode == 4 || mode == 8 ? 4 : mode == 5 || mode == 6 ? 0 : 1);
             det.set_device_polygons(mode != 1);
             double best = 1e30;
             for (int r = 0; r < 6; ++r)
             {
                 const auto t0 = clk::now();
-                if (mode >= 2 && mode != 6)
+                if (mode >= 2 && mode < 6)
                     det.find_primitives_batch(raw.data(), 0.2f, B, bp, bc);
                 else
                     det.find_primitives_batch(batch.data(), B, bp, bc);
@@ -156,7 +156,7 @@ int main(int argc, char** argv)
             for (const auto& c : bp)
                 np += c.size();
             std::printf("overlay batch of %d  %-44s %8.1f us per frame (%.0f frames/s, %zu planes per batch)\n", B,
-                        mode == 0 ? "float32 frames, polygons on the device" : mode == 1 ? "float32 frames, polygons by the host class" : mode == 2 ? "raw uint16 frames, polygons on the device" : mode == 3 ? "raw uint16 frames, two shards on the device" : mode == 4 ? "raw uint16 frames, four shards on the device" : mode == 5 ? "raw uint16 frames, default shards" : "float32 frames, default shards",
+                        mode == 0 ? "float32 frames, polygons on the device" : mode == 1 ? "float32 frames, polygons by the host class" : mode == 2 ? "raw uint16 frames, polygons on the device" : mode == 3 ? "raw uint16 frames, two shards on the device" : mode == 4 ? "raw uint16 frames, four shards on the device" : mode == 5 ? "raw uint16 frames, default shards" : mode == 6 ? "float32 frames, default shards" : mode == 7 ? "float32 frames, two shards on the device" : "float32 frames, four shards on the device",
                         best / B, 1e6 * B / best, np);
         }
     }

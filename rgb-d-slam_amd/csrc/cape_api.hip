@@ -1430,7 +1430,12 @@ int cape_copy_results(cape_handle h, int32_t n_frames, cape_frame_record* record
             std::memcpy(boundary, h->boundary, n * (size_t)h->boundaryCap * 3 * sizeof(double));
         return CAPE_OK;
     }
-    CAPE_HIP_TRY(hipDeviceSynchronize());
+    // behind THIS handle's work only (its event, its side stream): several handles driven from several host threads -- the overlay's
+    // shards -- must not wait for each other's kernels here (through round 5 this was a hipDeviceSynchronize)
+    if (h->workRecorded || h->sidePending)
+        CAPE_HIP_TRY(drain_handle(h));
+    else
+        CAPE_HIP_TRY(hipDeviceSynchronize());
     if (records)
         CAPE_HIP_TRY(hipMemcpy(records, h->records, n * sizeof(cape_frame_record), hipMemcpyDeviceToHost));
     log_batch(h, records, n_frames);
@@ -1717,7 +1722,10 @@ int cape_copy_matches(cape_handle h, int32_t n_frames, cape_frame_match* out)
     if (!h->matches)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "cape_match_consecutive has not run");
     CAPE_ON_DEVICE(h);
-    CAPE_HIP_TRY(hipDeviceSynchronize());
+    if (h->workRecorded || h->sidePending)
+        CAPE_HIP_TRY(drain_handle(h));
+    else
+        CAPE_HIP_TRY(hipDeviceSynchronize());
     CAPE_HIP_TRY(hipMemcpy(out, h->matches, (size_t)n_frames * sizeof(cape_frame_match), hipMemcpyDeviceToHost));
     return CAPE_OK;
 }

@@ -612,9 +612,32 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
     L.sidx = reinterpret_cast<unsigned char*>(L.inc + 128 * T::kStack);
     const unsigned* list = p.pairLists + (size_t)TIER * p.pairCapacity;
     const unsigned count = p.listCounts[TIER];
-    for (unsigned t = blockIdx.x * T::kWavesPerGroup + wave; t < count; t += gridDim.x * T::kWavesPerGroup)
+    // The tiers behind the first hold few pairs of very unequal cost (an outline of 70 vertices over 145 slabs keeps a lone wave busy
+    // for 0.1 ms, its neighbours on the list for a tenth of that): their waves take pairs off a TICKET counter (listCounts[4 + TIER],
+    // cleared with the counts) instead of a fixed stride, so a wave that drew a long pair does not also sit on the pairs queued
+    // behind it.  CAPE_MP_TICKETS: bit TIER set = that tier draws tickets (A/B builds; default: tiers 1..3).
+#ifndef CAPE_MP_TICKETS
+#define CAPE_MP_TICKETS 0xE
+#endif
+#ifndef CAPE_MP_REVERSE
+#define CAPE_MP_REVERSE 0
+#endif
+    constexpr bool kTickets = ((CAPE_MP_TICKETS >> TIER) & 1) != 0;
+    constexpr bool kReverse = ((CAPE_MP_REVERSE >> TIER) & 1) != 0;
+    auto next_index = [&](unsigned prev, bool first) -> unsigned {
+        if (!kTickets)
+            return first ? blockIdx.x * T::kWavesPerGroup + wave : prev + gridDim.x * T::kWavesPerGroup;
+        unsigned t = 0;
+        if (lane == 0)
+            t = atomicAdd(&p.listCounts[4 + TIER], 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    for (unsigned t = next_index(0u, true); t < count; t = next_index(t, false))
     {
-        const unsigned pair = list[t];
+        // (tier 0's list is the gate kernel's, front only; the later tiers': front entries, then the back entries)
+        const unsigned front = TIER == 0 ? count : p.listCounts[24 + TIER];
+        const unsigned u = kReverse ? count - 1u - t : t;
+        const unsigned pair = u < front ? list[u] : list[p.pairCapacity - 1u - (u - front)];
         const int frame = (int)(pair >> 8), j = (int)((pair >> 4) & 15u), i = (int)(pair & 15u);
         cape_frame_match_exact& out = p.matches[frame];
         const int si = out.seg_cur[i], sj = out.seg_prev[j];
@@ -724,7 +747,18 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                         (is_nan_code(result, kNanRing) && later_ring<TIER>() > T::kRing);
             if (again)
             {
-                p.pairLists[(size_t)(TIER + 1) * p.pairCapacity + atomicAdd(&p.listCounts[TIER + 1], 1u)] = pair;
+                // the next tier's list fills from both ends: pairs that left for their ring's size -- the big outlines, the long pairs --
+                // at the front (their number in listCounts[24 + tier]), the others from the back; the tier works front first, so its
+                // longest pairs start first.  A/B (profiles/r06_match_tickets.txt): no gain over arrival order once the waves draw tickets -- the tier ends with its longest PAIR, wherever that starts; kept as a build knob, off (0: one list in arrival order)
+#ifndef CAPE_MP_HEAVY_FIRST
+#define CAPE_MP_HEAVY_FIRST 0
+#endif
+                atomicAdd(&p.listCounts[TIER + 1], 1u);
+                unsigned* nextList = p.pairLists + (size_t)(TIER + 1) * p.pairCapacity;
+                if (CAPE_MP_HEAVY_FIRST == 0 || is_nan_code(result, kNanRing))
+                    nextList[atomicAdd(&p.listCounts[24 + TIER + 1], 1u)] = pair;
+                else
+                    nextList[p.pairCapacity - 1u - atomicAdd(&p.listCounts[28 + TIER + 1], 1u)] = pair;
                 // why the pair moves on (cape_debug_match_lists: words 8 + 4 * tier + reason; a handful of atomics per batch)
                 atomicAdd(&p.listCounts[8 + 4 * TIER + (is_nan_code(result, kNanRing) ? 1 : (is_nan_code(result, kNanSlabs) ? 2 : 3))], 1u);
             }

@@ -540,14 +540,15 @@ void Primitive_Detection::batch_impl(const float* depth, const uint16_t* raw, fl
         int wanted = _requestedShards;
         if (wanted <= 0)
         {
-            // default: up to four shards per visible device when the batch gives each of them whole chunks -- their host threads
-            // overlap one shard's PCIe copy with another's kernels, read-back and container building (each shard has its own
-            // stream; measured on one MI355X, 1 024 raw frames: 58 k frames/s with one shard, 74 k with four)
+            // default: FOUR shards per visible device as soon as the batch holds two chunks per device, else one -- the shards' host
+            // threads overlap one shard's PCIe copy with another's kernels, read-back and container building (each shard has its own
+            // handle and stream, and a handle's read-back waits for that handle's work only).  Measured on one MI355X, round 6
+            // (profiles/r06_overlay_batch_rate.txt): 512 raw frames 61 k frames/s with one shard, 64 k with two, 70 k with four;
+            // 1 024: 61 k / 68 k / 78 k; below 384 frames the shards' fixed costs eat the overlap (256: 61 k / 52 k / 61 k).
             int devices = 0;
             if (cape_device_count(&devices) != CAPE_OK || devices <= 0)
                 devices = 1;
-            int perDevice = n_frames / (devices * _maxBatch);
-            perDevice = perDevice < 1 ? 1 : (perDevice > 4 ? 4 : perDevice);
+            const int perDevice = n_frames / devices >= 2 * _maxBatch ? 4 : 1;
             wanted = devices * perDevice;
         }
         if (wanted > n_frames)
