@@ -88,6 +88,8 @@ while done < n_total:
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH batch@{done} frame {k} cylinders={cyl}: {str(e)[:200]}", flush=True)
+                if os.environ.get("FUZZ_DUMP"):  # the offending frame, for a stand-alone reproduction
+                    np.save(os.path.join(os.environ["FUZZ_DUMP"], f"fuzz_fail_{W}x{H}_{done}_{k}_{int(cyl)}.npy"), frames[k])
             if cyl:
                 stats["cyl_labels"] += int(r.cyl_labels.max() > 0)
                 stats["planes"] += len(r.planes)

@@ -319,7 +319,11 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
     // segment is never written above the record it comes from); the cylinder instance, whose cylinder_fitting appends
     // segments of its own, has a separate area.
     double* s_pend = CYL ? s_pendCyl : s_seg;     // base of the record window (plane-only: advanced to s_seg + nSeg at each flush)
-    int pendCount = 0, pendCap = CYL ? kPendCyl : MAXP + 1;
+    // (never more than 64 records in the window: their fits run one LANE each.  Through round 5 the 64-segment plane-only instance
+    // let the window of an empty segment list grow to its 65 slots, and the 65th record -- a frame with that many regions before a
+    // flush, which the round-6 fuzz sweep found -- was converted with whatever fit its slot held from before)
+    constexpr int kWindowMax = 64;
+    int pendCount = 0, pendCap = CYL ? kPendCyl : (MAXP + 1 < kWindowMax ? MAXP + 1 : kWindowMax);
     int listTop = 0;                               // bump pointer in s_list: recorded regions keep their cell lists
     bool moreSeeds = !RESUME;
 
@@ -766,7 +770,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
             {
                 // plane-only: the next window starts at the first free segment slot (one spare slot past MAXP keeps it non-empty)
                 s_pend = s_seg + nSeg * kSegDoubles;
-                pendCap = MAXP + 1 - nSeg;
+                pendCap = MAXP + 1 - nSeg < kWindowMax ? MAXP + 1 - nSeg : kWindowMax;
             }
         }
         if (!moreSeeds)

@@ -1114,3 +1114,39 @@ def test_spill_pool_exhausted_is_flagged_not_silent(oracle_mod):
     warned = [ln for ln in lines if "per-frame capacity exceeded" in ln[1]]
     assert [ln[2] for ln in warned] == [f]
     ex.close()
+
+
+def test_record_window_of_more_than_64_regions(oracle_mod):
+    """A frame whose seed loop records 66 regions of which 59 become plane segments: it overflows the 32-segment instance and is redone
+    by the 64-segment one, whose record window used to hold MAXP + 1 = 65 slots while the regions' plane fits run one LANE each -- the
+    65th record was converted with whatever its slot held (found by the round-6 fuzz sweep: an extra segment in about half of 16 copies
+    of such a frame).  Sixteen copies in one batch, all equal to the oracle."""
+    from cape_amd import Extractor, synth
+
+    W, H, tile = 1280, 960, 120
+    intr = {k: v * 2.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
+    u = (np.arange(W) - intr["cx"]) / intr["fx"]
+    v = (np.arange(H) - intr["cy"]) / intr["fy"]
+    X, Y = np.meshgrid(u, v)
+    rng = np.random.default_rng(5)
+    tilts = [(0.5, 0.0), (-0.5, 0.0), (0.0, 0.5), (0.0, -0.5)]
+    z = np.zeros((H, W))
+    for ty in range(0, H, tile):
+        for tx in range(0, W, tile):
+            nx, ny = tilts[((tx // tile) % 2) + 2 * ((ty // tile) % 2)]
+            d = 2000.0 + 120.0 * (((tx // tile) * 7 + (ty // tile) * 13) % 9)
+            sl = (slice(ty, min(ty + tile, H)), slice(tx, min(tx + tile, W)))
+            sigma = 15.0 if ((tx // tile) + (ty // tile)) % 3 == 0 else 0.6  # a third of the facets: too noisy for a plane
+            z[sl] = d / (1.0 + nx * X[sl] + ny * Y[sl]) + rng.normal(0, sigma, z[sl].shape)
+    frame = np.round(z).astype(np.float32)
+    orc = oracle_mod.Oracle(W, H, cylinders=False, **intr)
+    want = orc.run(frame)
+    recorded = int(np.isin(want.seed_outcome, (1, 2, 3)).sum())
+    assert recorded >= 65 and 32 < len(want.segments) <= 64, (recorded, len(want.segments))
+    ex = Extractor(W, H, cylinders=False, max_batch=16, **intr)
+    for rep in range(2):
+        n = ex.extract_host(np.stack([frame] * 16))
+        res = ex.results(n)
+        for f in range(n):
+            compare_frame(want, ex, res, f, check_cells=False)
+    ex.close()
