@@ -822,8 +822,11 @@ namespace {
 // Outer boundary of the union of two simple rings (any orientation), counter-clockwise; empty if degenerate.
 // holes (optional): the bounded faces of the arrangement that lie in neither ring, i.e. the regions the two outlines
 // enclose without covering them (what boost::geometry::union_ returns as interior rings).
+// `faceRule` selects which bounded faces of the arrangement of the two rings go to `holes`: 0 = inside neither operand (the holes of
+// the union), 1 = inside A and outside B (the pieces of A \ B), 2 = inside both (the pieces of A n B).  Two faces that share an edge
+// differ in their membership of that edge's ring, so every face is a whole piece.
 std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std::vector<vector2>& B,
-                                       std::vector<std::vector<vector2>>* holes = nullptr)
+                                       std::vector<std::vector<vector2>>* holes = nullptr, int faceRule = 0)
 {
     double scale = 1.0;
     for (const auto* r : {&A, &B})
@@ -1003,7 +1006,10 @@ std::vector<vector2> rings_union_outer(const std::vector<vector2>& A, const std:
                         found = point_in_ring(probe, face, false);
                     }
                 }
-                if (found && !point_in_ring(probe, A, true) && !point_in_ring(probe, B, true))
+                if (!found)
+                    continue;
+                const bool inA = point_in_ring(probe, A, true), inB = point_in_ring(probe, B, true);
+                if ((faceRule == 0 && !inA && !inB) || (faceRule == 1 && inA && !inB) || (faceRule == 2 && inA && inB))
                     holes->push_back(face);
             }
     }
@@ -1074,14 +1080,38 @@ bool Polygon::merge_union(const Polygon& other)
             if (h.size() >= 3 && ring_is_simple(h))
                 merged.add_hole(h);
         }
-        // a hole an operand already had: kept if the other operand stays clear of it
+        // A hole an operand already had (boost::geometry::union_ of polygons with interior rings, polygon.cpp:463-470): what the
+        // other operand leaves uncovered of it stays a hole -- the whole of it if the other stays clear, nothing if the other
+        // covers it, and otherwise the pieces of (hole \ other's outer ring) plus the pieces of (hole n other's own holes).
+        // (Through round 5 a partly re-covered hole counted as filled.)
         const double tiny = 1e-12 * std::max(areaA, areaB);
+        // (the uncovered set is the disjoint union of  holeA \ outerB,  holeA n holeB  and  holeB \ outerA: the middle term is
+        // taken from this polygon's side only)
+        auto carry_hole = [&](const std::vector<vector2>& h, const std::vector<vector2>& otherRing,
+                              const std::vector<std::vector<vector2>>& otherHoles, const bool withOverlaps) {
+            const double covered = polygons_inter_area(h, {}, otherRing, otherHoles);
+            if (covered <= tiny)
+            {
+                merged.add_hole(h);
+                return;
+            }
+            std::vector<std::vector<vector2>> pieces;
+            if (rings_inter_area(h, otherRing) < std::abs(ring_area_signed(h)) - tiny)
+                (void)rings_union_outer(h, otherRing, &pieces, 1); // hole \ other
+            for (const auto& oh : otherHoles)
+                if (withOverlaps && rings_inter_area(h, oh) > tiny)
+                    (void)rings_union_outer(h, oh, &pieces, 2);    // hole n (a hole of the other)
+            for (auto& piece : pieces)
+            {
+                drop_collinear(piece);
+                if (piece.size() >= 3 && ring_is_simple(piece) && std::abs(ring_area_signed(piece)) > tiny)
+                    merged.add_hole(piece);
+            }
+        };
         for (const auto& h : _inners)
-            if (polygons_inter_area(h, {}, o._ring, o._inners) <= tiny)
-                merged.add_hole(h);
+            carry_hole(h, o._ring, o._inners, true);
         for (const auto& h : o._inners)
-            if (polygons_inter_area(h, {}, _ring, _inners) <= tiny)
-                merged.add_hole(h);
+            carry_hole(h, _ring, _inners, false);
     }
     *this = merged;
     simplify();

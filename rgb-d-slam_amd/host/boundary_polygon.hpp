@@ -81,8 +81,8 @@ class Polygon
     // being projected into this frame first; two disjoint polygons leave the larger one (the reference keeps the biggest
     // piece of the multi-polygon), then simplify().  A region that the two outlines enclose without covering it becomes an
     // interior ring, like in the Boost polygon the reference assigns (area, contains and the intersection / union areas
-    // honour it).  A hole one of the operands already had survives if the other operand does not touch it and is
-    // dropped otherwise (a partly re-covered hole counts as filled: the one approximation here).  Returns false (and
+    // honour it).  Of a hole one of the operands already had, what the other operand leaves uncovered stays a hole (the
+    // whole of it, nothing, or the pieces of hole \ other: round 6).  Returns false (and
     // changes nothing) if the result is empty.  Dependency-free: face walks over the arrangement of the two outer rings,
     // touching vertices and collinear overlaps included.
     bool merge_union(const Polygon& other);

@@ -263,6 +263,31 @@ int main()
         Polygon plug(std::vector<vector2> {{900, 900}, {2600, 900}, {2600, 2100}, {900, 2100}}, axes.first, axes.second, center);
         Polygon filled = ring;
         EXPECT(filled.merge_union(plug) && filled.interior_rings().empty() && near(filled.area(), 12e6) && filled.contains({1700, 1500}));
+        // a later union that covers the hole PARTLY leaves the rest of it a hole (boost::geometry::union_ of a polygon with an
+        // interior ring; through round 5 such a hole counted as filled): the plug covers x < 1750 of the hole [1000, 2500] x [1000, 2000]
+        Polygon halfPlug(std::vector<vector2> {{900, 900}, {1750, 900}, {1750, 2100}, {900, 2100}}, axes.first, axes.second, center);
+        Polygon half = ring;
+        EXPECT(half.merge_union(halfPlug) && half.interior_rings().size() == 1 && near(half.area(), 12e6 - 0.75e6));
+        EXPECT(half.contains({1500, 1500}) && !half.contains({2000, 1500}) && half.is_valid());
+        // the other way round: the plain rectangle takes the ring in
+        Polygon half2 = halfPlug;
+        EXPECT(half2.merge_union(ring) && half2.interior_rings().size() == 1 && near(half2.area(), 12e6 - 0.75e6) && !half2.contains({2000, 1500}));
+        // a bar through the middle of the hole cuts it in two: y in [1400, 1600] covered, two holes of 1500 x 400 remain
+        Polygon midBar(std::vector<vector2> {{500, 1400}, {3500, 1400}, {3500, 1600}, {500, 1600}}, axes.first, axes.second, center);
+        Polygon cut = ring;
+        EXPECT(cut.merge_union(midBar) && cut.interior_rings().size() == 2 && near(cut.area(), 12e6 - 2 * 0.6e6));
+        EXPECT(cut.contains({1700, 1500}) && !cut.contains({1700, 1200}) && !cut.contains({1700, 1800}));
+        // an operand that brings a hole of its own over the first one's: only the overlap of the two holes stays open
+        Polygon frame2 = cShape;
+        EXPECT(frame2.merge_union(bar));                                   // hole [1000, 2500] x [1000, 2000]
+        // the same figure 500 further along x: hole [1500, 3000] x [1000, 2000]
+        Polygon shifted(std::vector<vector2> {{500, 0}, {3500, 0}, {3500, 1000}, {1500, 1000}, {1500, 2000}, {3500, 2000}, {3500, 3000}, {500, 3000}},
+                        axes.first, axes.second, center);
+        Polygon bar2(std::vector<vector2> {{3000, 0}, {4500, 0}, {4500, 3000}, {3000, 3000}}, axes.first, axes.second, center);
+        EXPECT(shifted.merge_union(bar2) && shifted.interior_rings().size() == 1);
+        Polygon both = frame2;
+        EXPECT(both.merge_union(shifted) && both.interior_rings().size() == 1);
+        EXPECT(near(both.area(), 4500.0 * 3000.0 - 1000.0 * 1000.0) && !both.contains({2000, 1500}) && both.contains({1200, 1500}) && both.contains({2800, 1500}));
         // two disjoint operands: the bigger piece stays, with its hole
         Polygon farAway(std::vector<vector2> {{9000, 0}, {9500, 0}, {9500, 500}, {9000, 500}}, axes.first, axes.second, center);
         Polygon big = ring;

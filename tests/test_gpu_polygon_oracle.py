@@ -290,3 +290,22 @@ def test_polygons_of_a_spilled_frame_against_the_reference_algorithm(P):
     m = ex.polygon_matches(n)
     assert [bool(int(m["flags"][f]) & MATCH_EXACT_OVERFLOW) for f in range(n)] == [False, True, True, True]
     ex.close()
+
+
+def test_hull_that_touches_itself_takes_the_convex_fallback_on_the_device(P):
+    """The comb of tests/test_polygon_oracle.py::test_hull_that_touches_itself_is_flagged_and_measured on the device: the oracle flags
+    NEEDS_DISSOLVE (the reference would re-unite the traced pieces with Boost), the device -- like the host class -- returns the convex
+    hull, flagged CAPE_POLY_CONVEX_FALLBACK, whose area is the rectangle's (the measured cost of the fallback is in the CPU test)."""
+    import cape_amd
+    from cape_amd import Extractor, synth
+    from test_polygon_oracle import _comb_touching_itself
+
+    pts = _comb_touching_itself()
+    nrm, ctr = np.array([0.0, 0.0, 1.0]), np.zeros(3)
+    ref = P.Polygon.from_points(pts, nrm, ctr)
+    assert ref.flags & P.NEEDS_DISSOLVE
+    ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
+    pol, verts = ex.debug_polygon(pts, nrm, ctr)
+    assert pol["flags"] & cape_amd.POLY_VALID and pol["flags"] & cape_amd.POLY_CONVEX_FALLBACK, hex(int(pol["flags"]))
+    assert abs(float(pol["area"]) - 4000.0 * 2000.0) < 1e-6 * 8e6 and len(verts) == 4
+    ex.close()
