@@ -486,7 +486,9 @@ bool polygon_is_valid(const Ring& r)
 // geometry::correct of third_party/correct_boost_polygon.hpp:547-558 for an outer ring WITHOUT self-intersections:
 // impl::correct(ring, clockwise) = close (:188-195), reverse if its area is negative (:172-186), no self turns (:127-160)
 // -> the ring itself if |area| > 0 (:349-356), else nothing.  needsDissolve: the ring touches or crosses itself, the
-// reference then traces sub-rings and unions them with Boost -- not restated.
+// reference then traces sub-rings and unions them with Boost -- proper crossings are restated below; a mere touch is not, and
+// tests/test_polygon_oracle.py::test_hull_that_touches_itself_is_flagged_and_measured forces one and measures what the product's
+// convex fallback costs there.
 // dissolve (correct_boost_polygon.hpp:127-160, :199-330) for PROPER crossings: the crossing point becomes a pseudo-vertex of both
 // edges (:146-157), the trace from a start key follows the ring up to the crossing, takes the by-pass to the other edge and
 // runs on (:286-300): the ring comes apart into the part that runs on past the crossing and the loop it cuts off.  The
@@ -494,7 +496,8 @@ bool polygon_is_valid(const Ring& r)
 // loop cut off by a crossing winds the other way and lies outside the rest, so it is not subtracted from it: covered_by :383-392
 // fails) -- UNPINNED where it leans on Boost (the turn point's coordinates, the order of the union's output): restated as "cut at
 // the first crossing in edge order, keep the piece of greater |area|, orient it clockwise (:358-369), repeat".  A ring that merely
-// touches itself (a vertex on another edge, collinear overlap) needs Boost's union of the traced pieces: not restated.
+// touches itself needs Boost's union of the traced pieces: not restated.  Only a touch along COLLINEAR points can come out of the
+// walk (a vertex on another edge makes Intersects reject the candidate: same test); flagged F_NEEDS_DISSOLVE, pinned by that test.
 bool first_contact(const Ring& r, size_t& ci, size_t& cj, bool& proper)
 {
     const size_t n = r.size() - 1; // closed ring: n edges

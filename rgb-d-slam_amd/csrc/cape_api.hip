@@ -24,6 +24,7 @@ hipError_t launch_cell_strips(const StageAParams& p, int nFrames, uint32_t* fram
 int cell_plane_rows_per_tile(const StageAParams& p, int nFrames);
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done,
                        const GenParams* gen);
+hipError_t launch_grow_general(const StageBParams& p, const GenParams& g, int nFrames, hipStream_t stream);
 size_t grow_lds_bytes(int cells, bool cylinders, int maxPlanes);
 size_t grow_state_bytes(int cells);
 bool resume_group_fits(const StageBParams& p);
@@ -110,6 +111,17 @@ class DeviceGuard
     if (_deviceGuard.error() != hipSuccess)                                                                  \
     return fail(CAPE_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_deviceGuard.error()))
 
+// A one-frame chain may have left the general grow instance to the first reader of its results (cape_handle_s::lazySpillArmed):
+// an entry point that is about to enqueue work on those results settles that first (a host wait -- such handles serve one frame
+// at a time, their callers wait for every call anyway).
+#define CAPE_SETTLE_RESULTS(h)                                                                               \
+    do                                                                                                       \
+    {                                                                                                        \
+        if ((h)->lazySpillArmed)                                                                             \
+            if (const int rc_ = wait_results(h); rc_ != CAPE_OK)                                             \
+                return rc_;                                                                                  \
+    } while (0)
+
 } // namespace
 
 struct cape_handle_s
@@ -184,6 +196,11 @@ struct cape_handle_s
     uint32_t* doneFlag = nullptr;
     uint32_t* doneCounter = nullptr; // device: the one-frame chain's grow kernel counts its waves out and stores the number itself
     uint32_t doneSeq = 0;      // sequence number of the last chain enqueued
+    // one-frame chain: the general grow instance is enqueued by whoever waits for the results, and only if the chain's last wave
+    // reported frames on the spill list (doneFlag[1], StageBParams::spillHost); the chain's parameters are kept for that launch
+    bool lazySpillArmed = false;
+    int lazySpillFrames = 0;
+    cape::StageBParams lazySpillParams{};
     bool doneArmed = false;    // a chain with a signal behind it is (or was) in flight
     // host staging for cape_extract_host
     float* depthStage = nullptr;
@@ -445,6 +462,7 @@ void offset_params(const cape_handle_s* h, int f0, cape::StageAParams& a, cape::
 }
 
 int fold_timings(cape_handle_s* h);
+int wait_results(cape_handle_s* h);
 
 // utils::Random (src/utils/random.hpp:17-30, :59-64): the first kRngTable doubles of mt19937(seed) + uniform_real_distribution(0, 1)
 // (libstdc++ on the host = the reference's own generator)
@@ -601,6 +619,7 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         bb.doneFlag = h->doneFlag;
         bb.doneCounter = h->doneCounter;
         bb.doneSeq = ++h->doneSeq;
+        bb.spillHost = h->generalAll ? nullptr : h->doneFlag + 1;
     }
     if (bb.needCylinder)
     {
@@ -661,6 +680,12 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
         }
         h->doneArmed = true;
     }
+    h->lazySpillArmed = bb.spillHost != nullptr;
+    if (h->lazySpillArmed)
+    {
+        h->lazySpillParams = bb;
+        h->lazySpillFrames = frames;
+    }
     return CAPE_OK;
 }
 
@@ -668,7 +693,33 @@ int launch_chain(cape_handle_s* h, const cape::StageAParams& a, const cape::Stag
 // ~10 us of wake-up on top of the kernels when the whole call is ~130 us; a spin on a pinned word costs a PCIe write.
 // If the word does not arrive in time (a faulted kernel, a descheduled process) the stream synchronisation takes over
 // and reports whatever went wrong.
+int wait_results_once(cape_handle_s* h);
 int wait_results(cape_handle_s* h)
+{
+    if (const int rc = wait_results_once(h); rc != CAPE_OK)
+        return rc;
+    if (h->lazySpillArmed)
+    {
+        // the one-frame chain left the general grow instance to us: a frame of more than 64 plane segments / cylinder labels is on
+        // the spill list (the word next to the completion word says how many) -- enqueue that kernel now and wait for its signal
+        h->lazySpillArmed = false;
+        if (h->doneFlag && h->doneFlag[1] != 0u)
+        {
+            cape::StageBParams p = h->lazySpillParams;
+            p.spillHost = nullptr;
+            p.allFrames = 0;
+            p.doneSeq = ++h->doneSeq;
+            CAPE_HIP_TRY(cape::launch_grow_general(p, h->gen, h->lazySpillFrames, h->lastStream));
+            if (h->workDone && hipEventRecord(h->workDone, h->lastStream) == hipSuccess)
+                h->workRecorded = true;
+            h->doneArmed = true;
+            return wait_results_once(h);
+        }
+    }
+    return CAPE_OK;
+}
+
+int wait_results_once(cape_handle_s* h)
 {
     if (h->doneArmed && h->doneFlag)
     {
@@ -1232,6 +1283,7 @@ static int extract_impl(cape_handle h, const float* depth_dev, const uint16_t* d
     h->pa.depth_u16 = depth_u16;
     h->pa.u16_scale = scale;
     h->doneArmed = false; // only launch_chain puts a signal behind the work; every other path drains the stream
+    h->lazySpillArmed = false; // (a one-frame chain nobody read: its results are about to be overwritten)
     if (h->cfg.sub_batches > 1 && n_frames >= 2 * h->cfg.sub_batches)
     {
         // fork: both internal streams wait for everything already enqueued on the caller's stream
@@ -1554,6 +1606,7 @@ int cape_copy_seed_sequence(cape_handle h, int32_t frame, int32_t* seeds_out, in
     if (!h || !n_out || frame < 0 || frame >= h->cfg.max_batch || capacity < 0 || (capacity > 0 && !seeds_out))
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / frame / buffer");
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     CAPE_HIP_TRY(hipDeviceSynchronize());
     cape_frame_header hdr;
     CAPE_HIP_TRY(hipMemcpy(&hdr, &h->records[frame].header, sizeof(hdr), hipMemcpyDeviceToHost));
@@ -1685,6 +1738,7 @@ int cape_match_consecutive(cape_handle h, int32_t n_frames, uint32_t flags, void
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     StreamScope streamScope(h, static_cast<hipStream_t>(stream_));
     if (streamScope.rc() != CAPE_OK)
         return streamScope.rc();
@@ -1855,6 +1909,7 @@ int cape_pack_primitives(cape_handle h, int32_t n_frames, int32_t first_frame, v
     if (n_frames > h->lastFrames)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     if (const int rc = ensure_gather_configured(h); rc != CAPE_OK)
         return rc;
     if (n_frames > h->gatherLayout.frames_capacity)
@@ -1973,6 +2028,7 @@ static int gather_impl(cape_handle h, int32_t n_frames, int32_t first_frame, int
     if (n_frames > h->lastFrames)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     if (const int rc = ensure_gather_configured(h); rc != CAPE_OK)
         return rc;
     if (n_frames > h->gatherLayout.frames_capacity)
@@ -2023,6 +2079,7 @@ int cape_count_primitives(cape_handle h, int32_t n_frames, int32_t* n_planes, in
     if (n_frames > h->lastFrames)
         return fail(CAPE_ERR_CAPACITY, "n_frames exceeds the last cape_extract batch");
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     int32_t tot[4] = {0, 0, 0, 0};
     if (n_frames > 0)
     {
@@ -2076,6 +2133,7 @@ int cape_build_polygons(cape_handle h, int32_t n_frames, void* stream_)
     if (n_frames == 0)
         return CAPE_OK;
     CAPE_ON_DEVICE(h);
+    CAPE_SETTLE_RESULTS(h);
     const size_t B = (size_t)h->cfg.max_batch + (size_t)h->spillRecords; // a polygon row / vertex slab per record, spill pool included
     if (!h->polygons)
     {

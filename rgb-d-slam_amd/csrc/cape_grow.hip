@@ -825,8 +825,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, CYL ? (RESUME ? CAPE_B_RESUME_
             if (atomicAdd(p.doneCounter, 1u) == total - 1u)
             {
                 atomicExch(p.doneCounter, 0u); // ready for the next chain
-                // a frame handed to the general instance is not done yet: that kernel, enqueued right behind, signals instead
-                if (!(p.spillList && atomicAdd(&p.spillList[0], 0u) != 0u))
+                // a frame handed to the general instance is not done yet: either that kernel is enqueued right behind and signals
+                // instead, or (p.spillHost) the host is told how many frames wait for it and enqueues it itself
+                const unsigned waiting = p.spillList ? atomicAdd(&p.spillList[0], 0u) : 0u;
+                if (p.spillHost)
+                    __hip_atomic_store(p.spillHost, waiting, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p.spillHost || waiting == 0u)
                     __hip_atomic_store(p.doneFlag, p.doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -951,7 +955,7 @@ hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, h
             CAPE_LAUNCH_TRY((launch_grow_variant<true, CAPE_MAX_PLANES>(p, nFrames, stream)));
         else
             CAPE_LAUNCH_TRY((launch_grow_variant<false, CAPE_MAX_PLANES>(p, nFrames, stream)));
-        if (gen && p.spillList)
+        if (gen && p.spillList && !p.spillHost)
             CAPE_LAUNCH_TRY(launch_grow_general(p, *gen, nFrames, stream));
         return hipSuccess;
     }

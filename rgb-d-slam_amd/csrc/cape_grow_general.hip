@@ -1070,6 +1070,8 @@ __device__ void general_frame(const StageBParams& p, const GenParams& g, const G
     CAPE_WAVE_SYNC();
 }
 
+} // namespace
+
 template <bool CYL> __global__ __launch_bounds__(64, 1) void cape_grow_general_kernel(StageBParams p, GenParams g, int nFrames)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1110,8 +1112,6 @@ template <bool CYL> __global__ __launch_bounds__(64, 1) void cape_grow_general_k
         }
     }
 }
-
-} // namespace
 
 // Most plane segments / cylinder labels a frame can hold: every segment consumes cells of its own -- a grown region at least
 // max(1, minCellActivated) (primitive_detection.cpp:362-363), a plane found inside a cylinder candidate at least six inliers

@@ -139,6 +139,10 @@ struct StageBParams
     uint32_t* doneFlag;      // pinned, device-mapped ; nullptr: nobody to signal
     uint32_t* doneCounter;   // device: waves of the signalling kernel that are through
     uint32_t doneSeq;
+    // one-frame chain on a grid the fast kernels serve: the general instance is NOT enqueued behind the 64-segment one (a launch on
+    // the latency path for a frame in ten thousand) -- the signalling wave leaves the number of frames on spillList in this pinned
+    // word, and whoever reads the results launches the general kernel then, if it is not zero (cape_api.hip: wait_results)
+    uint32_t* spillHost;
 };
 
 // The general grow instance (cape_grow_general.hip): any grid size, any number of plane segments.  One wavefront per frame, its

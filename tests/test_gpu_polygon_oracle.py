@@ -292,20 +292,23 @@ def test_polygons_of_a_spilled_frame_against_the_reference_algorithm(P):
     ex.close()
 
 
-def test_hull_that_touches_itself_takes_the_convex_fallback_on_the_device(P):
-    """The comb of tests/test_polygon_oracle.py::test_hull_that_touches_itself_is_flagged_and_measured on the device: the oracle flags
-    NEEDS_DISSOLVE (the reference would re-unite the traced pieces with Boost), the device -- like the host class -- returns the convex
-    hull, flagged CAPE_POLY_CONVEX_FALLBACK, whose area is the rectangle's (the measured cost of the fallback is in the CPU test)."""
+def test_hull_that_touches_itself_on_the_device(P):
+    """The comb of tests/test_polygon_oracle.py::test_hull_that_touches_itself_is_flagged_and_measured on the device.  The oracle flags
+    NEEDS_DISSOLVE (its validity test counts a contact along collinear points; the reference would re-unite the traced pieces with
+    Boost).  The device -- same statements as the host class -- looks for PROPER crossings only, finds none, keeps the walk's ring and
+    simplifies it (the doubled stretch along the tooth goes with Douglas-Peucker): a valid polygon whose area is within 2 % of the region
+    the walk's ring covers by the non-zero winding rule.  That is the measured size of the one N1 divergence that is left."""
     import cape_amd
     from cape_amd import Extractor, synth
-    from test_polygon_oracle import _comb_touching_itself
+    from test_polygon_oracle import _comb_touching_itself, winding_area
 
     pts = _comb_touching_itself()
     nrm, ctr = np.array([0.0, 0.0, 1.0]), np.zeros(3)
     ref = P.Polygon.from_points(pts, nrm, ctr)
     assert ref.flags & P.NEEDS_DISSOLVE
+    covered = winding_area(ref.ring)
     ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
     pol, verts = ex.debug_polygon(pts, nrm, ctr)
-    assert pol["flags"] & cape_amd.POLY_VALID and pol["flags"] & cape_amd.POLY_CONVEX_FALLBACK, hex(int(pol["flags"]))
-    assert abs(float(pol["area"]) - 4000.0 * 2000.0) < 1e-6 * 8e6 and len(verts) == 4
+    assert pol["flags"] & cape_amd.POLY_VALID and not pol["flags"] & cape_amd.POLY_OVERFLOW, hex(int(pol["flags"]))
+    assert abs(float(pol["area"]) / covered - 1.0) < 0.02, (float(pol["area"]), covered)
     ex.close()

@@ -346,9 +346,10 @@ def winding_area(ring, samples=400000, seed=3):
 def test_hull_that_touches_itself_is_flagged_and_measured(P):
     """The one N1 case that is NOT restated: a hull that merely TOUCHES itself.  The reference re-unites the traced pieces with Boost set
     operations (correct_boost_polygon.hpp:222-356); the oracle flags NEEDS_DISSOLVE and gives no polygon, the product (host class and
-    device, tests/test_gpu_polygon_oracle.py) falls back to the convex hull like for a failed walk (polygon.cpp:200-207).  This input
-    forces the case, and the cost of the fallback is measured: the region the walk's ring covers (non-zero winding, Monte Carlo) against
-    the convex hull the product returns.  (A T-shaped touch cannot come out of the walk at all -- the reference's Intersects counts a
+    device, tests/test_gpu_polygon_oracle.py::test_hull_that_touches_itself_on_the_device) keeps the walk's ring when it has no PROPER
+    crossing and simplifies it, and falls back to the convex hull otherwise (polygon.cpp:200-207).  This input forces the case, and
+    its cost is measured: the region the walk's ring covers (non-zero winding, Monte Carlo) against the convex hull -- the upper bound
+    of what the product can return for it.  (A T-shaped touch cannot come out of the walk at all -- the reference's Intersects counts a
     crossing point inside both bounding boxes, ends included, and rejects the candidate edge: the pinched pair of squares below walks
     to a simple ring --; what does come out is a touch along COLLINEAR points, which Intersects never reports: 'parallel segments never
     intersect'.)"""
