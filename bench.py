@@ -163,7 +163,7 @@ def parity_check(ex, frames_host, intr, cylinders, n):
                 and np.array_equal(bits(segs["centroid"]), bits(o[:, 4:7])) and np.array_equal(bits(segs["mse"]), bits(o[:, 7]))
                 and np.array_equal(bits(segs["score"]), bits(o[:, 8])) and np.array_equal(bits(segs["sums"]), bits(o[:, 9:18]))
                 and np.array_equal(segs["merge_label"], r.merge_labels))
-        kept = res.records["cylinders"][f][: hdr["n_cylinder_labels"]]
+        kept = res.cylinder_labels(f)  # (follows the frame's spill records, if it has more than 64 labels)
         kept = kept[kept["kept"] == 1]
         cyl_ok = len(kept) == len(r.cylinders)
         if cyl_ok and len(kept):
@@ -290,6 +290,7 @@ def main():
                     help="N>1: gather the packed lists to rank 0 only (cape_gather_primitives_root) instead of all-gathering them")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the in-run comparison of the last step's results with the CPU oracle")
     ap.add_argument("--parity-frames", type=int, default=0, help="frames of the last step the in-run check compares with the oracle (0 = every distinct frame)")
+    ap.add_argument("--no-wide-grid", action="store_true", help="skip the extra legs on a 1920x1080 grid and on a frame of more than 64 plane segments")
     ap.add_argument("--no-polygons", action="store_true", help="skip the extra boundary-polygon leg (cape_build_polygons)")
     ap.add_argument("--no-cylinders-on", action="store_true",
                     help="N=1 default workload: skip the extra 'cylinders_on' leg (same stream with the reference's unconditional cylinder branch)")
@@ -946,6 +947,69 @@ def main():
         for h in pair:
             h.close()
         out["find_primitives_equivalent"] = fpe
+    if (rank == 0 and world == 1 and not multi and out is not None and not args.no_wide_grid and not args.cylinders and not args.u16
+            and not args.match and scene == "room" and (W, H) == (640, 480)):
+        # Round 6: what lies beyond the fast kernels' fixed shapes, in the driver-visible line.  (a) 1920 x 1080 (96 x 54 cells: every
+        # frame through the general grow instance), frames resident in HBM, every frame of the step checked against the oracle;
+        # (b) a frame of more than 64 plane segments (a checkerboard of tilted facets) inside an ordinary 1280 x 960 batch: its record
+        # chain against the oracle.  Not part of `value`.
+        Ww, Hw, nw = 1920, 1080, 256
+        intr_w = {k: v * Ww / 640.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
+        dw = synth_gpu.stream("room", 7, nw, width=Ww, height=Hw, device="cuda", chunk=16)
+        exw = Extractor(Ww, Hw, cylinders=True, device=dev_index, max_batch=nw, **intr_w)
+        for _ in range(2):
+            exw.extract_device(dw.data_ptr(), nw, stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            exw.extract_device(dw.data_ptr(), nw, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        msw = e0.elapsed_time(e1) / 5
+        wide = {"grid": f"{Ww}x{Hw} ({Ww // 20} x {Hw // 20} cells)", "frames": nw, "ms_per_batch": msw, "frames_per_s": nw / (msw * 1e-3),
+                "general_instance_frames": exw.spill_info()[2], "cylinders": True,
+                "note": "the reference takes any image size (primitive_detection.cpp:26-67); grids beyond 64 x 64 cells run in "
+                        "cape_grow_general_kernel (bit rows in memory, 16-bit labels), stage A unchanged"}
+        if not args.no_parity_check:
+            wide["parity_check"] = parity_check(exw, lambda a, c: dw[a:a + c].cpu().numpy(), intr_w, True, nw)
+            if not parity_ok(wide["parity_check"]):
+                print(f"bench.py: 1920x1080 results differ from the oracle: {wide['parity_check']}", file=sys.stderr)
+                raise SystemExit(3)
+        exw.close()
+        del dw
+        Wc, Hc = 1280, 960
+        intr_c = {k: v * 2.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
+        uu = (np.arange(Wc) - intr_c["cx"]) / intr_c["fx"]
+        vv = (np.arange(Hc) - intr_c["cy"]) / intr_c["fy"]
+        Xc, Yc = np.meshgrid(uu, vv)
+        rngc = np.random.default_rng(3)
+        zc = np.zeros((Hc, Wc))
+        tilts = [(0.5, 0.0), (-0.5, 0.0), (0.0, 0.5), (0.0, -0.5)]
+        for ty in range(0, Hc, 100):
+            for tx in range(0, Wc, 100):
+                nxc, nyc = tilts[((tx // 100) % 2) + 2 * ((ty // 100) % 2)]
+                dc = 2000.0 + 120.0 * (((tx // 100) * 7 + (ty // 100) * 13) % 9)
+                sl = (slice(ty, min(ty + 100, Hc)), slice(tx, min(tx + 100, Wc)))
+                zc[sl] = dc / (1.0 + nxc * Xc[sl] + nyc * Yc[sl])
+        zc += rngc.normal(0, 0.6, zc.shape)
+        board = np.round(zc).astype(np.float32)
+        mix = np.stack([synth.room(seed=1, frame=k, width=Wc, height=Hc, intr=intr_c) if k % 4 else board for k in range(8)])
+        exc = Extractor(Wc, Hc, cylinders=True, device=dev_index, max_batch=len(mix), **intr_c)
+        exc.extract_host(mix)
+        used, cap, through = exc.spill_info()
+        chain = {"grid": "1280x960", "frames": len(mix), "frames_of_more_than_64_segments": int(through), "spill_records_used": int(used),
+                 "spill_pool": int(cap),
+                 "most_segments_in_a_frame": int(exc.results(len(mix), with_boundary=False).records["header"]["n_plane_segments"].max()),
+                 "note": "_planeSegments is an unbounded vector in the reference (primitive_detection.hpp:206): a frame beyond a record's 64 "
+                         "segments continues in spill records (cape_frame_header.next_record), written by the general instance"}
+        if not args.no_parity_check:
+            chain["parity_check"] = parity_check(exc, mix, intr_c, True, len(mix))
+            if not parity_ok(chain["parity_check"]):
+                print(f"bench.py: record-chain results differ from the oracle: {chain['parity_check']}", file=sys.stderr)
+                raise SystemExit(3)
+        exc.close()
+        out["beyond_fixed_capacities"] = {"wide_grid": wide, "record_chain": chain}
     if out is not None and polygons_leg is not None:
         out["boundary_polygons"] = polygons_leg
     result_line = json.dumps(out) if out is not None else None

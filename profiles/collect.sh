@@ -20,7 +20,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 CAPE_BENCH_FORCE_GATHER=1 python $R/bench.py --gpus 1 --no-cpu-baseline > $OUT/${TAG}_configs3_bench.json 2> $OUT/bench3.err
-BARGS="--no-cpu-baseline --steps 60 --warmup 3 --no-cylinders-on --no-polygons --no-parity-check"
+BARGS="--no-cpu-baseline --steps 60 --warmup 3 --no-cylinders-on --no-polygons --no-parity-check --no-wide-grid"
 stats() { # name, bench args...
     local name=$1; shift
     rocprofv3 --kernel-trace --stats -d $OUT/kt_$name -o k -- python $R/bench.py $BARGS "$@" > /dev/null 2> $OUT/kt_$name.err
