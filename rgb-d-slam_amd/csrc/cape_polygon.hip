@@ -1420,7 +1420,21 @@ __global__ __launch_bounds__(64 * kPolyWavesPerGroup, CAPE_POLY_OCC) void cape_p
 constexpr int kListFrames = 16; // frames (waves) of a list workgroup: ONE atomic per counter and workgroup -- a counter that every
                                 // frame's wave bumps on its own serialises 4 096 atomics on one address (74 us of the pass)
 constexpr int kSizeBuckets = 16;
-__global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames, int pass)
+// the headers of the two work lists and of the queue, zeroed by ONE small launch (three memset nodes through round 5)
+__global__ void cape_polygon_reset_kernel(PolygonParams p)
+{
+    const int t = threadIdx.x;
+    if (t < kPolyListHeader)
+    {
+        p.lists[t] = 0u;
+        p.lists[(size_t)p.listStride + t] = 0u;
+        p.queue[t] = 0u;
+    }
+}
+
+// `queueLen`: slots of the task queue this call may use; pass 0 marks them "not written yet" and clears the polygon rows -- every
+// virtual frame's wave its share, instead of two memsets over 7 MB + 25 MB per 4 096 frames in front of the pass
+__global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(PolygonParams p, int nFrames, int pass, unsigned queueLen)
 {
     __shared__ unsigned s_cnt[kSizeBuckets + 1], s_base[kSizeBuckets + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1432,11 +1446,21 @@ __global__ __launch_bounds__(64 * kListFrames) void cape_polygon_list_kernel(Pol
     {
         frame = p.poolBase + (vframe - nFrames);
         live = true;
-        if (pass == 0) // (the batch's rows were cleared by launch_polygons' memset; the pool's only where they are in use)
+    }
+    if (pass == 0)
+    {
+        // this wave's share of the queue marks (every virtual frame takes part, in use or not) ...
+        const unsigned vTotal = (unsigned)(nFrames + p.poolCapacity);
+        const unsigned share = (queueLen + vTotal - 1u) / vTotal;
+        const unsigned q0 = (unsigned)vframe * share;
+        if ((unsigned)vframe < vTotal)
+            for (unsigned q = q0 + lane; q < q0 + share && q < queueLen; q += 64)
+                p.queue[kPolyListHeader + q] = 0xFFFFFFFFu;
+        // ... and the polygon rows of its record (segments that are no output plane keep the empty record)
+        if (live)
         {
-            cape_polygon* row = p.polygons + (size_t)frame * CAPE_MAX_PLANES + lane;
-            uint32_t* w = reinterpret_cast<uint32_t*>(row);
-            for (int k = 0; k < (int)(sizeof(cape_polygon) / 4); ++k)
+            uint32_t* w = reinterpret_cast<uint32_t*>(p.polygons + (size_t)frame * CAPE_MAX_PLANES);
+            for (int k = lane; k < (int)(CAPE_MAX_PLANES * sizeof(cape_polygon) / 4); k += 64)
                 w[k] = 0u;
         }
     }
@@ -1544,22 +1568,17 @@ void polygon_bind_scratch(PolygonParams& p, void* base, size_t frames, int bound
 
 hipError_t launch_polygons(const PolygonParams& p, int nFrames, hipStream_t stream)
 {
-    // the headers of the two work lists (list m at p.lists + m * listStride) and of the queue, and the queue's "not written yet"
-    // marks: ONE length -- what nFrames frames can spawn plus a quit mark per wave -- for the memset and for the kernel's bounds
-    for (int m = 0; m < 2; ++m)
-        if (const hipError_t e = hipMemsetAsync(p.lists + (size_t)m * p.listStride, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
-            return e;
-    if (const hipError_t e = hipMemsetAsync(p.queue, 0, kPolyListHeader * sizeof(uint32_t), stream); e != hipSuccess)
+    // the headers of the two work lists (list m at p.lists + m * listStride) and of the queue: one small launch; the queue's "not
+    // written yet" marks and the polygon rows: pass 0 of the list kernel.  ONE length -- what the frames can spawn plus a quit mark
+    // per wave -- for the marks and for the task kernel's bounds
+    hipLaunchKernelGGL(cape_polygon_reset_kernel, dim3(1), dim3(64), 0, stream, p);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess)
         return e;
     const size_t wanted = polygon_queue_slots((size_t)nFrames + (size_t)p.poolCapacity);
     const size_t queue = wanted < (size_t)p.queueCapacity ? wanted : (size_t)p.queueCapacity;
-    if (const hipError_t e = hipMemsetAsync(p.queue + kPolyListHeader, 0xFF, queue * sizeof(uint32_t), stream); e != hipSuccess)
-        return e;
-    if (const hipError_t e = hipMemsetAsync(p.polygons, 0, (size_t)nFrames * CAPE_MAX_PLANES * sizeof(cape_polygon), stream); e != hipSuccess)
-        return e;
     for (int pass = 0; pass < 2; ++pass)
     {
-        hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + p.poolCapacity + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames, pass);
+        hipLaunchKernelGGL(cape_polygon_list_kernel, dim3((nFrames + p.poolCapacity + kListFrames - 1) / kListFrames), dim3(64 * kListFrames), 0, stream, p, nFrames, pass, (unsigned)queue);
         if (const hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
