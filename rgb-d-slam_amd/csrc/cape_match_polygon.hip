@@ -46,21 +46,32 @@ template <int TIER> struct Tier;
 #ifndef CAPE_MP_T0_GROUPS
 #define CAPE_MP_T0_GROUPS 4
 #endif
+// kCoop (round 6): the four waves of a workgroup work on ONE pair -- the tiers behind the first hold the long pairs (an outline of
+// 70 vertices over 145 slabs: 0.1 ms on a lone wave), whose edge-pair crossings, boundary sort and (edge, slab) incidences are
+// data-parallel; only the final sum of the slab terms is ordered.  Same LDS per pair as before (the carve is shared), a quarter of
+// the time for the parallel phases.  CAPE_MP_COOP=0: one wave per pair in every tier (the round-5 kernel, A/B builds).
+#ifndef CAPE_MP_COOP
+#define CAPE_MP_COOP 1
+#endif
 template <> struct Tier<0>
 {
     static constexpr int kRing = 32, kXs = CAPE_MP_T0_XS, kStack = CAPE_MP_T0_STACK, kWavesPerGroup = 2, kGroupsPerCu = CAPE_MP_T0_GROUPS;
+    static constexpr bool kCoop = false;
 };
 template <> struct Tier<1>
 {
-    static constexpr int kRing = 128, kXs = 1024, kStack = 16, kWavesPerGroup = 1, kGroupsPerCu = 2;
+    static constexpr bool kCoop = CAPE_MP_COOP != 0;
+    static constexpr int kRing = 128, kXs = 1024, kStack = 16, kWavesPerGroup = kCoop ? 4 : 1, kGroupsPerCu = 2;
 };
 template <> struct Tier<2> // the comb-shaped outline that comes along once in a few thousand frames
 {
-    static constexpr int kRing = 128, kXs = 1024, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
+    static constexpr bool kCoop = CAPE_MP_COOP != 0;
+    static constexpr int kRing = 128, kXs = 1024, kStack = 32, kWavesPerGroup = kCoop ? 4 : 1, kGroupsPerCu = 1;
 };
 template <> struct Tier<3> // outlines of more than 128 vertices: the 64 x 48 cell grid of 1280 x 960 frames shows them (207 on the
-{                          // TUM-like stream, profiles/r04_capacity_probe.txt); 145 KB of LDS, one wave per CU
-    static constexpr int kRing = 512, kXs = 2048, kStack = 32, kWavesPerGroup = 1, kGroupsPerCu = 1;
+{                          // TUM-like stream, profiles/r04_capacity_probe.txt); 145 KB of LDS, one workgroup per CU
+    static constexpr bool kCoop = CAPE_MP_COOP != 0;
+    static constexpr int kRing = 512, kXs = 2048, kStack = 32, kWavesPerGroup = kCoop ? 4 : 1, kGroupsPerCu = 1;
 };
 constexpr int kTiers = 4;
 // the largest capacity any LATER tier offers (a pair beyond a tier's capacity moves on while one of them can hold it)
@@ -103,6 +114,7 @@ struct MpLds
     unsigned short* bk;   // 2 x 64 x CAP: their edge indices
     unsigned short* inc;  // 2 x 64 x CAP: where each (edge, slab) incidence of the window went: bucket << 8 | position
     unsigned char* sidx;  // 2 x 64 x CAP: positions in sorted order
+    int* sh;              // 8 words the waves of a cooperative workgroup hand uniform values over in (kCoop tiers)
 };
 
 __device__ __forceinline__ double y_at(const Edge& e, double x) { return e.a.y + (e.b.y - e.a.y) * ((x - e.a.x) / (e.b.x - e.a.x)); }
@@ -442,6 +454,298 @@ __device__ inline double rings_inter_area(const MpLds& L, int na, int nb, int la
     return area;
 }
 
+// rings_inter_area for the FOUR waves of a workgroup on one pair (Tier::kCoop): the same statements, the data-parallel loops
+// spread over 256 threads, the wave-collective ones (ordered compaction of the edges, std::unique, the prefix over the edges'
+// slab counts, the slabs' trapezoids and the ordered sum) on wave 0, workgroup barriers between them.  Uniform values travel
+// through L.sh.  The area is wave 0's (thread 0 stores it); every thread returns the same NaN code when a capacity is exceeded.
+template <int kStackCap, int kXsCap>
+__device__ inline double rings_inter_area_coop(const MpLds& L, int na, int nb, int tid)
+{
+    constexpr int kTermsPerSlab = kStackCap;
+    constexpr int NT = 256;
+    const int lane = tid & 63, wave = tid >> 6;
+    int* sh = L.sh;
+    if (na < 3 || nb < 3)
+        return 0.0;
+    if (wave == 0)
+    {
+        const int nea0 = edges_of(L.ringA, na, L.ea, lane), neb0 = edges_of(L.ringB, nb, L.eb, lane);
+        if (lane == 0)
+        {
+            sh[0] = nea0;
+            sh[1] = neb0;
+            sh[2] = na + nb; // boundaries so far: every vertex
+            sh[3] = 0;       // overflow
+        }
+    }
+    for (int i = tid; i < na; i += NT)
+        L.xs[i] = L.ringA[i].x;
+    for (int i = tid; i < nb; i += NT)
+        L.xs[na + i] = L.ringB[i].x;
+    __syncthreads();
+    const int nea = sh[0], neb = sh[1];
+    // isolated edge crossings: every wave takes its share of the edge pairs and reserves room for what it finds with one atomic
+    // (the boundaries are sorted afterwards: their arrival order is free)
+    const int pairs = nea * neb;
+    for (int base = 64 * wave; base < pairs; base += NT)
+    {
+        const int q = base + lane;
+        bool has = false;
+        double x = 0.0;
+        if (q < pairs)
+        {
+            const Edge e = L.ea[q / neb], f = L.eb[q % neb];
+            const double d1x = e.b.x - e.a.x, d1y = e.b.y - e.a.y, d2x = f.b.x - f.a.x, d2y = f.b.y - f.a.y;
+            const double den = d1x * d2y - d1y * d2x;
+            if (den != 0) // parallel / collinear: no isolated crossing
+            {
+                const double t = ((f.a.x - e.a.x) * d2y - (f.a.y - e.a.y) * d2x) / den;
+                const double u = ((f.a.x - e.a.x) * d1y - (f.a.y - e.a.y) * d1x) / den;
+                if (t > 0 && t < 1 && u > 0 && u < 1)
+                {
+                    has = true;
+                    x = e.a.x + t * d1x;
+                }
+            }
+        }
+        const unsigned long long hb = __ballot(has);
+        const int add = __popcll(hb);
+        if (add)
+        {
+            int at = 0;
+            if (lane == 0)
+                at = atomicAdd(&sh[2], add);
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (at + add > kXsCap)
+            {
+                if (lane == 0)
+                    sh[3] = 1;
+            }
+            else if (has)
+                L.xs[at + __popcll(hb & ((1ull << lane) - 1ull))] = x;
+        }
+    }
+    __syncthreads();
+    if (sh[3])
+        return nan_code(kNanSlabs);
+    int nx = sh[2];
+    // bitonic sort of the boundaries over the workgroup
+    {
+        int np = 64;
+        while (np < nx)
+            np <<= 1;
+        for (int i = nx + tid; i < np; i += NT)
+            L.xs[i] = __builtin_inf();
+        __syncthreads();
+        for (int size = 2; size <= np; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1)
+            {
+                for (int t = tid; t < np / 2; t += NT)
+                {
+                    const int lo = (t / stride) * (2 * stride) + (t % stride), hi = lo + stride;
+                    const bool up = ((lo / size) & 1) == 0;
+                    const double a = L.xs[lo], b = L.xs[hi];
+                    if ((b < a) == up && a != b)
+                    {
+                        L.xs[lo] = b;
+                        L.xs[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    // std::unique (wave 0, in order)
+    if (wave == 0)
+    {
+        int n = 0;
+        for (int base = 0; base < nx; base += 64)
+        {
+            const int i = base + lane;
+            double v = 0.0;
+            bool keep = false;
+            if (i < nx)
+            {
+                v = L.xs[i];
+                keep = i == 0 || !(L.xs[i - 1] == v);
+            }
+            const unsigned long long kb = __ballot(keep);
+            CAPE_MP_SYNC();
+            if (keep)
+                L.xs[n + __popcll(kb & ((1ull << lane) - 1ull))] = v;
+            n += __popcll(kb);
+            CAPE_MP_SYNC();
+        }
+        if (lane == 0)
+            sh[2] = n;
+    }
+    __syncthreads();
+    nx = sh[2];
+    const int R = L.ringCap;
+    for (int k = tid; k < 2 * R; k += NT)
+    {
+        const bool isB = k >= R;
+        const int kk = isB ? k - R : k;
+        int lo = 0, hi = 0;
+        if (kk < (isB ? neb : nea))
+        {
+            const Edge e = isB ? L.eb[kk] : L.ea[kk];
+            lo = boundary_index(L.xs, nx, e.a.x);
+            hi = boundary_index(L.xs, nx, e.b.x);
+        }
+        L.elo[k] = lo;
+        L.ehi[k] = hi;
+    }
+    __syncthreads();
+    double area = 0.0; // (wave 0's)
+    for (int base = 0; base + 1 < nx; base += 64)
+    {
+        const int top = (base + 64 < nx - 1) ? base + 64 : nx - 1; // slabs [base, top)
+        if (wave == 0)
+        {
+            int carry = 0;
+            for (int kb = 0; kb < 2 * R; kb += 64)
+            {
+                const int k = kb + lane;
+                int c = 0;
+                if (k < 2 * R)
+                {
+                    const int lo = L.elo[k] > base ? L.elo[k] : base, hi = L.ehi[k] < top ? L.ehi[k] : top;
+                    c = hi > lo ? hi - lo : 0;
+                }
+                const int incl = wave_scan_i32(c);
+                if (k < 2 * R)
+                    L.pre[k] = carry + incl - c;
+                carry += __builtin_amdgcn_readlane(incl, 63);
+            }
+            if (lane == 0)
+            {
+                L.pre[2 * R] = carry;
+                sh[4] = carry;
+                sh[5] = 0; // a bucket overflowed
+                sh[6] = 0; // more terms than a slab holds
+            }
+        }
+        for (int q = tid; q < 128; q += NT)
+            L.cnt[q] = 0;
+        __syncthreads();
+        const int total = sh[4];
+        if (total > 2 * 64 * kStackCap)
+            return nan_code(kNanStack); // (some bucket must overflow)
+        bool over = false;
+        for (int t = tid; t < total; t += NT)
+        {
+            int lo = 0, hi = 2 * R;
+            while (hi - lo > 1)
+            {
+                const int mid = (lo + hi) >> 1;
+                if (L.pre[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int k = lo;
+            const bool isB = k >= R;
+            const int kk = isB ? k - R : k;
+            const int first = L.elo[k] > base ? L.elo[k] : base;
+            const int sl = first + (t - L.pre[k]) - base;
+            const Edge e = isB ? L.eb[kk] : L.ea[kk];
+            const double x0 = L.xs[base + sl], x1 = L.xs[base + sl + 1], xm = 0.5 * (x0 + x1);
+            const double y = y_at(e, xm);
+            const int bucket = (isB ? 64 : 0) + sl;
+            const int pos = atomicAdd(&L.cnt[bucket], 1);
+            if (pos < kStackCap)
+            {
+                L.by[bucket * kStackCap + pos] = y;
+                L.bk[bucket * kStackCap + pos] = (unsigned short)kk;
+                L.inc[t] = (unsigned short)((bucket << 8) | pos);
+            }
+            else
+                over = true;
+        }
+        if (over)
+            sh[5] = 1;
+        __syncthreads();
+        if (sh[5])
+            return nan_code(kNanStack);
+        for (int t = tid; t < total; t += NT)
+        {
+            const int bucket = L.inc[t] >> 8, pos = L.inc[t] & 255;
+            const double y = L.by[bucket * kStackCap + pos];
+            const int kk = L.bk[bucket * kStackCap + pos];
+            const int c = L.cnt[bucket];
+            int rank = 0;
+            for (int m = 0; m < c; ++m)
+            {
+                const double y2 = L.by[bucket * kStackCap + m];
+                const int k2 = L.bk[bucket * kStackCap + m];
+                rank += (y2 < y || (y2 == y && k2 < kk)) ? 1 : 0;
+            }
+            L.sidx[bucket * kStackCap + rank] = (unsigned char)pos;
+        }
+        __syncthreads();
+        if (wave == 0)
+        {
+            const int s = base + lane;
+            int myTerms = 0;
+            if (s < top)
+            {
+                const double x0 = L.xs[s], x1 = L.xs[s + 1];
+                const int ca = L.cnt[lane], cb = L.cnt[64 + lane];
+                const int oa = lane * kStackCap, ob = (64 + lane) * kStackCap;
+                for (int i = 0; i + 1 < ca; i += 2)
+                {
+                    const int pa0 = L.sidx[oa + i], pa1 = L.sidx[oa + i + 1];
+                    const double ya0 = L.by[oa + pa0], ya1 = L.by[oa + pa1];
+                    for (int j = 0; j + 1 < cb; j += 2)
+                    {
+                        const int pb0 = L.sidx[ob + j], pb1 = L.sidx[ob + j + 1];
+                        const double yb0 = L.by[ob + pb0], yb1 = L.by[ob + pb1];
+                        const bool loA = ya0 > yb0;
+                        const double loY = loA ? ya0 : yb0;
+                        const bool hiA = ya1 < yb1;
+                        const double hiY = hiA ? ya1 : yb1;
+                        if (!(hiY <= loY))
+                        {
+                            const Edge lo = loA ? L.ea[L.bk[oa + pa0]] : L.eb[L.bk[ob + pb0]];
+                            const Edge hi = hiA ? L.ea[L.bk[oa + pa1]] : L.eb[L.bk[ob + pb1]];
+                            const double h0 = y_at(hi, x0) - y_at(lo, x0);
+                            const double h1 = y_at(hi, x1) - y_at(lo, x1);
+                            if (myTerms < kTermsPerSlab)
+                                L.terms[lane * kTermsPerSlab + myTerms] = 0.5 * (h0 + h1) * (x1 - x0);
+                            ++myTerms;
+                        }
+                    }
+                }
+            }
+            CAPE_MP_SYNC();
+            if (__any(myTerms > kTermsPerSlab))
+            {
+                if (lane == 0)
+                    sh[6] = 1;
+            }
+            else
+            {
+                const double t0 = myTerms > 0 ? L.terms[lane * kTermsPerSlab] : 0.0, t1 = myTerms > 1 ? L.terms[lane * kTermsPerSlab + 1] : 0.0;
+                const int slabs = top - base;
+                for (int l = 0; l < slabs; ++l)
+                {
+                    const int c = __builtin_amdgcn_readlane(myTerms, l);
+                    if (c > 0)
+                        area += readlane_f64(t0, l);
+                    if (c > 1)
+                        area += readlane_f64(t1, l);
+                    for (int t = 2; t < c; ++t)
+                        area += L.terms[l * kTermsPerSlab + t];
+                }
+            }
+        }
+        __syncthreads();
+        if (sh[6])
+            return nan_code(kNanStack); // (cannot happen with simple rings)
+    }
+    return area;
+}
+
 // the kept planes of a frame (output plane whose polygon Primitive_Detection keeps), in segment order: lane k < count holds
 // the segment index of plane k
 // hostOnly: some output plane of the frame has no device polygon (CAPE_POLY_OVERFLOW: its outline is left to the host class,
@@ -593,7 +897,11 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
     constexpr bool kHasNext = TIER + 1 < kTiers;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char* smem = smem_all + (size_t)wave * ldsPerWave;
+    constexpr bool kCoop = T::kCoop;
+    // cooperative tiers: ONE carve for the workgroup's four waves, `tid` strides of 256; else a carve per (independent) wave
+    const int tid = kCoop ? (int)threadIdx.x : lane;
+    constexpr int kStride = kCoop ? 256 : 64;
+    unsigned char* smem = smem_all + (kCoop ? (size_t)0 : (size_t)wave * ldsPerWave);
     MpLds L;
     L.ringCap = T::kRing;
     L.ringA = reinterpret_cast<double2*>(smem);
@@ -610,6 +918,7 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
     L.bk = reinterpret_cast<unsigned short*>(L.cnt + 128);
     L.inc = L.bk + 128 * T::kStack;
     L.sidx = reinterpret_cast<unsigned char*>(L.inc + 128 * T::kStack);
+    L.sh = reinterpret_cast<int*>(smem + ldsPerWave - 32); // the carve's last 32 bytes (tier_lds_bytes)
     const unsigned* list = p.pairLists + (size_t)TIER * p.pairCapacity;
     const unsigned count = p.listCounts[TIER];
     // The tiers behind the first hold few pairs of very unequal cost (an outline of 70 vertices over 145 slabs keeps a lone wave busy
@@ -625,12 +934,29 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
     constexpr bool kTickets = ((CAPE_MP_TICKETS >> TIER) & 1) != 0;
     constexpr bool kReverse = ((CAPE_MP_REVERSE >> TIER) & 1) != 0;
     auto next_index = [&](unsigned prev, bool first) -> unsigned {
+        if (kCoop)
+        {
+            // one pair per WORKGROUP: thread 0 draws (or strides), everybody reads the number
+            if (threadIdx.x == 0)
+                L.sh[7] = (int)(kTickets ? atomicAdd(&p.listCounts[4 + TIER], 1u) : (first ? blockIdx.x : prev + gridDim.x));
+            __syncthreads();
+            const unsigned t = (unsigned)L.sh[7];
+            __syncthreads(); // (everybody has read it before thread 0 may write the next one)
+            return t;
+        }
         if (!kTickets)
             return first ? blockIdx.x * T::kWavesPerGroup + wave : prev + gridDim.x * T::kWavesPerGroup;
         unsigned t = 0;
         if (lane == 0)
             t = atomicAdd(&p.listCounts[4 + TIER], 1u);
         return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    // ordering point between the lanes that share a carve: the wave (fence + wait) or the workgroup (barrier)
+    auto sync = [&]() {
+        if (kCoop)
+            __syncthreads();
+        else
+            CAPE_MP_SYNC();
     };
     for (unsigned t = next_index(0u, true); t < count; t = next_index(t, false))
     {
@@ -651,7 +977,7 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
         {
             const double2* vertsC = p.vertices + (size_t)frame * p.boundaryCapacity + PS.vertex_offset;
             const double2* vertsP = p.vertices + (size_t)(frame - 1) * p.boundaryCapacity + PQ.vertex_offset;
-            for (int v = lane; v < na; v += 64)
+            for (int v = tid; v < na; v += kStride)
                 L.ringA[v] = vertsC[v];
             // Polygon::project (polygon.cpp:338-382): every vertex of the previous plane's ring lifted to 3-D and expressed in
             // the frame of plane i; the projected ring is re-oriented clockwise like every polygon (OpenRing constructor)
@@ -677,7 +1003,7 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                     ny[0] /= ly, ny[1] /= ly, ny[2] /= ly;
                 // transform_boundary (polygon.cpp:430-451): every vertex lifted to 3-D, moved, re-expressed in the new frame; then the
                 // explicit-ring constructor's orientation fix (polygon.cpp:236-266)
-                for (int v = lane; v < nb; v += 64)
+                for (int v = tid; v < nb; v += kStride)
                 {
                     const double2 q = vertsP[v];
                     const double X = qc[0] + q.x * qx[0] + q.y * qy[0], Y = qc[1] + q.x * qx[1] + q.y * qy[1], Z = qc[2] + q.x * qx[2] + q.y * qy[2];
@@ -686,22 +1012,22 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                     const double dx = mx - nc[0], dy = my - nc[1], dz = mz - nc[2];
                     L.ringB[v] = make_double2((nx[0] * dx + nx[1] * dy) + nx[2] * dz, (ny[0] * dx + ny[1] * dy) + ny[2] * dz);
                 }
-                CAPE_MP_SYNC();
+                sync();
                 if (ring_area_signed(L.ringB, nb) > 0)
                 {
-                    for (int v = lane; v < nb / 2; v += 64)
+                    for (int v = tid; v < nb / 2; v += kStride)
                     {
                         const double2 a = L.ringB[v], b = L.ringB[nb - 1 - v];
                         L.ringB[v] = b;
                         L.ringB[nb - 1 - v] = a;
                     }
-                    CAPE_MP_SYNC();
+                    sync();
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
                     qc[r] = nc[r], qx[r] = nx[r], qy[r] = ny[r];
             }
-            for (int v = lane; v < nb; v += 64)
+            for (int v = tid; v < nb; v += kStride)
             {
                 const double2 q = p.poses ? L.ringB[v] : vertsP[v];
                 const double X = qc[0] + q.x * qx[0] + q.y * qy[0];
@@ -711,23 +1037,26 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                 L.ringB[v] = make_double2((PS.x_axis[0] * dx + PS.x_axis[1] * dy) + PS.x_axis[2] * dz,
                                           (PS.y_axis[0] * dx + PS.y_axis[1] * dy) + PS.y_axis[2] * dz);
             }
-            CAPE_MP_SYNC();
+            sync();
             if (ring_area_signed(L.ringB, nb) > 0)
             {
                 // reverse in place: lane v swaps v and nb - 1 - v
-                for (int v = lane; v < nb / 2; v += 64)
+                for (int v = tid; v < nb / 2; v += kStride)
                 {
                     const double2 a = L.ringB[v], b = L.ringB[nb - 1 - v];
                     L.ringB[v] = b;
                     L.ringB[nb - 1 - v] = a;
                 }
-                CAPE_MP_SYNC();
+                sync();
             }
 #ifdef CAPE_MP_PROFILE
             unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const unsigned long long tStart = __builtin_amdgcn_s_memtime();
-            result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane, prof);
-            if (lane == 0 && i < 8 && j < 8)
+            if constexpr (kCoop)
+                result = rings_inter_area_coop<T::kStack, T::kXs>(L, na, nb, tid);
+            else
+                result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane, prof);
+            if (!kCoop && lane == 0 && i < 8 && j < 8)
             {
                 // unused slots of the area matrix carry the ticks of this pair (profiles/match_polygons_bench.py decodes them)
                 out.inter_area[j + 8][i + 8] = (double)((prof[3] - tStart) >> 4) + 1e6 * na + 1e9 * nb + 1e12 * (double)prof[5];
@@ -735,11 +1064,14 @@ __global__ __launch_bounds__(64 * Tier<TIER>::kWavesPerGroup) void cape_polygon_
                 out.inter_area[j][i + 8] = (double)((prof[3] - prof[2]) >> 4) + 1e6 * (double)prof[6] + 1e12 * TIER;
             }
 #else
-            result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane);
+            if constexpr (kCoop)
+                result = rings_inter_area_coop<T::kStack, T::kXs>(L, na, nb, tid);
+            else
+                result = rings_inter_area<T::kStack, T::kXs>(L, na, nb, lane);
 #endif
-            CAPE_MP_SYNC();
+            sync();
         }
-        if (lane == 0)
+        if (tid == 0)
         {
             bool again = false;
             if (kHasNext)
@@ -821,13 +1153,15 @@ template <int TIER> static size_t tier_lds_bytes()
     using T = Tier<TIER>;
     const size_t b = (size_t)2 * T::kRing * sizeof(double2) + (size_t)2 * T::kRing * sizeof(Edge) + (size_t)T::kXs * 8 +
                      (size_t)64 * T::kStack * 8 + (size_t)128 * T::kStack * (8 + 2 + 2 + 1) + (size_t)(6 * T::kRing + 2 + 128) * 4;
-    return (b + 15) & ~(size_t)15;
+    return ((b + 15) & ~(size_t)15) + 32; // + MpLds::sh
 }
 
 template <int TIER> static hipError_t launch_tier(const MatchPolygonParams& p, int blocks, hipStream_t stream)
 {
     const int lds = (int)tier_lds_bytes<TIER>();
-    hipLaunchKernelGGL(cape_polygon_inter_kernel<TIER>, dim3(blocks), dim3(64 * Tier<TIER>::kWavesPerGroup), (size_t)lds * Tier<TIER>::kWavesPerGroup, stream, p, lds);
+    // (a cooperative tier's four waves share ONE carve)
+    hipLaunchKernelGGL(cape_polygon_inter_kernel<TIER>, dim3(blocks), dim3(64 * Tier<TIER>::kWavesPerGroup),
+                       (size_t)lds * (Tier<TIER>::kCoop ? 1 : Tier<TIER>::kWavesPerGroup), stream, p, lds);
     return hipGetLastError();
 }
 
@@ -841,18 +1175,18 @@ hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipSt
     // persistent grids: as many workgroups as the chip holds at once
     const int cus = p.computeUnits > 0 ? p.computeUnits : 256;
     const int maxPairs = nFrames * MP * MP;
-    auto blocks_for = [&](int perCu, int wavesPerGroup) {
-        const int need = (maxPairs + wavesPerGroup - 1) / wavesPerGroup;
+    auto blocks_for = [&](int perCu, int pairsPerGroup) { // pairs a workgroup works on at a time: its waves, or one (cooperative tiers)
+        const int need = (maxPairs + pairsPerGroup - 1) / pairsPerGroup;
         return need < cus * perCu ? need : cus * perCu;
     };
     if (const hipError_t e = launch_tier<0>(p, blocks_for(Tier<0>::kGroupsPerCu, Tier<0>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
-    if (const hipError_t e = launch_tier<1>(p, blocks_for(Tier<1>::kGroupsPerCu, Tier<1>::kWavesPerGroup), stream); e != hipSuccess)
+    if (const hipError_t e = launch_tier<1>(p, blocks_for(Tier<1>::kGroupsPerCu, Tier<1>::kCoop ? 1 : Tier<1>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
-    if (const hipError_t e = launch_tier<2>(p, blocks_for(Tier<2>::kGroupsPerCu, Tier<2>::kWavesPerGroup), stream); e != hipSuccess)
+    if (const hipError_t e = launch_tier<2>(p, blocks_for(Tier<2>::kGroupsPerCu, Tier<2>::kCoop ? 1 : Tier<2>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
     if (p.boundaryCapacity > Tier<2>::kRing && tier_lds_bytes<3>() <= (size_t)p.ldsLimitBytes) // (a ring is a subset of its plane's candidates)
-        if (const hipError_t e = launch_tier<3>(p, blocks_for(Tier<3>::kGroupsPerCu, Tier<3>::kWavesPerGroup), stream); e != hipSuccess)
+        if (const hipError_t e = launch_tier<3>(p, blocks_for(Tier<3>::kGroupsPerCu, Tier<3>::kCoop ? 1 : Tier<3>::kWavesPerGroup), stream); e != hipSuccess)
             return e;
     hipLaunchKernelGGL(cape_polygon_select_kernel, dim3((nFrames + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, stream, p, nFrames);
     return hipGetLastError();
