@@ -53,10 +53,13 @@ template <int TIER> struct Tier;
 #ifndef CAPE_MP_COOP
 #define CAPE_MP_COOP 1
 #endif
+#ifndef CAPE_MP_COOP0
+#define CAPE_MP_COOP0 0 // the first tier cooperative as well (A/B builds: -DCAPE_MP_COOP0=1 -DCAPE_MP_T0_GROUPS=8)
+#endif
 template <> struct Tier<0>
 {
-    static constexpr int kRing = 32, kXs = CAPE_MP_T0_XS, kStack = CAPE_MP_T0_STACK, kWavesPerGroup = 2, kGroupsPerCu = CAPE_MP_T0_GROUPS;
-    static constexpr bool kCoop = false;
+    static constexpr bool kCoop = CAPE_MP_COOP0 != 0;
+    static constexpr int kRing = 32, kXs = CAPE_MP_T0_XS, kStack = CAPE_MP_T0_STACK, kWavesPerGroup = kCoop ? 4 : 2, kGroupsPerCu = CAPE_MP_T0_GROUPS;
 };
 template <> struct Tier<1>
 {
@@ -1179,7 +1182,7 @@ hipError_t launch_match_polygons(const MatchPolygonParams& p, int nFrames, hipSt
         const int need = (maxPairs + pairsPerGroup - 1) / pairsPerGroup;
         return need < cus * perCu ? need : cus * perCu;
     };
-    if (const hipError_t e = launch_tier<0>(p, blocks_for(Tier<0>::kGroupsPerCu, Tier<0>::kWavesPerGroup), stream); e != hipSuccess)
+    if (const hipError_t e = launch_tier<0>(p, blocks_for(Tier<0>::kGroupsPerCu, Tier<0>::kCoop ? 1 : Tier<0>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
     if (const hipError_t e = launch_tier<1>(p, blocks_for(Tier<1>::kGroupsPerCu, Tier<1>::kCoop ? 1 : Tier<1>::kWavesPerGroup), stream); e != hipSuccess)
         return e;
