@@ -949,8 +949,8 @@ def main():
         out["find_primitives_equivalent"] = fpe
     if (rank == 0 and world == 1 and not multi and out is not None and not args.no_wide_grid and not args.cylinders and not args.u16
             and not args.match and scene == "room" and (W, H) == (640, 480)):
-        # Round 6: what lies beyond the fast kernels' fixed shapes, in the driver-visible line.  (a) 1920 x 1080 (96 x 54 cells: every
-        # frame through the general grow instance), frames resident in HBM, every frame of the step checked against the oracle;
+        # Round 6: what lay beyond the fast kernels' fixed shapes through round 5, in the driver-visible line.  (a) 1920 x 1080 (96 x 54
+        # cells: rows of two mask words in the fast kernels), frames resident in HBM, every frame of the step checked against the oracle;
         # (b) a frame of more than 64 plane segments (a checkerboard of tilted facets) inside an ordinary 1280 x 960 batch: its record
         # chain against the oracle.  Not part of `value`.
         Ww, Hw, nw = 1920, 1080, 256
@@ -969,8 +969,9 @@ def main():
         msw = e0.elapsed_time(e1) / 5
         wide = {"grid": f"{Ww}x{Hw} ({Ww // 20} x {Hw // 20} cells)", "frames": nw, "ms_per_batch": msw, "frames_per_s": nw / (msw * 1e-3),
                 "general_instance_frames": exw.spill_info()[2], "cylinders": True,
-                "note": "the reference takes any image size (primitive_detection.cpp:26-67); grids beyond 64 x 64 cells run in "
-                        "cape_grow_general_kernel (bit rows in memory, 16-bit labels), stage A unchanged"}
+                "note": "the reference takes any image size (primitive_detection.cpp:26-67); rows of 65 .. 128 cells run in the fast grow "
+                        "kernels on two mask words per lane (Mask128), grids of more than 64 rows or 128 columns in cape_grow_general_kernel "
+                        "(bit rows in memory, 16-bit labels); stage A unchanged"}
         if not args.no_parity_check:
             wide["parity_check"] = parity_check(exw, lambda a, c: dw[a:a + c].cpu().numpy(), intr_w, True, nw)
             if not parity_ok(wide["parity_check"]):

@@ -1,4 +1,4 @@
-"""Throughput of the general grow instance (csrc/cape_grow_general.hip): frames resident in HBM, HIP-event timings of stage A and
+"""Throughput of the grow instances beyond the 64-cell row: the two-word fast kernels (Mask128) and the general grow instance (csrc/cape_grow_general.hip): frames resident in HBM, HIP-event timings of stage A and
 stage B per call, (a) on the 640x480 / 1280x960 grids where CAPE_GROW=general can be compared with the fast kernels on the same
 frames, (b) on grids only it serves (1920x1080, 1080x1920, 2560x1440).   python profiles/general_instance_rate.py [out.txt]"""
 import os
@@ -52,7 +52,7 @@ def main():
                 rows.append((W, H, n, scene, cyl, True, run(W, H, n, scene, cyl, False)))
     print(f"{'grid':>11} {'frames':>6} {'scene':>7} {'cyl':>4} {'instance':>9} {'ms/call':>9} {'frames/s':>11} {'stage A ms':>10} {'stage B ms':>10}", file=out)
     for W, H, n, scene, cyl, general, r in rows:
-        print(f"{W:>6}x{H:<4} {n:>6} {scene:>7} {str(cyl):>4} {'general' if general else 'fast':>9} {r['ms']:>9.3f} {r['fps']:>11.0f} "
+        print(f"{W:>6}x{H:<4} {n:>6} {scene:>7} {str(cyl):>4} {('general' if r['general_frames'] else ('fast-128' if W > 1280 else 'fast')):>9} {r['ms']:>9.3f} {r['fps']:>11.0f} "
               f"{r['a_ms']:>10.3f} {r['b_ms']:>10.3f}", file=out)
 
 

@@ -914,7 +914,7 @@ int cape_create(const cape_config* cfg, cape_handle* out)
     h->cells = h->hCells * h->vCells;
     h->boundaryCap = cfg->boundary_capacity > 0 ? cfg->boundary_capacity : 2 * h->cells;
     const size_t B = (size_t)cfg->max_batch, C = (size_t)h->cells;
-    h->generalAll = h->hCells > 64 || h->vCells > 64; // beyond "one lane per grid row, one mask word per row"
+    h->generalAll = h->hCells > 128 || h->vCells > 64; // beyond "one lane per grid row, two mask words per row"
     if (const char* e = std::getenv("CAPE_GROW")) // debug knob: "general" sends every frame through the general instance
     {
         if (std::string(e) == "general")

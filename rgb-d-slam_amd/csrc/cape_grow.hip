@@ -142,6 +142,74 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
     if constexpr (!RESUME)
     {
         int nPlanarLocal = 0;
+        if constexpr (sizeof(MaskT) == 16)
+        {
+            // rows of up to 128 cells (two mask words): two ballots per grid row, six rows requested together
+            constexpr int kAheadW = 6;
+            for (int t0 = 0; t0 < VC; t0 += kAheadW)
+            {
+                uint32_t fl[kAheadW][2];
+                int bn[kAheadW][2];
+#pragma unroll
+                for (int k = 0; k < kAheadW; ++k)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w)
+                    {
+                        const int r = t0 + k < VC ? t0 + k : VC - 1, c = 64 * w + lane;
+                        const int ci = r * HC + (c < HC ? c : 0); // clamped: unconditional loads
+                        fl[k][w] = p.cell_flags[cellBase + ci];
+                        bn[k][w] = p.cell_bins[cellBase + ci];
+                    }
+#pragma unroll
+                for (int k = 0; k < kAheadW; ++k)
+                {
+                    const int t = t0 + k;
+                    if (t < VC)
+                    {
+                        unsigned long long bU[2], bL2M[2], bM2L[2], bU2M[2], bM2U[2];
+#pragma unroll
+                        for (int w = 0; w < 2; ++w)
+                        {
+                            const int c = 64 * w + lane;
+                            const bool in = c < HC;
+                            const uint32_t f = in ? fl[k][w] : 0u;
+                            if (in)
+                            {
+                                const int ci = t * HC + c;
+                                s_lab[ci] = 0;
+                                if (CYL)
+                                    s_cyl[ci] = 0;
+                                s_bins[ci] = (short)bn[k][w];
+                                if (f & kFlagPlanar)
+                                {
+                                    atomicAdd(&s_hist[bn[k][w]], 1);
+                                    ++nPlanarLocal;
+                                }
+                            }
+                            if (f & kFlagNearEdge)
+                                status |= CAPE_FRAME_BIN_NEAR_EDGE;
+                            if (f & kFlagInorder)
+                                status |= CAPE_FRAME_INORDER_CELLS;
+                            bU[w] = __ballot((f & kFlagPlanar) != 0);
+                            bL2M[w] = __ballot((f & kFlagLeftToMe) != 0);
+                            bM2L[w] = __ballot((f & kFlagMeToLeft) != 0);
+                            bU2M[w] = __ballot((f & kFlagUpToMe) != 0);
+                            bM2U[w] = __ballot((f & kFlagMeToUp) != 0);
+                        }
+                        if (lane == t)
+                        {
+                            U = MaskT(bU[0], bU[1]);
+                            EL = MaskT(bL2M[0], bL2M[1]);
+                            ER = MaskT(bM2L[0], bM2L[1]) >> 1;
+                            EU = MaskT(bU2M[0], bU2M[1]);
+                        }
+                        if (lane == t - 1)
+                            ED = MaskT(bM2U[0], bM2U[1]);
+                    }
+                }
+            }
+        }
+        else
         {
             constexpr bool kTwoRows = sizeof(MaskT) == 4;
             const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
@@ -230,6 +298,44 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
         }
         // the vertical edges between the first cell row of a stage-A2 tile and the row above it (rows k * a2RowsPerTile):
         // both rows' planes are read back and the predicate is evaluated here, exactly as stage A2 does inside a tile
+        if constexpr (sizeof(MaskT) == 16)
+        {
+            const int RPT = p.a2RowsPerTile;
+            const int nB = (VC - 1) / RPT;
+            for (int k = 1; k <= nB; ++k)
+            {
+                const int r = k * RPT;
+                unsigned long long bU2M[2], bM2U[2];
+                double2 m0[2], m1[2], m2[2], m3[2], u0[2], u1[2], u2[2], u3[2];
+                float mt[2], ut[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w)
+                {
+                    const int c = 64 * w + lane;
+                    const size_t ciMe = cellBase + (size_t)r * HC + (c < HC ? c : 0), ciUp = ciMe - HC;
+                    const double2* pm = reinterpret_cast<const double2*>(p.cell_plane + ciMe * kPlaneStride);
+                    const double2* pu = reinterpret_cast<const double2*>(p.cell_plane + ciUp * kPlaneStride);
+                    m0[w] = pm[0]; m1[w] = pm[1]; m2[w] = pm[2]; m3[w] = pm[3];
+                    u0[w] = pu[0]; u1[w] = pu[1]; u2[w] = pu[2]; u3[w] = pu[3];
+                    mt[w] = p.cell_tol[ciMe];
+                    ut[w] = p.cell_tol[ciUp];
+                }
+#pragma unroll
+                for (int w = 0; w < 2; ++w)
+                {
+                    const bool on = 64 * w + lane < HC;
+                    const bool u2m = on & can_be_merged(u0[w].x, u0[w].y, u1[w].x, u1[w].y, m0[w].x, m0[w].y, m1[w].x, m2[w].x, m2[w].y, m3[w].x, (double)mt[w], p.cosMerge);
+                    const bool m2u = on & can_be_merged(m0[w].x, m0[w].y, m1[w].x, m1[w].y, u0[w].x, u0[w].y, u1[w].x, u2[w].x, u2[w].y, u3[w].x, (double)ut[w], p.cosMerge);
+                    bU2M[w] = __ballot(u2m);
+                    bM2U[w] = __ballot(m2u);
+                }
+                if (lane == r)
+                    EU = MaskT(bU2M[0], bU2M[1]);
+                if (lane == r - 1)
+                    ED = MaskT(bM2U[0], bM2U[1]);
+            }
+        }
+        else
         {
             constexpr bool kTwoRows = sizeof(MaskT) == 4;
             const int h = kTwoRows ? (lane >> 5) : 0, col = kTwoRows ? (lane & 31) : lane;
@@ -462,7 +568,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                 const double2 sp0 = spl[0], sp1 = spl[1], sp2 = spl[2], sp3 = spl[3];
                 const float stolf = p.cell_tol[cellBase + seed];
                 const MaskT seedRowU = shfl_mask<MaskT>(U, sy);
-                const bool seedUnassigned = (seedRowU >> sx) & (MaskT)1;
+                const bool seedUnassigned = test_bit<MaskT>(seedRowU, sx);
 
                 CAPE_TICK(3); // seed pick
                 // ---- region_growing (:778-818) as label propagation on bit rows
@@ -514,7 +620,7 @@ __device__ __forceinline__ void grow_frame_wave(const StageBParams& p, int nFram
                     {
                         const int c = ctz<MaskT>(m);
                         rlist[pos++] = (unsigned short)(lane * HC + c);
-                        m &= m - 1;
+                        m = clear_lowest<MaskT>(m);
                     }
                 }
                 CAPE_WAVE_SYNC();
@@ -883,7 +989,10 @@ int grow_waves_per_cu(const StageBParams& p)
         --wpg;
     int blocks = 0;
     hipError_t e;
-    if (p.hCells <= 32)
+    if (p.hCells > 64)
+        e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<Mask128, true, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<Mask128, false, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
+    else if (p.hCells <= 32)
         e = cyl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, true, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cape_grow_kernel<uint32_t, false, kFastPlanes, false>, 64 * wpg, (size_t)ldsPerWave * wpg);
     else
@@ -911,8 +1020,10 @@ hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t s
     const dim3 grid((nFrames + wpg - 1) / wpg), block(64 * wpg);
     if (p.hCells <= 32)
         hipLaunchKernelGGL((cape_grow_kernel<uint32_t, CYL, MAXP, RESUME>), grid, block, lds, stream, p, nFrames, ldsPerWave);
-    else
+    else if (p.hCells <= 64)
         hipLaunchKernelGGL((cape_grow_kernel<unsigned long long, CYL, MAXP, RESUME>), grid, block, lds, stream, p, nFrames, ldsPerWave);
+    else // rows of up to 128 cells: two mask words per lane (1920 x 1080 = 96 x 54 cells)
+        hipLaunchKernelGGL((cape_grow_kernel<Mask128, CYL, MAXP, RESUME>), grid, block, lds, stream, p, nFrames, ldsPerWave);
     return hipGetLastError();
 }
 

@@ -93,10 +93,27 @@ template <typename MaskT> __device__ __forceinline__ int ctz(MaskT m);
 template <> __device__ __forceinline__ int ctz<uint32_t>(uint32_t m) { return __ffs(m) - 1; }
 template <> __device__ __forceinline__ int ctz<unsigned long long>(unsigned long long m) { return __ffsll(m) - 1; }
 
+template <> __device__ __forceinline__ int popc<Mask128>(Mask128 m) { return __popcll(m.lo) + __popcll(m.hi); }
+template <> __device__ __forceinline__ int ctz<Mask128>(Mask128 m) { return m.lo ? __ffsll(m.lo) - 1 : 64 + __ffsll(m.hi) - 1; }
+
 template <typename MaskT> __device__ __forceinline__ MaskT shfl_mask(MaskT v, int src)
 {
     return (MaskT)__shfl((unsigned long long)v, src);
 }
+template <> __device__ __forceinline__ Mask128 shfl_mask<Mask128>(Mask128 v, int src) { return Mask128(__shfl(v.lo, src), __shfl(v.hi, src)); }
+// the mask without its lowest set bit; bit c of a mask; the first HC cells of a row
+template <typename MaskT> __device__ __forceinline__ MaskT clear_lowest(MaskT m) { return m & (MaskT)(m - 1); }
+template <> __device__ __forceinline__ Mask128 clear_lowest<Mask128>(Mask128 m) { return m.lo ? Mask128(m.lo & (m.lo - 1ull), m.hi) : Mask128(0ull, m.hi & (m.hi - 1ull)); }
+template <typename MaskT> __device__ __forceinline__ bool test_bit(MaskT m, int c) { return ((m >> c) & (MaskT)1) != (MaskT)0; }
+template <typename MaskT> __device__ __forceinline__ MaskT width_mask(int hc)
+{
+    return (hc >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (MaskT)(((MaskT)1 << hc) - 1);
+}
+template <> __device__ __forceinline__ Mask128 width_mask<Mask128>(int hc)
+{
+    return hc >= 128 ? Mask128(~0ull, ~0ull) : (hc >= 64 ? Mask128(~0ull, hc == 64 ? 0ull : ((1ull << (hc - 64)) - 1ull)) : Mask128((1ull << hc) - 1ull, 0ull));
+}
+constexpr bool kIsWide(size_t maskBytes) { return maskBytes == 16; }
 
 // 3x3 morphology on bit rows.  up/dn are the neighbouring rows (0 outside the grid).
 template <typename MaskT> __device__ __forceinline__ MaskT row3(MaskT x, MaskT widthMask) { return (x | (x << 1) | (x >> 1)) & widthMask; }
@@ -247,7 +264,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
 #endif
     const int C = p.cells, HC = p.hCells, VC = p.vCells;
     const size_t cellBase = (size_t)frame * C;
-    const MaskT widthMask = (HC >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << HC) - 1);
+    const MaskT widthMask = width_mask<MaskT>(HC);
     CAPE_TICK_INIT();
     // =========================================================================================
     // merge_planes (:503-560) with get_connected_components_matrix (:736-776)
@@ -351,7 +368,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
     // within 3 sigma of the plane, in row-major order.  The ring cells are enumerated with a prefix sum over the rows into a
     // cell list (the staging chunk is free here), so that 64 lanes test 64 ring cells at a time instead of one grid row at
     // a time; a band of rows that surely fits the list is handled per pass (the whole grid for 640x480).
-    constexpr int kBandRows = sizeof(MaskT) == 4 ? 32 : 16;                  // band rows x grid width <= 1024 entries
+    constexpr int kBandRows = sizeof(MaskT) == 4 ? 32 : (sizeof(MaskT) == 8 ? 16 : 8); // band rows x grid width <= 1024 entries
     for (int pi = 0; pi < nSeg; ++pi)
     {
         const int mlabel = s_mlab[pi];
@@ -377,6 +394,18 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
                         M = (MaskT)(uint32_t)bm;
                     if (lane == 2 * t + 1)
                         M = (MaskT)(uint32_t)(bm >> 32);
+                }
+            }
+            else if constexpr (sizeof(MaskT) == 16)
+            {
+                // rows of up to 128 cells: two ballots per row
+                for (int r = 0; r < VC; ++r)
+                {
+                    const int l0 = lane < HC ? (int)s_lab[r * HC + lane] : 0, l1 = 64 + lane < HC ? (int)s_lab[r * HC + 64 + lane] : 0;
+                    const unsigned long long b0 = __ballot(l0 > 0 && ((group >> (l0 - 1)) & 1ull));
+                    const unsigned long long b1 = __ballot(l1 > 0 && ((group >> (l1 - 1)) & 1ull));
+                    if (lane == r)
+                        M = MaskT(b0, b1);
                 }
             }
             else
@@ -413,7 +442,7 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
                     {
                         const int c = ctz<MaskT>(m);
                         s_ring[pos++] = (unsigned short)(lane * HC + c);
-                        m &= m - 1;
+                        m = clear_lowest<MaskT>(m);
                     }
                 }
                 CAPE_LDS_SYNC();
@@ -425,7 +454,8 @@ __device__ __forceinline__ void grow_tail(const StageBParams& p, const int frame
                     // every lane takes part in the two lane look-ups (a permute reads nothing from an inactive lane)
                     const int cell = s_ring[j < R ? j : R - 1];
                     const int r = cell / HC, c = cell - r * HC;
-                    const double ac = __shfl(acolCenterOfLane, c), br = __shfl(browCenterOfLane, r);
+                    // (column c's centre abscissa lives in lane c -- on the grids of up to 64 columns; a wider row reads it from memory)
+                    const double ac = sizeof(MaskT) == 16 ? p.acol[c * kCell + kCell / 2] : __shfl(acolCenterOfLane, c), br = __shfl(browCenterOfLane, r);
                     const double dpt = (double)s_zc[cell]; // depthImage(centerY, centerX), staged by stage A
                     if (j < R && dpt > 0)
                     {

@@ -1022,8 +1022,10 @@ hipError_t launch_resume_group(const StageBParams& p, int nFrames, hipStream_t s
         return hipErrorInvalidConfiguration;
     if (p.hCells <= 32)
         hipLaunchKernelGGL(cape_resume_group_kernel<uint32_t>, dim3(nFrames), dim3(kGroupThreads), lds, stream, p, (int)lds);
-    else
+    else if (p.hCells <= 64)
         hipLaunchKernelGGL(cape_resume_group_kernel<unsigned long long>, dim3(nFrames), dim3(kGroupThreads), lds, stream, p, (int)lds);
+    else
+        hipLaunchKernelGGL(cape_resume_group_kernel<Mask128>, dim3(nFrames), dim3(kGroupThreads), lds, stream, p, (int)lds);
     return hipGetLastError();
 }
 

@@ -176,11 +176,47 @@ __device__ __forceinline__ int wave_scan_i32(int vi)
     return v;
 }
 
+// A grid row of up to 128 cells as two 64-bit words (round 6: 1920 x 1080 = 96 x 54 cells in the fast grow kernels): the operators
+// the bit-row code uses on its 32- / 64-bit masks, with the carry between the words.
+struct Mask128
+{
+    unsigned long long lo, hi;
+    __device__ __forceinline__ Mask128() {}
+    __device__ __forceinline__ Mask128(unsigned long long l, unsigned long long h = 0ull) : lo(l), hi(h) {}
+    __device__ __forceinline__ Mask128 operator<<(int n) const
+    {
+        if (n == 0)
+            return *this;
+        if (n >= 64)
+            return Mask128(0ull, n >= 128 ? 0ull : lo << (n - 64));
+        return Mask128(lo << n, (hi << n) | (lo >> (64 - n)));
+    }
+    __device__ __forceinline__ Mask128 operator>>(int n) const
+    {
+        if (n == 0)
+            return *this;
+        if (n >= 64)
+            return Mask128(n >= 128 ? 0ull : hi >> (n - 64), 0ull);
+        return Mask128((lo >> n) | (hi << (64 - n)), hi >> n);
+    }
+    __device__ __forceinline__ Mask128 operator&(const Mask128& o) const { return Mask128(lo & o.lo, hi & o.hi); }
+    __device__ __forceinline__ Mask128 operator|(const Mask128& o) const { return Mask128(lo | o.lo, hi | o.hi); }
+    __device__ __forceinline__ Mask128 operator~() const { return Mask128(~lo, ~hi); }
+    __device__ __forceinline__ Mask128& operator&=(const Mask128& o) { lo &= o.lo; hi &= o.hi; return *this; }
+    __device__ __forceinline__ Mask128& operator|=(const Mask128& o) { lo |= o.lo; hi |= o.hi; return *this; }
+    __device__ __forceinline__ bool operator==(const Mask128& o) const { return lo == o.lo && hi == o.hi; }
+    __device__ __forceinline__ bool operator!=(const Mask128& o) const { return lo != o.lo || hi != o.hi; }
+    __device__ __forceinline__ explicit operator bool() const { return (lo | hi) != 0ull; }
+    __device__ __forceinline__ explicit operator int() const { return (int)lo; } // (ablation builds only)
+};
+
 // the value of the lane below / above (zero past the ends of the wave)
 __device__ __forceinline__ unsigned wave_from_lane_below(unsigned v) { return dpp_u32<kDppWaveShr1>(v); }       // lane i <- i - 1
 __device__ __forceinline__ unsigned wave_from_lane_above(unsigned v) { return dpp_u32<kDppWaveShl1>(v); }       // lane i <- i + 1
 __device__ __forceinline__ unsigned long long wave_from_lane_below(unsigned long long v) { return dpp_u64<kDppWaveShr1>(v); }
 __device__ __forceinline__ unsigned long long wave_from_lane_above(unsigned long long v) { return dpp_u64<kDppWaveShl1>(v); }
+__device__ __forceinline__ Mask128 wave_from_lane_below(const Mask128& v) { return Mask128(dpp_u64<kDppWaveShr1>(v.lo), dpp_u64<kDppWaveShr1>(v.hi)); }
+__device__ __forceinline__ Mask128 wave_from_lane_above(const Mask128& v) { return Mask128(dpp_u64<kDppWaveShl1>(v.lo), dpp_u64<kDppWaveShl1>(v.hi)); }
 __device__ __forceinline__ double wave_from_lane_below(double v)
 {
     return __longlong_as_double((long long)dpp_u64<kDppWaveShr1>((unsigned long long)__double_as_longlong(v)));

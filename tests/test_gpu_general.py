@@ -49,20 +49,26 @@ def test_general_instance_equals_the_oracle_on_the_fast_kernels_grids(oracle_mod
 
 
 @pytest.mark.parametrize("cyl", [False, True])
-@pytest.mark.parametrize("size", [(1920, 1080), (1080, 1920), (2560, 1440), (1300, 1300)])
-def test_grids_beyond_64_cells_equal_the_oracle(oracle_mod, size, cyl):
-    """1920 x 1080 (96 x 54 cells), its portrait twin (54 x 96), 2560 x 1440 (128 x 72) and 65 x 65 cells: a room / tunnel / desk mix,
-    every observable of compare_frame incl. the per-cell fits of stage A on these widths."""
+@pytest.mark.parametrize("size", [(1920, 1080, "wide"), (1920, 1080, "general"), (2560, 1280, "wide"), (1080, 1920, "general"), (2560, 1440, "general"),
+                                  (1300, 1300, "general")])
+def test_grids_beyond_64_cells_equal_the_oracle(oracle_mod, monkeypatch, size, cyl):
+    """1920 x 1080 (96 x 54 cells) and 2560 x 1280 (128 x 64): the fast kernels' two-word rows (Mask128) -- and 1920 x 1080 once more
+    through the general instance (CAPE_GROW=general); the portrait twin (54 x 96), 2560 x 1440 (128 x 72) and 65 x 65 cells: more rows
+    than a wave has lanes, the general instance.  A room / tunnel / desk mix, every observable of compare_frame incl. the per-cell fits
+    of stage A on these widths."""
     from cape_amd import Extractor
 
-    W, H = size
+    W, H, instance = size
     intr = _intr(W)
     frames = _mix(W, H, 6, intr)
     orc = oracle_mod.Oracle(W, H, cylinders=cyl, **intr)
+    if instance == "general":
+        monkeypatch.setenv("CAPE_GROW", "general")  # (read at cape_create; a no-op on the grids only that instance serves)
     ex = Extractor(W, H, cylinders=cyl, max_batch=len(frames), **intr)
     for rep in range(2):
         n = ex.extract_host(frames)
         res = ex.results(n)
+        assert ex.spill_info()[2] == (n if instance == "general" else 0), "which grow instance served the frames"
         for f in range(n):
             compare_frame(orc.run(frames[f]), ex, res, f, check_cells=(rep == 0))
     # one frame at a time on a handle of its own (results in pinned host memory, the general kernel signals the host)
