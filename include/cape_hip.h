@@ -90,8 +90,8 @@ enum
  */
 typedef struct cape_config
 {
-    int32_t width;      /* multiple of 20; at most 256 cells wide (5120 px) and 65 535 cells in all -- grids up to 64 x 64 cells */
-    int32_t height;     /* multiple of 20     (1280 x 1280 px) run in the fast kernels, larger ones in the general instance    */
+    int32_t width;      /* multiple of 20; at most 256 cells wide (5120 px) and 65 535 cells in all -- grids of up to 128 x 64 cells */
+    int32_t height;     /* multiple of 20     (2560 x 1280 px) run in the fast kernels, larger ones in the general instance      */
     double fx, fy, cx, cy;
     uint32_t flags;     /* CAPE_FLAG_* */
     int32_t device;     /* HIP device ordinal */

@@ -7,7 +7,7 @@
 //
 // The seed loop is sequential by construction (every seed consumes cells and histogram counts), so a frame gets
 // one 64-lane wave and thousands of frames are in flight.  Inside the wave:
-//   * the cell grid is held as bit rows: lane r owns row r of the 32x24 (u32) or 64x48 (u64) grid;
+//   * the cell grid is held as bit rows: lane r owns row r of the 32x24 (u32), 64x48 (u64) or 96x54 (Mask128: two words) grid;
 //   * the recursive DFS of region_growing is directed-graph reachability: the merge predicate of every directed
 //     cell edge (parent plane vs child plane, child tolerance) is evaluated once per frame into four edge masks,
 //     and growing a region is label propagation on bit rows (shift/and/or + lane shuffles) iterated with a
@@ -1041,7 +1041,7 @@ hipError_t launch_grow_variant(const StageBParams& p, int nFrames, hipStream_t s
 // this stream, forked from `stream` through `fork` and closed by `done`; `stream` itself does not wait for it (the caller of
 // the next entry point on this handle does).  A second handle's streaming kernels then run under this one's slow tail.
 // `gen`: the general instance (cape_grow_general.hip) -- with gen->allFrames it is the ONLY grow kernel of the handle (grids beyond
-// 64 x 64 cells); otherwise it runs last, behind the 64-segment instance and on the same stream, over the frames that instance
+// 128 x 64 cells); otherwise it runs last, behind the 64-segment instance and on the same stream, over the frames that instance
 // listed in p.spillList (more than one record holds; none, as a rule: its waves leave at once).
 hipError_t launch_grow(const StageBParams& p, int nFrames, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t done,
                        const GenParams* gen)

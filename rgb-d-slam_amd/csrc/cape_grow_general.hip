@@ -2,10 +2,10 @@
 //
 // The reference's detector takes any image size (Primitive_Detection(width, height), primitive_detection.cpp:26-67) and keeps its
 // plane segments in an unbounded std::vector (primitive_detection.hpp:206, pushed at primitive_detection.cpp:391-411 and :437-476).
-// The everyday instances of the grow kernel (cape_grow.hip) buy their speed with two fixed shapes: a grid row is ONE 32- or 64-bit
-// mask held by the lane of that row (grids up to 64 x 64 cells) and a frame's segments sit in 32 or 64 LDS slots, "lane j <- segment
-// j" in every pass behind the seed loop.  This instance has neither limit and takes
-//   * every frame of a handle whose grid is wider or taller than 64 cells (1920 x 1080 = 96 x 54 cells, portrait formats, 4K), and
+// The everyday instances of the grow kernel (cape_grow.hip) buy their speed with two fixed shapes: a grid row is ONE mask of 32, 64
+// or 128 bits held by the lane of that row (grids up to 128 x 64 cells: 1920 x 1080 is 96 x 54) and a frame's segments sit in 32 or
+// 64 LDS slots, "lane j <- segment j" in every pass behind the seed loop.  This instance has neither limit and takes
+//   * every frame of a handle whose grid has more than 64 rows or 128 columns (portrait 1080 x 1920, 2560 x 1440, 4K), and
 //   * on the other handles, the frames the 64-segment instance ran out of record capacity on (StageBParams::spillList): a
 //     checkerboard of small facets gives more than 64 plane segments, a field of pipes more than 64 cylinder labels.
 // Same algorithm, statement for statement, as grow_frame_wave / grow_tail (the reference lines are cited there and again below);
