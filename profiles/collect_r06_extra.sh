@@ -14,10 +14,10 @@ python profiles/overlay_batch_rate.py 128:256 256:256 512:256 1024:256 2>&1 | gr
 python profiles/single_frame_latency.py > $OUT/r06_single_frame_latency.txt 2>&1
 python profiles/host_input_rate.py 256 > $OUT/r06_host_input_rate.txt 2>&1
 {
-  for v in "" mp_static mp_all mp_rev; do
+  for v in "" mp_nocoop mp_static mp_c0g8; do
     if [ -n "$v" ]; then export CAPE_HIP_LIB=$R/rgb-d-slam_amd/lib/exp/libcape_$v.so; else unset CAPE_HIP_LIB; fi
     [ -n "$v" ] && [ ! -f "$CAPE_HIP_LIB" ] && continue
-    echo "variant ${v:-shipped (tickets in tiers 1..3)}"; python profiles/match_ms.py; python profiles/match_ms.py
+    echo "variant ${v:-shipped (cooperative tiers 1..3, tickets)}"; python profiles/match_ms.py; python profiles/match_ms.py
   done
   unset CAPE_HIP_LIB
 } 2>&1 | grep -v amdgpu.ids > $OUT/r06_match_tickets_raw.txt
