@@ -349,7 +349,9 @@ int cape_rectify_depth_host(cape_handle h, const float* depth_host, float* recti
  * |cos 20 deg| (shape_primitives.cpp:70-86), inter > best so far and inter / area(detected) >= 0.4f (0.2 with
  * CAPE_MATCH_ADVANCED), previous planes visited in order with the is-matched flags updated between them
  * (feature_map.hpp:651-669), and the `selectedIndex <= 0` quirk that never returns detected plane 0
- * (map_primitive.cpp:146) unless CAPE_MATCH_ALLOW_INDEX0 is set.  Frame 0 of a batch has no predecessor (n_prev = 0). */
+ * (map_primitive.cpp:146) unless CAPE_MATCH_ALLOW_INDEX0 is set.  Frame 0 of a batch has no predecessor (n_prev = 0).
+ * A frame that continues in spill records (more than 64 plane segments) takes part with the planes of its FIRST record only: this
+ * pre-filter has no reference counterpart and its tables hold 64 planes; the polygon matcher below flags such a frame instead. */
 enum
 {
     CAPE_MATCH_ADVANCED = 1u << 0,
@@ -426,7 +428,8 @@ int cape_debug_polygon(cape_handle h, const double* points3, int32_t n, const do
 #define CAPE_MATCH_MAX_PLANES 16
 enum
 {
-    CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, an output plane of either frame
+    CAPE_MATCH_EXACT_OVERFLOW = 1u << 0 /* more than 16 kept planes in one of the two frames, a frame that continues in spill records
+                                           (cape_frame_header.next_record), an output plane of either frame
                                            whose polygon was left to the host class (CAPE_POLY_OVERFLOW: the host may keep it,
                                            so the kept-plane indices are not known here), or a polygon pair beyond the
                                            kernel's capacities (512 vertices per ring, 2 048 slab boundaries, 32 edges of a
