@@ -155,3 +155,61 @@ def test_timings_struct_carries_the_five_buckets(hip_library):
     assert C.sizeof(cape_amd.cape_timings) == 12 * 8
     src = open(os.path.join(ROOT, "include", "cape_hip.h")).read()
     assert "double reset_s, init_s, grow_phase_s, merge_s, refine_s;" in src
+
+
+def test_record_chains_on_the_host(hip_library):
+    """ABI 2: a frame of more than 64 plane segments is a chain of records (cape_frame_header.next_record).  Pure host logic on crafted
+    records, no GPU: the binding's FrameResults walks the chain (segments, planes, boundary slabs, cylinder labels), cape_log_records
+    follows it as far as the caller's array reaches and never loops on a zero-filled or backward link."""
+    import numpy as np
+    import pytest
+
+    import cape_amd
+
+    assert cape_amd.load_library().cape_abi_version() == cape_amd.CAPE_ABI_VERSION == 2
+    max_batch, cap = 2, 16
+    rec = np.zeros(max_batch, cape_amd.FRAME_RECORD_DTYPE)
+    spill = np.zeros(2, cape_amd.FRAME_RECORD_DTYPE)
+    rec["header"]["next_record"] = -1
+    spill["header"]["next_record"] = -1
+    # frame 0: 64 + 64 + 2 segments over three records; frame 1: three segments in its own record
+    rec["header"]["n_plane_segments"][0], rec["header"]["next_record"][0] = 130, max_batch + 0
+    spill["header"]["n_plane_segments"][0], spill["header"]["segment_base"][0], spill["header"]["next_record"][0] = 66, 64, max_batch + 1
+    spill["header"]["n_plane_segments"][1], spill["header"]["segment_base"][1] = 2, 128
+    for r, base in ((rec[0], 0), (spill[0], 64), (spill[1], 128)):
+        n = min(64, int(r["header"]["n_plane_segments"]))
+        r["segments"]["merge_label"][:n] = np.arange(base, base + n)
+        r["segments"]["planar"][:n] = 1
+        r["segments"]["is_output"][:n] = (np.arange(base, base + n) % 2 == 0)
+        r["segments"]["boundary_offset"][:n] = np.arange(n) % 4 * 3
+        r["segments"]["boundary_count"][:n] = 3
+    rec["header"]["n_plane_segments"][1] = 3
+    rec["segments"]["merge_label"][1][:3] = [0, 0, 2]
+    rec["segments"]["planar"][1][:3] = [1, 1, 1]
+    rec["segments"]["boundary_count"][1][:3] = [2, 0, 5]  # a planar merge root with two boundary points: the reference's warning
+    rec["header"]["n_cylinder_labels"][0] = 65
+    rec["cylinders"]["kept"][0][:64] = 1
+    spill["header"]["n_cylinder_labels"][0] = 1
+    spill["cylinders"]["kept"][0][0] = 1
+    bd = np.arange(max_batch * cap * 3, dtype=np.float64).reshape(max_batch, cap, 3)
+    sbd = -np.arange(2 * cap * 3, dtype=np.float64).reshape(2, cap, 3)
+    res = cape_amd.FrameResults(rec, None, None, bd, max_batch, spill, sbd)
+    segs = res.segments(0)
+    assert len(segs) == 130 and np.array_equal(segs["merge_label"], np.arange(130)) and len(res.chain(0)) == 3 and len(res.chain(1)) == 1
+    assert len(res.planes(0)) == 65 and len(res.cylinder_labels(0)) == 65 and len(res.segments(1)) == 3
+    pb = res.plane_boundaries(0)
+    assert len(pb) == 65 and pb[0].shape == (3, 3) and pb[0][0, 0] >= 0 and pb[32][0, 0] <= 0 and pb[64][0, 0] <= 0  # own slab, then the spill slabs
+    # a chain whose spill records were not copied is an error, not a silent truncation
+    with pytest.raises(cape_amd.CapeError):
+        cape_amd.FrameResults(rec, None, None, bd, max_batch).segments(0)
+    # the log lines: frame 1's rejected plane; the chain of frame 0 is followed through an array that holds batch + pool
+    both = np.concatenate([rec, spill])
+    spill2 = both[max_batch:]
+    spill2["segments"]["boundary_count"][1][1] = 1  # segment 129 (a merge root, planar): rejected
+    lines = cape_amd.log_records(both)
+    assert lines.count((1, "Could not find a correct boundary polygon, rejecting plane segment", 0)) == 1
+    assert lines.count((1, "Could not find a correct boundary polygon, rejecting plane segment", 1)) == 1
+    # links that point backwards or at the record itself never loop
+    both["header"]["next_record"][3] = 2
+    both["header"]["next_record"][1] = 1
+    assert isinstance(cape_amd.log_records(both), list)
