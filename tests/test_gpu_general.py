@@ -133,3 +133,84 @@ def test_more_than_64_cylinder_labels(oracle_mod):
     for f in range(n):
         compare_frame(want, ex, res, f, check_cells=False)
     ex.close()
+
+
+def test_next_rows_on_a_1920x1080_grid(oracle_mod):
+    """The rows around the path on a grid of 96-cell rows: N3 rectify_depth and N4 raw uint16 input bit-exact against the oracle,
+    N1 / N2 (device polygons + polygon matches) against the oracle of the reference's polygon algorithm, the cell-mask pre-filter
+    against match_oracle -- every piece that takes a width must take this one."""
+    import torch
+    import cape_amd
+    import match_oracle
+    import polygon_oracle_py as P
+    from cape_amd import Extractor, synth
+    from test_gpu_polygon_oracle import _center, compare_plane, new_stats
+
+    P.build()
+    W, H = 1920, 1080
+    intr = _intr(W)
+    frames = np.stack([synth.room(seed=5, frame=10 + k, width=W, height=H, intr=intr) for k in range(4)])
+    orc = oracle_mod.Oracle(W, H, cylinders=True, **intr)
+    ex = Extractor(W, H, cylinders=True, max_batch=len(frames), **intr)
+    st = torch.cuda.current_stream().cuda_stream
+    # N3
+    a = np.deg2rad(1.0)
+    T = np.array([[np.cos(a), 0, np.sin(a), -25.0], [0, 1, 0, 1.5], [-np.sin(a), 0, np.cos(a), 4.0], [0, 0, 0, 1]])
+    din = torch.from_numpy(frames).cuda()
+    dout = torch.empty_like(din)
+    ex.rectify_device(din.data_ptr(), dout.data_ptr(), len(frames), T, st)
+    got = dout.cpu().numpy()
+    for f in range(len(frames)):
+        assert np.array_equal(got[f].view(np.uint32), orc.rectify(frames[f], T).view(np.uint32)), "rectified depth differs"
+    # N4: millimetre depths as raw sensor units with scale 1 (examples/main_CAPE.cpp:58-59)
+    raw = frames.astype(np.uint16)
+    assert np.array_equal(raw.astype(np.float32), frames)
+    t16 = torch.from_numpy(raw.view(np.int16)).cuda()
+    ex.extract_device_u16(t16.data_ptr(), 1.0, len(frames), st)
+    res = ex.results(len(frames))
+    want = [orc.run(f) for f in frames]
+    for f in range(len(frames)):
+        compare_frame(want[f], ex, res, f, check_cells=(f == 0))
+    # N1 / N2
+    ex.build_polygons(len(frames), st)
+    ex.match_polygons(len(frames), 0, st)
+    ex.match_consecutive(len(frames), 0, st)
+    pol, ver = ex.polygons(len(frames))
+    got_m = ex.polygon_matches(len(frames))
+    stats = new_stats()
+    kept = []
+    for f in range(len(frames)):
+        planes = []
+        for i, s in enumerate(res.segments(f)):
+            if not s["is_output"]:
+                continue
+            p = pol[f, i]
+            o, c = int(p["vertex_offset"]), int(p["vertex_count"])
+            ref = compare_plane(P, p, ver[f, o:o + c], res.boundary_points(f, s), s["normal"], _center(s), f"1920x1080 frame {f} segment {i}", stats)
+            if ref is not None and ref.valid and ref.boundary_length() >= 3:
+                planes.append((i, np.asarray(s["out_normal"], np.float64), float(s["d"]), ref))
+        kept.append(planes)
+    assert stats["planes"] >= 8 and stats["vertex_identical"] >= 0.9 * (stats["planes"] - stats["threw"] - len(stats["dissolve"]) - stats.get("degenerate", 0)), stats
+    for f in range(1, len(frames)):
+        if got_m[f]["flags"] & cape_amd.MATCH_EXACT_OVERFLOW or len(stats["dissolve"]):
+            continue
+        prev, cur = kept[f - 1], kept[f]
+        wantm, _ = P.find_matches([q[1:] for q in prev], [q[1:] for q in cur], None, advanced=False, allow_index0=False)
+        assert list(got_m[f]["match"][: len(prev)]) == wantm
+    # the cell-mask pre-filter against match_oracle
+    mm = ex.matches(len(frames))
+
+    def per(r):
+        roots = r.planes[:, 19].astype(int) if len(r.planes) else np.zeros(0, int)
+        is_out = np.zeros(len(r.merge_labels), bool)
+        is_out[roots] = True
+        masks, _ = match_oracle.plane_masks(r.plane_labels, r.segments, r.merge_labels, is_out)
+        return {"masks": masks, "normals": r.planes[:, 0:3], "d": r.planes[:, 3]}
+
+    fr = [per(r) for r in want]
+    for k in range(1, len(frames)):
+        m, ap, ac, inter = match_oracle.match_frame(fr[k - 1], fr[k], advanced=False, allow_index0=False)
+        g = mm[k]
+        assert g["n_prev"] == len(ap) and g["n_cur"] == len(ac) and list(g["match"][: len(ap)]) == m
+        assert np.array_equal(g["inter"][: len(ap), : len(ac)], inter)
+    ex.close()
