@@ -2,6 +2,7 @@
 // in C++ on the host clock, PCIe both ways included.  Three ways to make the call:
 //   abi/pageable : cape_extract_host on an ordinary malloc'ed image (what a cv::Mat holds) + cape_host_results
 //   abi/pinned   : the image lives in cape_host_alloc'ed memory: the streaming kernel reads it over PCIe, no staging copy
+//   abi/pinned u16 : the same through cape_extract_u16_host on the raw uint16 image (half the bytes over the link)
 //   overlay      : Primitive_Detection::find_primitives of the host overlay (pageable image, boundary polygons included)
 // usage: latency_bench <frames.f32> <n_frames> <width> <height> <fx> <fy> <cx> <cy> <cylinders 0|1>
 #include <algorithm>
@@ -91,6 +92,39 @@ int main(int argc, char** argv)
         std::printf("               device time per call (HIP events, pinned run): moments %.1f us  plane %.1f us  grow %.1f us\n",
                     1e6 * tm.cell_moments_s / tm.calls, 1e6 * tm.cell_plane_s / tm.calls, 1e6 * tm.grow_s / tm.calls);
     cape_host_free(h, pinned);
+    // ---- abi / pinned, raw uint16 (the sensor's own format, examples/main_TUM.cpp:242: half the bytes over the link); only when the
+    // frames ARE whole millimetres below 65 536, so that the call sees the same depths as the rows above
+    bool whole = true;
+    for (size_t i = 0; i < frames.size() && whole; ++i)
+        whole = frames[i] >= 0.0f && frames[i] < 65536.0f && frames[i] == static_cast<float>(static_cast<uint16_t>(frames[i]));
+    uint16_t* pinned16 = nullptr;
+    if (whole && cape_host_alloc(h, px * nFrames * sizeof(uint16_t), reinterpret_cast<void**>(&pinned16)) == CAPE_OK)
+    {
+        for (size_t i = 0; i < frames.size(); ++i)
+            pinned16[i] = static_cast<uint16_t>(frames[i]);
+        t.clear();
+        long planes16 = 0, planes32 = 0;
+        for (int r = 0; r < reps + 2; ++r)
+            for (int k = 0; k < nFrames; ++k)
+            {
+                const auto t0 = clk::now();
+                if (cape_extract_u16_host(h, pinned16 + px * k, 1.0f, 1, nullptr) != CAPE_OK || cape_host_results(h, &rec, nullptr, nullptr, &bnd) != CAPE_OK)
+                    return 9;
+                planes16 += rec->header.n_planes;
+                if (r >= 2)
+                    t.push_back(us(t0, clk::now()));
+            }
+        for (int k = 0; k < nFrames; ++k)
+        {
+            if (cape_extract_host(h, frames.data() + px * k, 1, nullptr) != CAPE_OK || cape_host_results(h, &rec, nullptr, nullptr, &bnd) != CAPE_OK)
+                return 9;
+            planes32 += rec->header.n_planes * (reps + 2);
+        }
+        report("abi/pinned u16", t);
+        if (planes16 != planes32)
+            std::printf("               !! the uint16 calls saw %ld planes, the float32 calls %ld\n", planes16, planes32);
+        cape_host_free(h, pinned16);
+    }
     cape_destroy(h);
 
     // ---- overlay (cylinder branch always on, like the reference)

@@ -151,6 +151,7 @@ struct cape_handle_s
     uint32_t* stripCounters = nullptr;
     bool stripsAlways = false; // CAPE_STAGE_A=strips: also when the frame is read over the link (see launch_chain)
     bool inputOverLink = false; // the call in flight reads its frames straight from pinned host memory (cape_extract_host)
+    bool pinnedByDma = false;   // debug knob CAPE_PINNED_INPUT=dma: pinned frames take the staging copy as well (A/B of the two routes)
     uint32_t* resumeList = nullptr;   // [0] count, [1..] frames handed to the cylinder kernel WITH their recorded regions
     unsigned char* growState = nullptr; // max_batch x grow_state_bytes(): the parked state of those frames
     // schedule feedback: the count of the last two-pass call is copied to pinned host memory behind the kernels and read
@@ -982,6 +983,8 @@ int cape_create(const cape_config* cfg, cape_handle* out)
         if (cfg->max_batch <= kHostResultFrames && cfg->sub_batches <= 1 && !(stageA && std::string(stageA) == "bands"))
         {
             h->stripsAlways = stageA != nullptr; // (validated above: "strips")
+            const char* pinnedInput = std::getenv("CAPE_PINNED_INPUT");
+            h->pinnedByDma = pinnedInput && std::string(pinnedInput) == "dma";
             CAPE_ALLOC(dalloc(h->doneCounter, 1));
             CAPE_ALLOC(hipMemset(h->doneCounter, 0, sizeof(uint32_t)));
             CAPE_ALLOC(dalloc(h->stripCounters, (size_t)kHostResultFrames));
@@ -1367,7 +1370,7 @@ int cape_extract_host(cape_handle h, const float* depth_host, int32_t n_frames, 
     const bool pinned = hipPointerGetAttributes(&attr, depth_host) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer;
     if (!pinned)
         (void)hipGetLastError(); // an unregistered pointer is not an error here
-    if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 16 == 0)
+    if (pinned && !h->pinnedByDma && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 16 == 0)
     {
         h->inputOverLink = true;
         const int rc = cape_extract(h, static_cast<const float*>(attr.devicePointer), n_frames, stream_);
@@ -1422,7 +1425,7 @@ int cape_extract_u16_host(cape_handle h, const uint16_t* depth_host, float scale
     const bool pinned = hipPointerGetAttributes(&attr, depth_host) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer;
     if (!pinned)
         (void)hipGetLastError();
-    if (pinned && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 8 == 0)
+    if (pinned && !h->pinnedByDma && n_frames <= kHostResultFrames && reinterpret_cast<uintptr_t>(attr.devicePointer) % 8 == 0)
     {
         h->inputOverLink = true;
         const int rc = cape_extract_u16(h, static_cast<const uint16_t*>(attr.devicePointer), scale, n_frames, stream_);
