@@ -2338,7 +2338,7 @@ int cape_spill_info(cape_handle h, int32_t* used, int32_t* capacity, int32_t* fr
 
 int cape_copy_spill(cape_handle h, int32_t first, int32_t count, cape_frame_record* records, double* boundary)
 {
-    if (!h || first < 0 || count < 0 || first + count > h->spillRecords)
+    if (!h || first < 0 || count < 0 || first > h->spillRecords || count > h->spillRecords - first)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / spill record range");
     CAPE_ON_DEVICE(h);
     if (h->resultsOnHost)
@@ -2359,7 +2359,7 @@ int cape_copy_spill(cape_handle h, int32_t first, int32_t count, cape_frame_reco
 
 int cape_copy_spill_polygons(cape_handle h, int32_t first, int32_t count, cape_polygon* polygons, double* vertices)
 {
-    if (!h || first < 0 || count < 0 || first + count > h->spillRecords)
+    if (!h || first < 0 || count < 0 || first > h->spillRecords || count > h->spillRecords - first)
         return fail(CAPE_ERR_INVALID_ARGUMENT, "bad handle / spill record range");
     if (!h->polygons || h->polygonFrames <= 0)
         return fail(CAPE_ERR_CAPACITY, "no cape_build_polygons has run on the current batch");
