@@ -4,7 +4,7 @@ OF THE REFERENCE'S ALGORITHM (oracle/polygon_oracle.cpp) -- a long sweep over de
 dropped blocks (ragged, concave outlines), not part of the test suite.  Every disagreement is LISTED, nothing is averaged
 away: per plane validity / convex-fallback verdict / area ratio / IoU / vertex identity; the planes whose hull the reference
 would dissolve with Boost set operations (not restated); per frame pair the matcher's decisions and areas.
-usage: polygon_vs_oracle.py [frames_per_scene=256] [seed=3]"""
+usage: polygon_vs_oracle.py [frames_per_scene=256] [seed=3]   (POLY_DUMP=dir: the candidates of every plane that is not vertex-identical)"""
 import os
 import sys
 import time
@@ -106,6 +106,9 @@ for scene, cyl in (("room", False), ("tumlike", False), ("tumlike", True), ("tun
                 ratio = float(p["area"]) / ref.area
                 same = len(verts) == len(ref.ring) and np.array_equal(verts, ref.ring)
                 tot["vertex_identical"] += int(same)
+                if not same and os.environ.get("POLY_DUMP"):  # the plane's candidates, for a stand-alone reproduction on the CPU
+                    np.savez(os.path.join(os.environ["POLY_DUMP"], f"poly_diff_{seed}_{scene}_{int(cyl)}_{start}_{f}_{i}.npz"), pts=np.asarray(pts, np.float64),
+                             normal=np.asarray(s["normal"], np.float64), center=center(s), device_ring=verts, oracle_ring=ref.ring)
                 worst["iou"] = min(worst["iou"], iou)
                 worst["area"] = max(worst["area"], abs(ratio - 1))
                 if iou < 0.999:

@@ -394,10 +394,11 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
             hide(first, false); // the start point is put back into the index once the hull has three edges
             --usedCount;
         }
-        // ---- k nearest visible neighbours of the current point, ascending (squared distance, index)
-        // key = the squared distance's bit pattern (>= +0: the bits order like the value) with its ten lowest mantissa bits
-        // replaced by the point index: ONE 64-bit wave minimum per neighbour yields the nearest point and breaks ties (and
-        // distances within 2^-42 of each other) by index.  The host class sorts by the very same key.
+        // ---- k nearest visible neighbours of the current point, ascending (squared distance, index) -- EXACTLY that order.
+        // Fast key = the squared distance's bit pattern (>= +0: the bits order like the value) with its ten lowest mantissa bits
+        // replaced by the point index: ONE 64-bit wave minimum per neighbour.  Two keys order like (distance, index) unless they
+        // share their upper 54 bits (a "bucket": distances within 2^-42 of each other); every selection below notices when a
+        // bucket it touched holds a second visible key (`sameBucket`) and the step is then selected again on the full bit patterns.
         unsigned long long key[kPolyPerLane];
 #pragma unroll
         for (int j = 0; j < kPolyPerLane; ++j)
@@ -423,6 +424,7 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
         int myCand = 0, myClass = 0;
         double myVx = 0.0, myVy = 0.0, myPx = 0.0, myPy = 0.0; // candidate c's point lives in lane c too
         bool selected = false;
+        bool sameBucket = false; // (uniform)
         if (kk >= kPolySortSelect)
         {
             // Many neighbours: ONE sort instead of kk minima.  Every lane offers its smallest key; sorted across the wave, lane c
@@ -444,7 +446,10 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
                 }
             const unsigned long long sorted = wave_sort_u64(head, lane);
             const unsigned long long hidden = wave_min_u64(second);
-            if (__popcll(__ballot(sorted < hidden)) >= kk)
+            // one of the kk smallest heads shares its bucket with the next head, or with the smallest key behind the heads
+            const unsigned long long after = wave_from_lane_above(sorted); // (lanes below kk <= 21 are the ones that look)
+            sameBucket = __any(lane < kk && (((sorted ^ after) >> 10) == 0 || ((sorted ^ hidden) >> 10) == 0));
+            if (__popcll(__ballot(sorted < hidden)) >= kk && !sameBucket)
             {
                 selected = true;
                 if (lane < kk)
@@ -459,27 +464,80 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
                 }
             }
         }
-        for (int c = 0; c < kk && !selected; ++c)
+        if (!selected && !sameBucket)
         {
-            unsigned long long best = ~0ull;
-#pragma unroll
-            for (int j = 0; j < kPolyPerLane; ++j)
-                if ((EXACT || 64 * j < n) && key[j] < best)
-                    best = key[j];
-            const unsigned long long m = wave_min_u64_lead(best);
-            const int idx = (int)(m & 1023ull);
-#pragma unroll
-            for (int j = 0; j < kPolyPerLane; ++j)
-                if ((EXACT || 64 * j < n) && key[j] == m)
-                    key[j] = ~0ull; // taken (keys are unique: they carry the index)
-            const double2 q = point_of(idx);
-            if (lane == c)
+            unsigned long long prevMin = ~0ull;
+            for (int c = 0; c < kk; ++c)
             {
-                myCand = idx;
-                myPx = q.x;
-                myPy = q.y;
-                myVx = q.x - cur.x;
-                myVy = q.y - cur.y;
+                unsigned long long best = ~0ull;
+#pragma unroll
+                for (int j = 0; j < kPolyPerLane; ++j)
+                    if ((EXACT || 64 * j < n) && key[j] < best)
+                        best = key[j];
+                const unsigned long long m = wave_min_u64_lead(best);
+                sameBucket |= ((m ^ prevMin) >> 10) == 0; // two minima in a row out of one bucket
+                prevMin = m;
+                const int idx = (int)(m & 1023ull);
+#pragma unroll
+                for (int j = 0; j < kPolyPerLane; ++j)
+                    if ((EXACT || 64 * j < n) && key[j] == m)
+                        key[j] = ~0ull; // taken (keys are unique: they carry the index)
+                const double2 q = point_of(idx);
+                if (lane == c)
+                {
+                    myCand = idx;
+                    myPx = q.x;
+                    myPy = q.y;
+                    myVx = q.x - cur.x;
+                    myVy = q.y - cur.y;
+                }
+            }
+            // ... or the last one shares its bucket with a key that stayed behind
+            bool behind = false;
+#pragma unroll
+            for (int j = 0; j < kPolyPerLane; ++j)
+                if ((EXACT || 64 * j < n) && ((key[j] ^ prevMin) >> 10) == 0)
+                    behind = true;
+            sameBucket |= __any(behind) != 0;
+        }
+        if (sameBucket)
+        {
+            // The rare step (distances within 2^-42 of each other among the nearest): kk minima of (bit pattern of the squared
+            // distance, index), the order the host class and the oracle sort by.  Nothing is kept from the attempt above.
+            unsigned taken = 0; // bit j: my point lane + 64 j is among the neighbours already
+            for (int c = 0; c < kk; ++c)
+            {
+                unsigned long long bestD = ~0ull;
+                unsigned bestI = ~0u;
+#pragma unroll
+                for (int j = 0; j < kPolyPerLane; ++j)
+                {
+                    const int i = lane + 64 * j;
+                    if ((EXACT || 64 * j < n) && i < n && !((myUsed >> j) & 1u) && !((taken >> j) & 1u))
+                    {
+                        const double2 q = my_point(j);
+                        const double dx = cur.x - q.x, dy = cur.y - q.y;
+                        const unsigned long long dq = (unsigned long long)__double_as_longlong(dx * dx + dy * dy);
+                        if (dq < bestD) // (ascending j = ascending index: the first of equal distances stays)
+                        {
+                            bestD = dq;
+                            bestI = (unsigned)i;
+                        }
+                    }
+                }
+                const unsigned long long md = wave_min_u64(bestD);
+                const int idx = (int)wave_min_u32(bestD == md ? bestI : ~0u);
+                if (lane == (idx & 63))
+                    taken |= 1u << (idx >> 6);
+                const double2 q = point_of(idx);
+                if (lane == c)
+                {
+                    myCand = idx;
+                    myPx = q.x;
+                    myPy = q.y;
+                    myVx = q.x - cur.x;
+                    myVy = q.y - cur.y;
+                }
             }
         }
         if (myVx == 0 && myVy == 0)

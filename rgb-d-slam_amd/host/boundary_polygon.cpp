@@ -169,11 +169,11 @@ size_t find_min_y_point(const std::vector<vector2>& pts)
 // back to it, and holds every point once when it ran out of points first (:126: `hull.size() != pointList.size()`).
 // Two restatements, both forced by what the device can reproduce bit for bit:
 //  * FLANN's approximate search over randomized kd-trees (:109-111, :258-288) is the EXACT k nearest visible points, nearest
-//    first, ordered by ONE 64-bit key -- the squared distance's bit pattern (>= +0: the bits order like the value) with its
-//    ten lowest mantissa bits replaced by the point index: ties, and distances within 2^-42 of each other, go to the smaller
-//    index (the device picks a neighbour with a single wave-wide minimum of that key; sets beyond its 1 024 points keep the
-//    plain (distance, index) order).  The start point re-enters the index at step 4 under its own index (the reference gives
-//    the copy the id n, :131: that only matters to an exact distance tie).
+//    first, ordered by (squared distance, point index): an exact tie goes to the smaller index.  (Through round 5 distances
+//    within 2^-42 of each other went to the smaller index too, because the device selected on a 64-bit key that carried the
+//    index in the distance's ten lowest mantissa bits; that moved 1 hull in ~10 000 away from the oracle's, and the device now
+//    re-selects such a step on the full bit patterns.)  The start point re-enters the index at step 4 under its own index (the
+//    reference gives the copy the id n, :131: that only matters to an exact distance tie).
 //  * SortByAngle (:296-315) orders the candidates by `-atan2` angles, descending, with the slack.  Here the clockwise turn
 //    from the previous edge is never computed as an angle: a class (same direction / less than half a turn / opposite / more)
 //    from the signs of one cross and one dot product, and inside a class one more cross product -- additions,
@@ -213,7 +213,7 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std
                 const double d2 = dx * dx + dy * dy;
                 uint64_t bits;
                 std::memcpy(&bits, &d2, sizeof bits);
-                cand.emplace_back(n <= 1024 ? ((bits & ~uint64_t(1023)) | static_cast<uint64_t>(i)) : bits, i);
+                cand.emplace_back(bits, i);
             }
         const size_t kk = std::min(k, cand.size());
         std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());

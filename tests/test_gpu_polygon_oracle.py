@@ -312,3 +312,20 @@ def test_hull_that_touches_itself_on_the_device(P):
     assert pol["flags"] & cape_amd.POLY_VALID and not pol["flags"] & cape_amd.POLY_OVERFLOW, hex(int(pol["flags"]))
     assert abs(float(pol["area"]) / covered - 1.0) < 0.02, (float(pol["area"]), covered)
     ex.close()
+
+
+def test_neighbours_at_nearly_equal_distances_on_the_device(P):
+    """tests/golden/polygon_near_ties.npz through cape_debug_polygon: the walk's fast key orders two neighbours whose squared
+    distances agree in their upper 54 bits by index; the kernel notices (`sameBucket`) and selects that step again on the full bit
+    patterns, so the ring is the oracle's -- which takes the nearer neighbour first, like the reference's nearest-first list."""
+    import cape_amd
+    from cape_amd import Extractor, synth
+    from test_polygon_oracle import _near_ties
+
+    ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
+    for name, pts, nrm, ctr, ring, area, flags, k in _near_ties():
+        pol, verts = ex.debug_polygon(pts, nrm, ctr)
+        assert bool(pol["flags"] & cape_amd.POLY_VALID) == bool(flags & P.VALID), name
+        assert bool(pol["flags"] & cape_amd.POLY_DISSOLVED) == bool(flags & P.DISSOLVED), name
+        assert np.array_equal(verts, ring), name
+    ex.close()
