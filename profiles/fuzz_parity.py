@@ -4,7 +4,8 @@ usage: fuzz_parity.py [n_frames=512] [seed=1] [width=640] [height=480]   -- ever
 FUZZ_BATCH=n: frames per call (n <= 8: one-frame handles, i.e. the latency instance of stage A and results in pinned memory);
 FUZZ_CELLS=1: the per-cell statistics are compared as well; FUZZ_BIG=1: one frame in eight is a checkerboard of tilted facets with a
 random tile size (frames of more than 64 plane segments: record chains through the general grow instance); CAPE_GROW=general in the
-environment sends every frame through that instance."""
+environment sends every frame through that instance; FUZZ_U16=1: the frames go in as raw uint16 sensor units (row N4, cape_extract_u16_host,
+scale 0.2 like a TUM depth PNG) and the oracle sees float(raw) * 0.2f."""
 import os
 import sys
 
@@ -25,6 +26,7 @@ intr = {k: v * W / 640.0 for k, v in synth.DEFAULT_INTRINSICS.items()}
 B = int(os.environ.get("FUZZ_BATCH", 64 if W * H <= 640 * 480 else 16))
 check_cells = os.environ.get("FUZZ_CELLS") == "1"
 big = os.environ.get("FUZZ_BIG") == "1"
+as_u16 = os.environ.get("FUZZ_U16") == "1"
 
 
 def checkerboard(tile, seed):
@@ -72,8 +74,11 @@ while done < n_total:
             d *= np.float32(rng.uniform(0.3, 3.0))
         frames.append(d)
     frames = np.stack(frames)
+    if as_u16:
+        raw = np.clip(np.nan_to_num(np.round(frames * 5.0), nan=0.0, posinf=65535.0, neginf=0.0), 0, 65535).astype(np.uint16)
+        frames = raw.astype(np.float32) * np.float32(0.2)  # what cv::Mat::convertTo(CV_32F, 0.2) leaves (examples/main_TUM.cpp:242)
     for cyl in (True, False):
-        n = ex[cyl].extract_host(frames)
+        n = ex[cyl].extract_host_u16(raw, 0.2) if as_u16 else ex[cyl].extract_host(frames)
         res = ex[cyl].results(n)
         for k in range(n):
             r = orc[cyl].run(frames[k])
