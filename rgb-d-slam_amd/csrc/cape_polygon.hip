@@ -284,23 +284,54 @@ __device__ __forceinline__ int wave_argmin2(double a, double b, int idx)
 // Clockwise rotation from the direction `P` to the vector `V`, as a class and an exact in-class comparison (the host class
 // orders candidates with the same predicates: no atan2, so host and device cannot disagree on a near-tie):
 //   0: same direction   1: strictly clockwise, less than half a turn   2: opposite   3: more than half a turn
+// Directions closer than 2 DBL_EPSILON radians are one direction (host class: same_direction_line -- what the reference's slack on
+// its atan2 angles makes of them): sin^2 <= (2 eps)^2 in products, behind a cheap test that cannot hide a case while |a| |b| < 2.2e12 mm^2.
+// (the product test sits behind WAVE-UNIFORM branches: left to itself the compiler turns the cheap first test into a select and
+//  pays the seven products on every comparison -- the walk measured 20 % slower)
+#ifndef CAPE_POLY_EPS
+#define CAPE_POLY_EPS 1 // A/B knob: 0 = exact cross products only (round 5), 2 = the products as an out-of-line function
+#endif
+#if CAPE_POLY_EPS == 2
+__device__ __attribute__((noinline)) bool same_direction_products(double cr, double ax, double ay, double bx, double by)
+#else
+__device__ __forceinline__ bool same_direction_products(double cr, double ax, double ay, double bx, double by)
+#endif
+{
+    constexpr double kEps2 = 1.9721522630525295135293214132069655741830160877724e-31; // 2^-102 = (2 DBL_EPSILON)^2
+    return cr * cr <= kEps2 * ((ax * ax + ay * ay) * (bx * bx + by * by));
+}
+// lane-parallel: every lane classifies its own candidate
 __device__ __forceinline__ int turn_class(double px, double py, double vx, double vy)
 {
     const double cr = px * vy - py * vx, dt = px * vx + py * vy;
-    if (cr < 0)
-        return 1;
-    if (cr > 0)
-        return 3;
-    return dt > 0 ? 0 : 2;
+    int cls = cr < 0 ? 1 : (cr > 0 ? 3 : (dt > 0 ? 0 : 2));
+    const bool nearLine = CAPE_POLY_EPS != 0 && fabs(cr) < 1e-3;
+    if (__any(nearLine))
+    {
+        if (nearLine && same_direction_products(cr, px, py, vx, vy))
+            cls = dt > 0 ? 0 : 2;
+    }
+    return cls;
 }
-// does candidate a turn further clockwise from P than candidate b (strictly)?
-__device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int cb, double bx, double by)
+// does candidate a turn further clockwise from P than candidate b (strictly)?  (uniform arguments: read out of the candidates' lanes)
+// The scan below runs the plain form -- the sign of one cross product -- and notes in `near` when a comparison came close enough for
+// the slack to matter (rare: a few steps in a thousand); that candidate scan is then repeated with the careful form.  A branch per
+// comparison instead cost the walk 15 % (profiles/r06_polygon_eps_ab.txt).
+__device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int cb, double bx, double by, bool& near)
+{
+    const double cr = bx * ay - by * ax; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
+    const bool sameOpenHalf = ca == cb && (ca & 1);
+    near |= CAPE_POLY_EPS != 0 && sameOpenHalf && cr < 0 && cr > -1e-3; // (the same test on cr's high word alone measured slower)
+    return ca != cb ? ca > cb : (sameOpenHalf && cr < 0);
+}
+__device__ __forceinline__ bool turns_further_careful(int ca, double ax, double ay, int cb, double bx, double by)
 {
     if (ca != cb)
         return ca > cb;
     if (ca == 0 || ca == 2)
         return false;
-    return (bx * ay - by * ax) < 0; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
+    const double cr = bx * ay - by * ax;
+    return cr < 0 && !(cr > -1e-3 && same_direction_products(cr, bx, by, ax, ay));
 }
 
 // One run of the k-nearest-neighbours walk (host: concave_hull_k = ConcaveHull of concave_fitting.cpp:93-183).  On success the
@@ -504,6 +535,8 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
         {
             // The rare step (distances within 2^-42 of each other among the nearest): kk minima of (bit pattern of the squared
             // distance, index), the order the host class and the oracle sort by.  Nothing is kept from the attempt above.
+            // (the start point, back in the index from step 4 on, carries the id n like the reference's copy, concave_fitting.cpp:131:
+            //  in an exact tie it comes last)
             unsigned taken = 0; // bit j: my point lane + 64 j is among the neighbours already
             for (int c = 0; c < kk; ++c)
             {
@@ -518,15 +551,17 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
                         const double2 q = my_point(j);
                         const double dx = cur.x - q.x, dy = cur.y - q.y;
                         const unsigned long long dq = (unsigned long long)__double_as_longlong(dx * dx + dy * dy);
-                        if (dq < bestD) // (ascending j = ascending index: the first of equal distances stays)
+                        const unsigned id = (i == first && step >= 4) ? (unsigned)n : (unsigned)i;
+                        if (dq < bestD || (dq == bestD && id < bestI))
                         {
                             bestD = dq;
-                            bestI = (unsigned)i;
+                            bestI = id;
                         }
                     }
                 }
                 const unsigned long long md = wave_min_u64(bestD);
-                const int idx = (int)wave_min_u32(bestD == md ? bestI : ~0u);
+                const int id = (int)wave_min_u32(bestD == md ? bestI : ~0u);
+                const int idx = id == n ? first : id;
                 if (lane == (idx & 63))
                     taken |= 1u << (idx >> 6);
                 const double2 q = point_of(idx);
@@ -553,18 +588,37 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
         {
             int b = -1, bClass = 0;
             double bVx = 0.0, bVy = 0.0;
+            bool near = false;
             for (int c = 0; c < kk; ++c)
             {
                 if ((tried >> c) & 1u)
                     continue;
                 const int cClass = __builtin_amdgcn_readlane(myClass, c);
                 const double cVx = readlane_f64(myVx, c), cVy = readlane_f64(myVy, c);
-                if (b < 0 || turns_further(cClass, cVx, cVy, bClass, bVx, bVy))
+                if (b < 0 || turns_further(cClass, cVx, cVy, bClass, bVx, bVy, near))
                 {
                     b = c;
                     bClass = cClass;
                     bVx = cVx;
                     bVy = cVy;
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane((int)near))
+            {
+                b = -1;
+                for (int c = 0; c < kk; ++c)
+                {
+                    if ((tried >> c) & 1u)
+                        continue;
+                    const int cClass = __builtin_amdgcn_readlane(myClass, c);
+                    const double cVx = readlane_f64(myVx, c), cVy = readlane_f64(myVy, c);
+                    if (b < 0 || turns_further_careful(cClass, cVx, cVy, bClass, bVx, bVy))
+                    {
+                        b = c;
+                        bClass = cClass;
+                        bVx = cVx;
+                        bVy = cVy;
+                    }
                 }
             }
             tried |= 1u << b;

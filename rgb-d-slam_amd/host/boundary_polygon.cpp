@@ -150,6 +150,20 @@ bool point_in_hull(const vector2& p, const std::vector<vector2>& pts, const std:
     return inout % 2 != 0;
 }
 
+// Two directions closer than 2 DBL_EPSILON radians are ONE direction.  The reference compares `-atan2` angles in [0, 2 pi) with a
+// slack of DBL_EPSILON (GreaterThan, concave_fitting.cpp:200; SortByAngle :296-315); the angles themselves resolve 2.2e-16 ..
+// 8.9e-16 rad depending on their size, so two directions a few 1e-16 apart come out as the same double, or one ulp apart and "equal"
+// by the rounding of `b + DBL_EPSILON`.  What that makes of a neighbour on the line of the previous edge is the angle 0 (or pi), not
+// 2 pi - 1e-16, and two neighbours on one ray from the current point stay nearest first.  Every such case met in 2.8e5 planes
+// (profiles/r06_polygon_cpu_sweep.txt) lies below 4e-16 and is decided like the reference decides it with this threshold; an exact
+// cross-product sign decided three of them the other way.  cr = ax by - ay bx; the test is sin^2 <= (2 eps)^2 in products only.
+// The cheap first test makes the products rare: it cannot hide a case as long as |a| |b| < 2.2e12 (millimetres: vectors < 1.4 km).
+inline bool same_direction_line(double cr, double ax, double ay, double bx, double by)
+{
+    constexpr double kEps2 = 1.9721522630525295135293214132069655741830160877724e-31; // 2^-102 = (2 DBL_EPSILON)^2
+    return std::abs(cr) < 1e-3 && cr * cr <= kEps2 * ((ax * ax + ay * ay) * (bx * bx + by * by));
+}
+
 // FindMinYPoint, concave_fitting.cpp:231-243: std::min_element under (y ascending, then x DESCENDING), comparisons with the slack
 size_t find_min_y_point(const std::vector<vector2>& pts)
 {
@@ -172,14 +186,15 @@ size_t find_min_y_point(const std::vector<vector2>& pts)
 //    first, ordered by (squared distance, point index): an exact tie goes to the smaller index.  (Through round 5 distances
 //    within 2^-42 of each other went to the smaller index too, because the device selected on a 64-bit key that carried the
 //    index in the distance's ten lowest mantissa bits; that moved 1 hull in ~10 000 away from the oracle's, and the device now
-//    re-selects such a step on the full bit patterns.)  The start point re-enters the index at step 4 under its own index (the
-//    reference gives the copy the id n, :131: that only matters to an exact distance tie).
+//    re-selects such a step on the full bit patterns.)  The start point re-enters the index at step 4 under the id n like the
+//    reference's copy (:131): in an exact distance tie it comes last.
 //  * SortByAngle (:296-315) orders the candidates by `-atan2` angles, descending, with the slack.  Here the clockwise turn
 //    from the previous edge is never computed as an angle: a class (same direction / less than half a turn / opposite / more)
 //    from the signs of one cross and one dot product, and inside a class one more cross product -- additions,
 //    multiplications and comparisons only, scanned nearest-first (the reference's sort of <= 16 candidates is an insertion
 //    sort: equal angles stay nearest-first there too).  An atan2 from glibc and one from ocml need not agree on two
-//    candidates a rounding error apart; these predicates do.  prevAngle = 0 (:122) is the +x direction, and so is the
+//    candidates a rounding error apart; these predicates do.  Directions within 2 DBL_EPSILON of each other count as equal
+//    (same_direction_line), which is what the reference's slack makes of them.  prevAngle = 0 (:122) is the +x direction, and so is the
 //    "direction" of a duplicate of the current point (atan2(+0, +0) = 0).
 bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std::vector<size_t>& h)
 {
@@ -213,18 +228,16 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std
                 const double d2 = dx * dx + dy * dy;
                 uint64_t bits;
                 std::memcpy(&bits, &d2, sizeof bits);
-                cand.emplace_back(bits, i);
+                cand.emplace_back(bits, (i == first && step >= 4) ? n : i); // the re-inserted start point carries the id n (:131)
             }
         const size_t kk = std::min(k, cand.size());
         std::partial_sort(cand.begin(), cand.begin() + kk, cand.end());
         cand.resize(kk);
         auto turn_class = [&](double vx, double vy) {
             const double cr = prevX * vy - prevY * vx, dt = prevX * vx + prevY * vy;
-            if (cr < 0)
-                return 1;
-            if (cr > 0)
-                return 3;
-            return dt > 0 ? 0 : 2;
+            if (same_direction_line(cr, prevX, prevY, vx, vy))
+                return dt > 0 ? 0 : 2;
+            return cr < 0 ? 1 : 3;
         };
         struct Cand
         {
@@ -236,7 +249,7 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std
         const size_t kc = cand.size();
         for (size_t c = 0; c < kc; ++c)
         {
-            const size_t i = cand[c].second;
+            const size_t i = cand[c].second == n ? first : cand[c].second;
             double vx = pts[i][0] - pts[current][0], vy = pts[i][1] - pts[current][1];
             if (vx == 0 && vy == 0)
                 vx = 1.0;
@@ -247,7 +260,8 @@ bool concave_hull_k(const std::vector<vector2>& pts, size_t first, size_t k, std
                 return a.cls > b.cls;
             if (a.cls == 0 || a.cls == 2)
                 return false;
-            return (b.vx * a.vy - b.vy * a.vx) < 0; // a lies clockwise of b inside the same open half turn
+            const double cr = b.vx * a.vy - b.vy * a.vx;
+            return cr < 0 && !same_direction_line(cr, b.vx, b.vy, a.vx, a.vy); // a lies clockwise of b inside the same open half turn
         };
         unsigned tried = 0;
         bool found = false;

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/polygon_near_ties.npz: boundary-candidate sets whose k-nearest-neighbour walk meets two neighbours at
-squared distances within 2^-42 of each other -- the steps where a selection on the 54-bit-distance + index key (the device's fast
-key; through round 5 also the host class's order) and the (distance, index) order of the polygon oracle part ways.  Four sets come
-out of the CPU extraction oracle on perturbed synthetic frames (found by a 42 785-plane sweep, round 6); the fifth was met on an
-MI355X (profiles/polygon_vs_oracle.py 1024 31 with POLY_DUMP: a device-rendered frame, so its candidates are kept as data in
-polygon_near_tie_device_dump.npz).  Expected outputs: the polygon oracle's ring, area, flags and k for every set.
+"""Regenerates tests/golden/polygon_near_ties.npz: boundary-candidate sets whose k-nearest-neighbour walk meets a near-tie that the
+product used to decide differently from the polygon oracle (round 6 sweeps, profiles/r06_polygon_cpu_sweep.txt):
+  * sets 0-3 and the first device dump: two neighbours at squared distances within 2^-42 of each other -- a selection on the
+    54-bit-distance + index key (the device's fast key; through round 5 also the host class's order) against (distance, index);
+  * sets 4-5 and the second device dump: two directions less than 4e-16 rad apart (a neighbour on the line of the previous edge,
+    two neighbours on one ray): the reference's atan2 angles + DBL_EPSILON slack call them equal, an exact cross product does not.
+The numbered sets come out of the CPU extraction oracle on perturbed synthetic frames; the dumps were met on an MI355X
+(profiles/polygon_vs_oracle.py 1024 31 / 32 with POLY_DUMP: device-rendered frames, so their candidates are kept as data in
+polygon_near_tie_device_dump*.npz).  Expected outputs: the polygon oracle's ring, area, flags and k for every set.
 
 usage: python tests/golden/make_polygon_near_ties.py
 """
@@ -24,7 +27,8 @@ from cape_amd import synth  # noqa: E402
 
 # (scene, first seed of the run, frame number in the run, output plane): frame k of a run is scene(seed = first + k // 16,
 # frame = 7 k mod 900), damaged by mode k mod 4 with ONE generator per run (so the draws of the frames before it are replayed)
-CASES = [("room", 17, 343, 1), ("room", 2017, 329, 0), ("tumlike", 6017, 45, 3), ("facets", 6017, 36, 1)]
+CASES = [("room", 17, 343, 1), ("room", 2017, 329, 0), ("tumlike", 6017, 45, 3), ("facets", 6017, 36, 1),
+         ("facets", 51017, 681, 2), ("facets", 52017, 1383, 4)]
 
 
 def frame_of(scene, seed0, k_wanted):
@@ -58,8 +62,9 @@ def main():
         r = O.Oracle(640, 480, cylinders=False, **intr).run(frame_of(scene, seed0, k))
         nrm = r.planes[i, 0:3].copy()
         sets.append((f"{scene}_{seed0}_{k}_{i}", r.boundary[i].copy(), nrm, nrm * (-r.planes[i, 3])))
-    dump = np.load(os.path.join(HERE, "polygon_near_tie_device_dump.npz"))
-    sets.append(("device_tunnel_31_768_30_0", dump["pts"], dump["normal"], dump["center"]))
+    for name, path in (("device_tunnel_31_768_30_0", "polygon_near_tie_device_dump.npz"), ("device_room_32_768_24_0", "polygon_near_tie_device_dump2.npz")):
+        dump = np.load(os.path.join(HERE, path))
+        sets.append((name, dump["pts"], dump["normal"], dump["center"]))
     out["names"] = np.array([s[0] for s in sets])
     for j, (name, pts, nrm, ctr) in enumerate(sets):
         ref = P.Polygon.from_points(pts, nrm, ctr)

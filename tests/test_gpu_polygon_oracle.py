@@ -315,9 +315,10 @@ def test_hull_that_touches_itself_on_the_device(P):
 
 
 def test_neighbours_at_nearly_equal_distances_on_the_device(P):
-    """tests/golden/polygon_near_ties.npz through cape_debug_polygon: the walk's fast key orders two neighbours whose squared
-    distances agree in their upper 54 bits by index; the kernel notices (`sameBucket`) and selects that step again on the full bit
-    patterns, so the ring is the oracle's -- which takes the nearer neighbour first, like the reference's nearest-first list."""
+    """tests/golden/polygon_near_ties.npz through cape_debug_polygon.  Distances: the walk's fast key orders two neighbours whose
+    squared distances agree in their upper 54 bits by index; the kernel notices (`sameBucket`) and selects that step again on the
+    full bit patterns (the re-inserted start point under the id n).  Directions: closer than 2 DBL_EPSILON they are one direction
+    (same_direction_line).  Either way the ring is the oracle's."""
     import cape_amd
     from cape_amd import Extractor, synth
     from test_polygon_oracle import _near_ties

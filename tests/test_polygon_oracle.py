@@ -376,10 +376,12 @@ def _near_ties():
 
 
 def test_neighbours_at_nearly_equal_distances_golden(P):
-    """tests/golden/polygon_near_ties.npz: five candidate sets whose walk meets two neighbours at squared distances within 2^-42 of
-    each other.  FLANN hands the neighbours over nearest first (concave_fitting.cpp:258-288), so the nearer one leads however small
-    the difference; the oracle orders by (distance, index) and these fixtures pin its rings over time.  (The product selected on
-    a key that carried the index in the distance's ten lowest bits through round 5 and built other hulls for all five.)"""
+    """tests/golden/polygon_near_ties.npz: eight candidate sets whose walk meets a near-tie -- two neighbours at squared distances
+    within 2^-42 of each other (FLANN hands the neighbours over nearest first, concave_fitting.cpp:258-288: the nearer one leads
+    however small the difference), or two directions less than 4e-16 rad apart (the reference's atan2 angles + DBL_EPSILON slack
+    call them equal: nearest first, and a neighbour on the line of the previous edge has the angle 0, :296-315).  The oracle's
+    rings are pinned here over time.  (Through round 5 the product selected on a key that carried the index in the distance's ten
+    lowest bits and compared directions by exact cross products: other hulls for all eight.)"""
     for name, pts, nrm, ctr, ring, area, flags, k in _near_ties():
         r = P.Polygon.from_points(pts, nrm, ctr)
         assert r.flags == flags and r.k_used == k, name
@@ -388,7 +390,7 @@ def test_neighbours_at_nearly_equal_distances_golden(P):
 
 
 def test_host_class_takes_the_nearer_of_two_nearly_equidistant_neighbours(P):
-    """The same five sets through the product's host class (libcape_primitives.so, CPU code): ring identical to the oracle's."""
+    """The same sets through the product's host class (libcape_primitives.so, CPU code): ring identical to the oracle's."""
     import ctypes as C
     import os
 
