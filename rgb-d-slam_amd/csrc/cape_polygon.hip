@@ -289,13 +289,9 @@ __device__ __forceinline__ int wave_argmin2(double a, double b, int idx)
 // (the product test sits behind WAVE-UNIFORM branches: left to itself the compiler turns the cheap first test into a select and
 //  pays the seven products on every comparison -- the walk measured 20 % slower)
 #ifndef CAPE_POLY_EPS
-#define CAPE_POLY_EPS 1 // A/B knob: 0 = exact cross products only (round 5), 2 = the products as an out-of-line function
+#define CAPE_POLY_EPS 1 // A/B knob: 0 = exact cross products only (round 5)
 #endif
-#if CAPE_POLY_EPS == 2
-__device__ __attribute__((noinline)) bool same_direction_products(double cr, double ax, double ay, double bx, double by)
-#else
 __device__ __forceinline__ bool same_direction_products(double cr, double ax, double ay, double bx, double by)
-#endif
 {
     constexpr double kEps2 = 1.9721522630525295135293214132069655741830160877724e-31; // 2^-102 = (2 DBL_EPSILON)^2
     return cr * cr <= kEps2 * ((ax * ax + ay * ay) * (bx * bx + by * by));
@@ -314,15 +310,18 @@ __device__ __forceinline__ int turn_class(double px, double py, double vx, doubl
     return cls;
 }
 // does candidate a turn further clockwise from P than candidate b (strictly)?  (uniform arguments: read out of the candidates' lanes)
-// The scan below runs the plain form -- the sign of one cross product -- and notes in `near` when a comparison came close enough for
-// the slack to matter (rare: a few steps in a thousand); that candidate scan is then repeated with the careful form.  A branch per
-// comparison instead cost the walk 15 % (profiles/r06_polygon_eps_ab.txt).
-__device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int cb, double bx, double by, bool& near)
+// The scan below runs this plain form -- the sign of one cross product, a total order inside an open half turn -- and then checks, every
+// untried candidate on its own lane, whether anything points within 1e-3 of a cross product of the winner's direction; only then (a few
+// steps in a thousand) is the scan repeated with the careful form.  (If nothing does, the winner is the plain maximum and compares the
+// same way under both forms with every candidate, so the careful scan would elect it too.)  Bookkeeping inside the comparisons cost
+// the walk 6 %, a branch per comparison 15 % (profiles/r06_polygon_eps_ab.txt).
+__device__ __forceinline__ bool turns_further(int ca, double ax, double ay, int cb, double bx, double by)
 {
-    const double cr = bx * ay - by * ax; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
-    const bool sameOpenHalf = ca == cb && (ca & 1);
-    near |= CAPE_POLY_EPS != 0 && sameOpenHalf && cr < 0 && cr > -1e-3; // (the same test on cr's high word alone measured slower)
-    return ca != cb ? ca > cb : (sameOpenHalf && cr < 0);
+    if (ca != cb)
+        return ca > cb;
+    if (ca == 0 || ca == 2)
+        return false;
+    return (bx * ay - by * ax) < 0; // cross(Vb, Va) < 0: Va lies clockwise of Vb inside the same open half turn
 }
 __device__ __forceinline__ bool turns_further_careful(int ca, double ax, double ay, int cb, double bx, double by)
 {
@@ -588,14 +587,13 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
         {
             int b = -1, bClass = 0;
             double bVx = 0.0, bVy = 0.0;
-            bool near = false;
             for (int c = 0; c < kk; ++c)
             {
                 if ((tried >> c) & 1u)
                     continue;
                 const int cClass = __builtin_amdgcn_readlane(myClass, c);
                 const double cVx = readlane_f64(myVx, c), cVy = readlane_f64(myVy, c);
-                if (b < 0 || turns_further(cClass, cVx, cVy, bClass, bVx, bVy, near))
+                if (b < 0 || turns_further(cClass, cVx, cVy, bClass, bVx, bVy))
                 {
                     b = c;
                     bClass = cClass;
@@ -603,7 +601,9 @@ __device__ CAPE_WALK_ATTR bool concave_hull_k(const PolyLds& L, int n, int first
                     bVy = cVy;
                 }
             }
-            if (__builtin_amdgcn_readfirstlane((int)near))
+            const bool nearWinner = CAPE_POLY_EPS != 0 && lane < kk && lane != b && !((tried >> lane) & 1u) && myClass == bClass && (bClass & 1) &&
+                                    fabs(bVx * myVy - bVy * myVx) < 1e-3;
+            if (__any(nearWinner))
             {
                 b = -1;
                 for (int c = 0; c < kk; ++c)
