@@ -330,3 +330,21 @@ def test_neighbours_at_nearly_equal_distances_on_the_device(P):
         assert bool(pol["flags"] & cape_amd.POLY_DISSOLVED) == bool(flags & P.DISSOLVED), name
         assert np.array_equal(verts, ring), name
     ex.close()
+
+
+def test_direction_gray_zone_divergence_on_the_device(P):
+    """tests/test_polygon_oracle.py::test_direction_gray_zone_divergence_is_pinned on the device: the same 10-vertex ring as the host
+    class (the oracle's has 7), IoU > 0.995."""
+    import os
+
+    from cape_amd import Extractor, synth
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "polygon_gray_zone_device_dump.npz"))
+    ex = Extractor(640, 480, max_batch=1, **synth.DEFAULT_INTRINSICS)
+    pol, verts = ex.debug_polygon(d["pts"], d["normal"], d["center"])
+    ex.close()
+    assert np.array_equal(verts, d["product_ring"])
+    ref = P.Polygon.from_points(d["pts"], d["normal"], d["center"])
+    mine = P.Polygon(verts, pol["x_axis"], pol["y_axis"], pol["center"])
+    inter = mine.inter_area(ref)
+    assert inter / (mine.area + ref.area - inter) > 0.995

@@ -413,3 +413,41 @@ def test_host_class_takes_the_nearer_of_two_nearly_equidistant_neighbours(P):
                                    out.ctypes.data_as(vp), len(out), C.byref(cnt), C.byref(a), xa.ctypes.data_as(vp), ya.ctypes.data_as(vp), C.byref(valid))
         assert rc == 0 and bool(valid.value) == bool(flags & P.VALID), name
         assert np.array_equal(out[: cnt.value], ring), name
+
+
+def test_direction_gray_zone_divergence_is_pinned(P):
+    """The one plane in 564 609 (profiles/r06_polygon_vs_oracle_long.txt, seed 118) whose ring is not the oracle's, kept as data: at one
+    step of the k = 3 walk two neighbours lie on one ray to 3.0e-16 rad; glibc's two atan2 angles (near 2 pi: an ulp is 8.9e-16) come out
+    one ulp apart, more than the reference's DBL_EPSILON slack, so the reference takes the FARTHER one first, its k = 3 walk then fails
+    and k = 7 gives a 7-vertex ring.  The product calls directions within 2 DBL_EPSILON equal (that decides the three other gray-zone
+    planes met in 9e5 like the reference; an exact sign decides this one right and those three wrong), takes the nearer one, and its
+    k = 3 hull stands: 10 vertices.  Measured here so that it cannot grow unnoticed: IoU > 0.995, area within 0.1 %."""
+    import ctypes as C
+    import os
+
+    import cape_amd
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = np.load(os.path.join(here, "golden", "polygon_gray_zone_device_dump.npz"))
+    ref = P.Polygon.from_points(d["pts"], d["normal"], d["center"])
+    assert np.array_equal(ref.ring, d["oracle_ring"]) and ref.k_used == 7
+    path = os.path.join(os.path.dirname(here), "rgb-d-slam_amd", "lib", "libcape_primitives.so")
+    if not os.path.exists(path) or not os.path.exists(os.path.join(os.path.dirname(path), "libcape_hip.so")):
+        pytest.skip("host library not built")
+    cape_amd.load_library()
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.cape_host_polygon.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), vp, vp, C.POINTER(C.c_int)]
+    pts = np.ascontiguousarray(d["pts"], np.float64)
+    out = np.zeros((len(pts), 2))
+    cnt, valid, a = C.c_int(0), C.c_int(0), C.c_double(0)
+    xa, ya = np.zeros(3), np.zeros(3)
+    rc = lib.cape_host_polygon(pts.ctypes.data_as(vp), len(pts), np.ascontiguousarray(d["normal"]).ctypes.data_as(vp), np.ascontiguousarray(d["center"]).ctypes.data_as(vp),
+                               out.ctypes.data_as(vp), len(out), C.byref(cnt), C.byref(a), xa.ctypes.data_as(vp), ya.ctypes.data_as(vp), C.byref(valid))
+    assert rc == 0 and valid.value
+    ring = out[: cnt.value]
+    assert np.array_equal(ring, d["product_ring"])  # (= what the device built on the MI355X that met it)
+    mine = P.Polygon(ring, xa, ya, d["center"])
+    inter = mine.inter_area(ref)
+    assert inter / (mine.area + ref.area - inter) > 0.995
+    assert abs(a.value / ref.area - 1.0) < 1e-3
